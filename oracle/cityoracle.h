@@ -1,0 +1,95 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY (see goldilocks.h). CPU restatement of the
+ * plonky2 0.2.2 proving primitives that city-rollup reaches through
+ * `CircuitData::prove`.
+ *
+ * Parity status: Poseidon permutation / sponge / two_to_one / Merkle path
+ * direction are PINNED against the reference's own known-answer data
+ * (tests/golden/, see tests/test_oracle_golden.py). NTT/LDE have no vectors in
+ * the reference tree; they are exact integer arithmetic and are pinned only
+ * indirectly (FRI fold consistency of the reference proofs in
+ * qbench_data/example.bin, tests/test_oracle_fri_reference.py).
+ */
+#ifndef CITY_ORACLE_H
+#define CITY_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- field (exported for ctypes-based tests) ---- */
+uint64_t or_gl_add(uint64_t a, uint64_t b);
+uint64_t or_gl_sub(uint64_t a, uint64_t b);
+uint64_t or_gl_mul(uint64_t a, uint64_t b);
+uint64_t or_gl_mul_slow(uint64_t a, uint64_t b);
+uint64_t or_gl_inv(uint64_t a);
+uint64_t or_gl_pow(uint64_t a, uint64_t e);
+uint64_t or_gl_root_of_unity(int log_n);
+
+/* ---- Poseidon-Goldilocks (width 12, x^7, 4+22+4 rounds) ---- */
+/* The 360 round constants, regenerated from the published procedure
+ * (ChaCha8 seeded with 0, uniform in [0,p)). out[360]. */
+void or_poseidon_round_constants(uint64_t *out);
+/* MDS: circulant first row (12) and diagonal (12). */
+void or_poseidon_mds(uint64_t *circ, uint64_t *diag);
+void or_poseidon_permute(uint64_t state[12]);
+void or_poseidon_permute_many(uint64_t *states, size_t count);
+
+/* PoseidonHash::hash_no_pad — overwrite-mode sponge, rate 8
+ * (call sites: city_crypto/src/hash/traits/hasher.rs:82-95). */
+void or_hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4]);
+/* hash_or_noop: n <= 4 -> zero-padded copy, else hash_no_pad. */
+void or_hash_or_noop(const uint64_t *in, size_t n, uint64_t out[4]);
+/* PoseidonHash::two_to_one (city_crypto/src/hash/traits/hasher.rs:77-80). */
+void or_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]);
+
+/* ---- Merkle tree with cap (plonky2 MerkleTree::new) ----
+ * leaves: n_leaves rows of leaf_len felts, row-major, in TREE order (the caller
+ * applies any bit-reversal). digests_out (optional, may be NULL) receives all
+ * levels below the cap, level 0 (leaf digests) first: n_leaves*4, then
+ * n_leaves/2*4, ... down to 2^(cap_height+1) nodes. cap_out: 2^cap_height * 4. */
+void or_merkle_tree(const uint64_t *leaves, size_t n_leaves, size_t leaf_len,
+                    int cap_height, uint64_t *digests_out, uint64_t *cap_out);
+/* same, leaves given column-major: element j of leaf i at cols[j*col_stride + i] */
+void or_merkle_tree_cols(const uint64_t *cols, size_t n_leaves, size_t leaf_len,
+                         size_t col_stride, int cap_height, uint64_t *digests_out,
+                         uint64_t *cap_out);
+/* Verify a Merkle path against a cap: returns 1 if ok. Path direction follows
+ * city_crypto/src/hash/merkle/core.rs:200-213 (bit i of index == 0 -> H(cur, sib)). */
+int or_merkle_verify(const uint64_t *leaf, size_t leaf_len, size_t index,
+                     const uint64_t *siblings, size_t n_siblings,
+                     const uint64_t *cap, int cap_height);
+
+/* ---- NTT over Goldilocks (plonky2 fft / ifft / coset LDE semantics) ----
+ * natural order in, natural order out; omega = g^((p-1)/n), g = 7. */
+void or_ntt(uint64_t *a, int log_n);
+void or_intt(uint64_t *a, int log_n);
+/* coefficients (n = 2^log_n) -> evaluations on shift*<omega_{n*2^rate_bits}>,
+ * natural order, out has n << rate_bits entries. */
+void or_coset_lde(const uint64_t *coeffs, int log_n, int rate_bits, uint64_t shift,
+                  uint64_t *out);
+/* in-place bit-reversal permutation of n = 2^log_n u64 */
+void or_bit_reverse(uint64_t *a, int log_n);
+/* O(n^2) DFT for small-size cross-checks */
+void or_dft_naive(const uint64_t *in, uint64_t *out, int log_n);
+
+/* ---- PolynomialBatch::from_values ----
+ * values: k polys, each n = 2^log_n values in natural order (poly-major).
+ * coeffs_out (k*n, optional), lde_out (k * n<<rate_bits, poly-major, BIT-REVERSED
+ * index order == Merkle leaf order; optional), cap_out (2^cap_height*4). */
+void or_commit_batch(const uint64_t *values, size_t k, int log_n, int rate_bits,
+                     int cap_height, uint64_t *coeffs_out, uint64_t *lde_out,
+                     uint64_t *digests_out, uint64_t *cap_out);
+
+/* number of worker threads the oracle uses for the batch entry points
+ * (or_poseidon_permute_many, or_merkle_tree*, or_commit_batch); default 1 */
+void or_set_threads(int n);
+int or_get_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Extract known-answer DATA from the reference tree into tests/golden/.
+
+Run once in the build container (where /root/reference exists):
+
+    python3 tests/golden/make_golden.py
+
+Everything written is data (inputs / expected outputs) that the reference's own
+tests and fixtures hold for the proving hot path; no reference source text is
+kept. Sources (paths relative to /root/reference):
+
+  P1/P2  city_crypto/src/hash/cached_zero_hashes.rs:11-2065
+         128 iterated two_to_one zero hashes + 128 iterated marked-leaf hashes
+  P3     city_rollup_core_orchestrator/src/lib.rs:52
+         circuit fingerprints: root = two_to_one(leaf_fp, aggregator_fp)
+         (rule: city_crypto/src/hash/merkle/treeprover/mod.rs:358-359)
+  P4     city_common_circuit/src/hash/merkle/gadgets/merkle_proof.rs:243-1121
+         city_common_circuit/src/hash/merkle/gadgets/delta_merkle_proof.rs:573-877
+  P6/P7  qbench_data/example.bin  (bincode BlockProofStoreDump,
+         city_rollup_core_worker_qbench/src/dump.rs:15-26)
+"""
+import json
+import os
+import re
+import struct
+import sys
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def hex_to_felts(h):
+    """QHashOut hex = reversed little-endian bytes of the 4 u64
+    (city_crypto/src/hash/qhashout.rs:28-58)."""
+    b = bytes.fromhex(h)[::-1]
+    b = b + b"\0" * (32 - len(b))
+    return list(struct.unpack("<4Q", b))
+
+
+def zero_hashes():
+    src = open(f"{REF}/city_crypto/src/hash/cached_zero_hashes.rs").read()
+    vals = [int(x) for x in re.findall(r"GoldilocksField\((\d+)\)", src)]
+    # four tables of 128 hashes x 4 felts: HashOut plain, HashOut marked, QHashOut plain, QHashOut marked
+    assert len(vals) == 4 * 128 * 4, len(vals)
+    t = [[vals[(k * 128 + i) * 4:(k * 128 + i) * 4 + 4] for i in range(128)] for k in range(4)]
+    assert t[0] == t[2] and t[1] == t[3]
+    return {"two_to_one": t[0], "marked_leaf": t[1]}
+
+
+def fingerprints():
+    src = open(f"{REF}/city_rollup_core_orchestrator/src/lib.rs").read()
+    lits = re.findall(r'r#"\s*(\{"network_magic".*?\})\s*"#', src, re.S)
+    out = []
+    seen = set()
+    for lit in lits:
+        try:
+            d = json.loads(lit)
+        except json.JSONDecodeError:
+            continue
+        for k, v in d.items():
+            if isinstance(v, dict) and "leaf_fingerprint" in v:
+                key = (v["leaf_fingerprint"], v["aggregator_fingerprint"])
+                if key in seen:
+                    continue
+                seen.add(key)
+                out.append({
+                    "name": k,
+                    "leaf": hex_to_felts(v["leaf_fingerprint"]),
+                    "aggregator": hex_to_felts(v["aggregator_fingerprint"]),
+                    "root": hex_to_felts(v["allowed_circuit_hashes_root"]),
+                })
+    return out
+
+
+def json_cases(path):
+    src = open(f"{REF}/{path}").read()
+    m = re.search(r'TEST_CASES_JSON: &str = r#"(.*?)"#', src, re.S)
+    cases = json.loads(m.group(1))
+    out = []
+    for c in cases:
+        o = {"index": c["index"], "siblings": [hex_to_felts(s) for s in c["siblings"]]}
+        for k in ("root", "value", "old_root", "old_value", "new_root", "new_value"):
+            if k in c:
+                o[k] = hex_to_felts(c[k])
+        out.append(o)
+    return out
+
+
+class Rd:
+    def __init__(self, b, o=0):
+        self.b, self.o = b, o
+
+    def u8(self):
+        v = self.b[self.o]
+        self.o += 1
+        return v
+
+    def u32(self):
+        v = struct.unpack_from("<I", self.b, self.o)[0]
+        self.o += 4
+        return v
+
+    def u64(self):
+        v = struct.unpack_from("<Q", self.b, self.o)[0]
+        self.o += 8
+        return v
+
+    def raw(self, n):
+        v = self.b[self.o:self.o + n]
+        self.o += n
+        return v
+
+    def qhash(self):
+        n = self.u64()
+        assert n == 64, n
+        return hex_to_felts(self.raw(64).decode())
+
+    def delta(self):
+        d = {"old_root": self.qhash(), "old_value": self.qhash(), "new_root": self.qhash(),
+             "new_value": self.qhash(), "index": self.u64()}
+        d["siblings"] = [self.qhash() for _ in range(self.u64())]
+        return d
+
+
+def parse_key(k):
+    topic, goal, ctype, group, sub, task, dtype, didx = struct.unpack("<BQBIIIBB", k)
+    return dict(topic=topic, goal_id=goal, circuit_type=ctype, group_id=group, sub_group_id=sub,
+                task_index=task, data_type=dtype, data_index=didx)
+
+
+def example_bin():
+    b = open(f"{REF}/qbench_data/example.bin", "rb").read()
+    r = Rd(b)
+    cfg = {"checkpoint_id": r.u64(), "rpc_node_id": r.u32(),
+           "job_config": [r.u64() for _ in range(6)]}
+    n = r.u64()
+    entries = []
+    for _ in range(n):
+        key = r.raw(24)
+        ln = r.u64()
+        entries.append((key, r.raw(ln)))
+    n_counters = r.u64()
+    assert n_counters == 0 and r.o == len(b), (n_counters, r.o, len(b))
+
+    index = []
+    deltas = []
+    proofs = []
+    for key, val in entries:
+        k = parse_key(key)
+        index.append({**k, "key": key.hex(), "len": len(val)})
+        # op-leaf witnesses: one or two DeltaMerkleProofCore (job_witnesses/op.rs:58-253)
+        if k["data_type"] == 0 and k["topic"] == 0 and k["circuit_type"] in (0, 2, 10):
+            rr = Rd(val)
+            deltas.append({"circuit_type": k["circuit_type"], "task": k["task_index"],
+                           "proofs": [rr.delta()], "allowed_circuit_hashes_root": rr.qhash()})
+            assert rr.o == len(val)
+        elif k["data_type"] == 0 and k["topic"] == 0 and k["circuit_type"] in (6, 8):
+            rr = Rd(val)
+            deltas.append({"circuit_type": k["circuit_type"], "task": k["task_index"],
+                           "proofs": [rr.delta(), rr.delta()],
+                           "allowed_circuit_hashes_root": rr.qhash()})
+            assert rr.o + 24 == len(val)
+        elif k["data_type"] == 1 and len(val) > 0:
+            proofs.append((k, val))
+    return cfg, index, deltas, proofs
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("reference tree not present; golden files are already committed")
+    json.dump(zero_hashes(), open(f"{OUT}/poseidon_zero_hashes.json", "w"))
+    json.dump(fingerprints(), open(f"{OUT}/circuit_fingerprints.json", "w"), indent=1)
+    json.dump(json_cases("city_common_circuit/src/hash/merkle/gadgets/merkle_proof.rs"),
+              open(f"{OUT}/merkle_proofs.json", "w"))
+    json.dump(json_cases("city_common_circuit/src/hash/merkle/gadgets/delta_merkle_proof.rs"),
+              open(f"{OUT}/delta_merkle_proofs.json", "w"))
+    cfg, index, deltas, proofs = example_bin()
+    json.dump({"config": cfg, "entries": index}, open(f"{OUT}/example_dump_index.json", "w"))
+    json.dump(deltas, open(f"{OUT}/example_delta_merkle.json", "w"))
+    # reference ProofWithPublicInputs blobs (bincode), kept verbatim as binary data:
+    # the first two WrappedSignatureProof (circuit_type 64) and the first Secp256K1SignatureProof (65)
+    kept = []
+    for want, cnt in ((64, 2), (65, 1)):
+        sel = [(k, v) for k, v in proofs if k["circuit_type"] == want][:cnt]
+        for k, v in sel:
+            name = f"example_proof_ct{want}_g{k['group_id']}_t{k['task_index']}.bin"
+            open(f"{OUT}/{name}", "wb").write(v)
+            kept.append({"file": name, **k, "len": len(v)})
+    json.dump(kept, open(f"{OUT}/example_proofs.json", "w"), indent=1)
+    print("zero hashes 2x128; fingerprints", len(fingerprints()), "; example entries", len(index),
+          "; delta witnesses", len(deltas), "; proofs kept", len(kept), "of", len(proofs))
+
+
+if __name__ == "__main__":
+    main()

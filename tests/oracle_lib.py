@@ -1,0 +1,195 @@
+"""ctypes loader for the CPU oracle (oracle/libcityoracle.so) — test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+P = 0xFFFFFFFF00000001
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = os.path.join(ORACLE_DIR, "libcityoracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("cityoracle.c", "cityoracle.h", "goldilocks.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        build()
+    L = ctypes.CDLL(so)
+    u64, sz, i = ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int
+    sigs = {
+        "or_gl_add": (u64, [u64, u64]), "or_gl_sub": (u64, [u64, u64]),
+        "or_gl_mul": (u64, [u64, u64]), "or_gl_mul_slow": (u64, [u64, u64]),
+        "or_gl_inv": (u64, [u64]), "or_gl_pow": (u64, [u64, u64]),
+        "or_gl_root_of_unity": (u64, [i]),
+        "or_poseidon_round_constants": (None, [_u64p]),
+        "or_poseidon_mds": (None, [_u64p, _u64p]),
+        "or_poseidon_permute": (None, [_u64p]),
+        "or_poseidon_permute_many": (None, [_u64p, sz]),
+        "or_hash_no_pad": (None, [_u64p, sz, _u64p]),
+        "or_hash_or_noop": (None, [_u64p, sz, _u64p]),
+        "or_two_to_one": (None, [_u64p, _u64p, _u64p]),
+        "or_merkle_tree": (None, [_u64p, sz, sz, i, _u64p, _u64p]),
+        "or_merkle_tree_cols": (None, [_u64p, sz, sz, sz, i, _u64p, _u64p]),
+        "or_merkle_verify": (i, [_u64p, sz, sz, _u64p, sz, _u64p, i]),
+        "or_ntt": (None, [_u64p, i]), "or_intt": (None, [_u64p, i]),
+        "or_coset_lde": (None, [_u64p, i, i, u64, _u64p]),
+        "or_bit_reverse": (None, [_u64p, i]),
+        "or_dft_naive": (None, [_u64p, _u64p, i]),
+        "or_commit_batch": (None, [_u64p, sz, i, i, i, _u64p, _u64p, _u64p, _u64p]),
+        "or_set_threads": (None, [i]), "or_get_threads": (i, []),
+    }
+    for name, (res, args) in sigs.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+def ptr(a):
+    if a is None:
+        return None
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_u64p)
+
+
+def arr(x):
+    return np.ascontiguousarray(np.array(x, dtype=np.uint64))
+
+
+# ---- thin numpy helpers -----------------------------------------------------
+def permute(state):
+    s = arr(state).copy()
+    lib().or_poseidon_permute(ptr(s))
+    return s
+
+
+def permute_many(states):
+    s = arr(states).copy()
+    lib().or_poseidon_permute_many(ptr(s), s.size // 12)
+    return s
+
+
+def hash_no_pad(x):
+    x = arr(x)
+    o = np.zeros(4, np.uint64)
+    lib().or_hash_no_pad(ptr(x), x.size, ptr(o))
+    return o
+
+
+def hash_or_noop(x):
+    x = arr(x)
+    o = np.zeros(4, np.uint64)
+    lib().or_hash_or_noop(ptr(x), x.size, ptr(o))
+    return o
+
+
+def two_to_one(l, r):
+    l, r = arr(l), arr(r)
+    o = np.zeros(4, np.uint64)
+    lib().or_two_to_one(ptr(l), ptr(r), ptr(o))
+    return o
+
+
+def merkle_tree(leaves, cap_height, want_digests=False):
+    leaves = arr(leaves)
+    n, k = leaves.shape
+    cap = np.zeros((1 << cap_height, 4), np.uint64)
+    dig = None
+    if want_digests:
+        tot = 0
+        m = n
+        while m > (1 << cap_height):
+            tot += m
+            m //= 2
+        dig = np.zeros((tot, 4), np.uint64)
+    lib().or_merkle_tree(ptr(leaves), n, k, cap_height, ptr(dig), ptr(cap))
+    return (cap, dig) if want_digests else cap
+
+
+def merkle_tree_cols(cols, cap_height, want_digests=False):
+    cols = arr(cols)
+    k, n = cols.shape
+    cap = np.zeros((1 << cap_height, 4), np.uint64)
+    dig = None
+    if want_digests:
+        tot, m = 0, n
+        while m > (1 << cap_height):
+            tot += m
+            m //= 2
+        dig = np.zeros((tot, 4), np.uint64)
+    lib().or_merkle_tree_cols(ptr(cols), n, k, n, cap_height, ptr(dig), ptr(cap))
+    return (cap, dig) if want_digests else cap
+
+
+def merkle_verify(leaf, index, siblings, cap, cap_height):
+    leaf, siblings, cap = arr(leaf), arr(siblings), arr(cap)
+    return bool(lib().or_merkle_verify(ptr(leaf), leaf.size, index, ptr(siblings),
+                                       siblings.size // 4, ptr(cap), cap_height))
+
+
+def ntt(a):
+    a = arr(a).copy()
+    lib().or_ntt(ptr(a), int(a.size).bit_length() - 1)
+    return a
+
+
+def intt(a):
+    a = arr(a).copy()
+    lib().or_intt(ptr(a), int(a.size).bit_length() - 1)
+    return a
+
+
+def coset_lde(coeffs, rate_bits, shift=7):
+    c = arr(coeffs)
+    out = np.zeros(c.size << rate_bits, np.uint64)
+    lib().or_coset_lde(ptr(c), int(c.size).bit_length() - 1, rate_bits, shift, ptr(out))
+    return out
+
+
+def bit_reverse(a):
+    a = arr(a).copy()
+    lib().or_bit_reverse(ptr(a), int(a.size).bit_length() - 1)
+    return a
+
+
+def commit_batch(values, rate_bits, cap_height, want=("coeffs", "lde", "cap")):
+    v = arr(values)
+    k, n = v.shape
+    log_n = int(n).bit_length() - 1
+    N = n << rate_bits
+    coeffs = np.zeros((k, n), np.uint64) if "coeffs" in want else None
+    lde = np.zeros((k, N), np.uint64) if "lde" in want else None
+    cap = np.zeros((1 << cap_height, 4), np.uint64)
+    dig = None
+    if "digests" in want:
+        tot, m = 0, N
+        while m > (1 << cap_height):
+            tot += m
+            m //= 2
+        dig = np.zeros((tot, 4), np.uint64)
+    lib().or_commit_batch(ptr(v), k, log_n, rate_bits, cap_height, ptr(coeffs), ptr(lde), ptr(dig),
+                          ptr(cap))
+    return {"coeffs": coeffs, "lde": lde, "cap": cap, "digests": dig}
+
+
+def splitmix64_felts(seed, n):
+    """Deterministic canonical field elements: splitmix64(seed + i) mod p."""
+    i = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) + i) * np.uint64(1)  # copy
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z % np.uint64(P)
