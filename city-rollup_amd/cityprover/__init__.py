@@ -1,0 +1,290 @@
+"""Host-side binding of libcityprover_hip.so (the C ABI in include/cityprover.h).
+
+This is plumbing only: every computation happens in the HIP library. There is no CPU fallback —
+constructing a `Prover` without a GPU raises `CityProverError`.
+
+The method names mirror what the reference reaches through plonky2 (`PolynomialBatch::from_values`,
+`MerkleTree::new`, `PoseidonHash::{hash_no_pad,two_to_one}`, `fft`/`ifft`/`coset_fft`), see
+SURVEY.md §8(a).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+P = 0xFFFFFFFF00000001
+NTT_INVERSE, NTT_BITREV_OUT, NTT_COSET, NTT_BITREV_IN = 1, 2, 4, 8
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol declared in include/cityprover.h
+ABI = {
+    "cp_abi_version": (ctypes.c_int, []),
+    "cp_device_count": (ctypes.c_int, []),
+    "cp_ctx_create": (_vp, [ctypes.c_int]),
+    "cp_ctx_destroy": (None, [_vp]),
+    "cp_last_error": (ctypes.c_char_p, [_vp]),
+    "cp_dev_alloc": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "cp_dev_free": (ctypes.c_int, [_vp, _vp]),
+    "cp_h2d": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "cp_d2h": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "cp_d2d": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "cp_sync": (ctypes.c_int, [_vp]),
+    "cp_event_create": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "cp_event_destroy": (ctypes.c_int, [_vp, _vp]),
+    "cp_event_record": (ctypes.c_int, [_vp, _vp]),
+    "cp_event_elapsed_ms": (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(ctypes.c_float)]),
+    "cp_ntt_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
+                                  ctypes.c_uint, ctypes.c_uint64]),
+    "cp_ntt": (ctypes.c_int, [_vp, _u64p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint,
+                              ctypes.c_uint64]),
+    "cp_lde_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint, _vp,
+                                  ctypes.c_size_t]),
+    "cp_poseidon_permute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    "cp_poseidon_permute": (ctypes.c_int, [_vp, _u64p, ctypes.c_size_t]),
+    "cp_hash_no_pad": (ctypes.c_int, [_vp, _u64p, ctypes.c_size_t, ctypes.c_size_t, _u64p]),
+    "cp_two_to_one": (ctypes.c_int, [_vp, _u64p, _u64p, ctypes.c_size_t, _u64p]),
+    "cp_merkle_cols_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_size_t,
+                                          ctypes.c_size_t, ctypes.c_int, _vp, _vp]),
+    "cp_merkle_cap": (ctypes.c_int, [_vp, _u64p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
+                                     _u64p]),
+    "cp_commit_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, _vp, _vp, _vp, _vp]),
+}
+
+
+class CityProverError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(build_if_missing=True):
+    """dlopen the in-tree HIP library; raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = _build.SO
+    if not os.path.exists(so):
+        if not build_if_missing:
+            raise CityProverError(f"{so} not built; run __graft_entry__.build()")
+        _build.build()
+    lib = ctypes.CDLL(so)
+    for name, (res, args) in ABI.items():
+        f = getattr(lib, name)  # AttributeError if the symbol is not exported
+        f.restype, f.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    assert isinstance(a, np.ndarray) and a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_u64p)
+
+
+def _as_u64(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.uint64))
+
+
+class DeviceBuffer:
+    """A u64 buffer in HBM owned by a Prover context."""
+
+    def __init__(self, prover, n_elems):
+        self.prover, self.n = prover, int(n_elems)
+        p = _vp()
+        prover._check(prover.lib.cp_dev_alloc(prover.ctx, self.n * 8, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = _as_u64(arr)
+        assert arr.size <= self.n
+        self.prover._check(self.prover.lib.cp_h2d(self.prover.ctx, self.ptr, arr.ctypes.data, arr.size * 8))
+        return self
+
+    def download(self, n=None, offset=0):
+        n = self.n - offset if n is None else int(n)
+        out = np.empty(n, np.uint64)
+        self.prover._check(self.prover.lib.cp_d2h(self.prover.ctx, out.ctypes.data, self.ptr + offset * 8, n * 8))
+        return out
+
+    def at(self, offset):
+        return self.ptr + offset * 8
+
+    def free(self):
+        if self.ptr:
+            self.prover._check(self.prover.lib.cp_dev_free(self.prover.ctx, self.ptr))
+            self.ptr = None
+
+
+class Prover:
+    """One context per GPU (one consumer per device)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        if self.lib.cp_device_count() <= 0:
+            raise CityProverError("no HIP device visible: cityprover has no CPU fallback")
+        self.ctx = self.lib.cp_ctx_create(device)
+        if not self.ctx:
+            raise CityProverError(self.lib.cp_last_error(None).decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.cp_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise CityProverError(f"[{rc}] " + self.lib.cp_last_error(self.ctx).decode())
+
+    # ---- memory / timing -----------------------------------------------------------------
+    def alloc(self, n_elems):
+        return DeviceBuffer(self, n_elems)
+
+    def to_device(self, arr):
+        arr = _as_u64(arr)
+        return DeviceBuffer(self, arr.size).upload(arr)
+
+    def sync(self):
+        self._check(self.lib.cp_sync(self.ctx))
+
+    def event(self):
+        e = _vp()
+        self._check(self.lib.cp_event_create(self.ctx, ctypes.byref(e)))
+        return e.value
+
+    def record(self, ev):
+        self._check(self.lib.cp_event_record(self.ctx, ev))
+
+    def elapsed_ms(self, e0, e1):
+        ms = ctypes.c_float()
+        self._check(self.lib.cp_event_elapsed_ms(self.ctx, e0, e1, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- device-resident entry points ----------------------------------------------------
+    def ntt_dev(self, buf_ptr, log_n, batch=1, stride=None, flags=0, shift=0):
+        stride = (1 << log_n) if stride is None else stride
+        self._check(self.lib.cp_ntt_dev(self.ctx, buf_ptr, log_n, batch, stride, flags, shift))
+
+    def lde_dev(self, coeffs_ptr, log_n, rate_bits, batch, out_ptr, shift=7, flags=NTT_BITREV_OUT,
+                in_stride=None, out_stride=None):
+        n = 1 << log_n
+        self._check(self.lib.cp_lde_dev(self.ctx, coeffs_ptr, in_stride or n, log_n, rate_bits, batch,
+                                        shift, flags, out_ptr, out_stride or (n << rate_bits)))
+
+    def poseidon_permute_dev(self, states_ptr, count):
+        self._check(self.lib.cp_poseidon_permute_dev(self.ctx, states_ptr, count))
+
+    def merkle_cols_dev(self, cols_ptr, n_leaves, leaf_len, cap_height, cap_ptr, digests_ptr=None,
+                        col_stride=None):
+        self._check(self.lib.cp_merkle_cols_dev(self.ctx, cols_ptr, n_leaves, leaf_len,
+                                                col_stride or n_leaves, cap_height, digests_ptr, cap_ptr))
+
+    def commit_dev(self, values_ptr, k, log_n, rate_bits, cap_height, lde_ptr, cap_ptr,
+                   coeffs_ptr=None, digests_ptr=None):
+        self._check(self.lib.cp_commit_dev(self.ctx, values_ptr, k, log_n, rate_bits, cap_height,
+                                           coeffs_ptr, lde_ptr, digests_ptr, cap_ptr))
+
+    # ---- host-array conveniences (numpy in / numpy out) -----------------------------------
+    def ntt(self, a, flags=0, shift=0):
+        a = _as_u64(a).copy()
+        batch = 1 if a.ndim == 1 else a.shape[0]
+        n = a.shape[-1]
+        log_n = int(n).bit_length() - 1
+        assert 1 << log_n == n
+        self._check(self.lib.cp_ntt(self.ctx, _ptr(a), log_n, batch, flags, shift))
+        return a
+
+    def intt(self, a, flags=0, shift=0):
+        return self.ntt(a, flags | NTT_INVERSE, shift)
+
+    def lde(self, coeffs, rate_bits, shift=7, bitrev=False):
+        c = _as_u64(coeffs)
+        c2 = c.reshape(1, -1) if c.ndim == 1 else c
+        k, n = c2.shape
+        log_n = int(n).bit_length() - 1
+        din, dout = self.to_device(c2), self.alloc(k * (n << rate_bits))
+        try:
+            self.lde_dev(din.ptr, log_n, rate_bits, k, dout.ptr, shift, NTT_BITREV_OUT if bitrev else 0)
+            out = dout.download().reshape(k, n << rate_bits)
+        finally:
+            din.free()
+            dout.free()
+        return out[0] if c.ndim == 1 else out
+
+    def poseidon_permute(self, states):
+        s = _as_u64(states).copy()
+        assert s.size % 12 == 0
+        self._check(self.lib.cp_poseidon_permute(self.ctx, _ptr(s), s.size // 12))
+        return s
+
+    def hash_no_pad(self, inputs):
+        x = _as_u64(inputs)
+        x2 = x.reshape(1, -1) if x.ndim == 1 else x
+        out = np.zeros((x2.shape[0], 4), np.uint64)
+        self._check(self.lib.cp_hash_no_pad(self.ctx, _ptr(x2), x2.shape[0], x2.shape[1], _ptr(out)))
+        return out[0] if x.ndim == 1 else out
+
+    def two_to_one(self, left, right):
+        l, r = _as_u64(left), _as_u64(right)
+        l2, r2 = l.reshape(-1, 4), r.reshape(-1, 4)
+        out = np.zeros_like(l2)
+        self._check(self.lib.cp_two_to_one(self.ctx, _ptr(l2), _ptr(r2), l2.shape[0], _ptr(out)))
+        return out.reshape(l.shape)
+
+    def merkle_cap(self, rows, cap_height):
+        rows = _as_u64(rows)
+        n, k = rows.shape
+        cap = np.zeros((1 << cap_height, 4), np.uint64)
+        self._check(self.lib.cp_merkle_cap(self.ctx, _ptr(rows), n, k, cap_height, _ptr(cap)))
+        return cap
+
+    def merkle_cols(self, cols, cap_height, want_digests=False):
+        cols = _as_u64(cols)
+        k, n = cols.shape
+        dc, dcap = self.to_device(cols), self.alloc(4 << cap_height)
+        nd = 2 * n - (2 << cap_height)
+        dd = self.alloc(nd * 4) if want_digests and nd > 0 else None
+        try:
+            self.merkle_cols_dev(dc.ptr, n, k, cap_height, dcap.ptr, dd.ptr if dd else None)
+            cap = dcap.download().reshape(-1, 4)
+            dig = dd.download().reshape(-1, 4) if dd else None
+        finally:
+            dc.free()
+            dcap.free()
+            if dd:
+                dd.free()
+        return (cap, dig) if want_digests else cap
+
+    def commit(self, values, rate_bits, cap_height, want=("coeffs", "lde", "cap")):
+        v = _as_u64(values)
+        k, n = v.shape
+        log_n = int(n).bit_length() - 1
+        N = n << rate_bits
+        dv, dl, dcap = self.to_device(v), self.alloc(k * N), self.alloc(4 << cap_height)
+        dco = self.alloc(k * n) if "coeffs" in want else None
+        nd = 2 * N - (2 << cap_height)
+        dd = self.alloc(nd * 4) if "digests" in want and nd > 0 else None
+        try:
+            self.commit_dev(dv.ptr, k, log_n, rate_bits, cap_height, dl.ptr, dcap.ptr,
+                            dco.ptr if dco else None, dd.ptr if dd else None)
+            res = {"cap": dcap.download().reshape(-1, 4)}
+            res["lde"] = dl.download().reshape(k, N) if "lde" in want else None
+            res["coeffs"] = dco.download().reshape(k, n) if dco else None
+            res["digests"] = dd.download().reshape(-1, 4) if dd else None
+        finally:
+            for b in (dv, dl, dcap, dco, dd):
+                if b:
+                    b.free()
+        return res

@@ -1,0 +1,599 @@
+// libcityprover_hip.so — C ABI (include/cityprover.h) over the gfx950 kernels.
+// No CPU fallback: every compute entry point needs a live HIP device and fails loudly without one.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/cityprover.h"
+#include "gl.h"
+#include "merkle.h"
+#include "ntt.h"
+#include "poseidon.h"
+
+namespace {
+
+thread_local std::string g_tls_error = "";
+
+struct PowTable {
+  uint64_t *dev = nullptr;  // 3 x 2048
+};
+
+}  // namespace
+
+struct cp_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  std::string error;
+  std::map<uint64_t, PowTable> pow_tables;  // keyed by base
+  // scratch buffer reused by natural-order NTT epilogues / merkle host paths
+  void *scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+namespace {
+
+int set_error(cp_ctx *ctx, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_tls_error = buf;
+  if (ctx) ctx->error = buf;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess)                                                                  \
+      return set_error(ctx, e__ == hipErrorOutOfMemory ? CP_ERR_OOM : CP_ERR_HIP,           \
+                       "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,    \
+                       __LINE__);                                                           \
+  } while (0)
+
+#define CP_TRY(expr)              \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != CP_OK) return rc__; \
+  } while (0)
+
+#define CHECK_CTX(ctx)                                                          \
+  do {                                                                          \
+    if (!(ctx)) return set_error(nullptr, CP_ERR_INVALID_ARG, "ctx is NULL");   \
+    hipError_t e__ = hipSetDevice((ctx)->device);                               \
+    if (e__ != hipSuccess)                                                      \
+      return set_error(ctx, CP_ERR_HIP, "hipSetDevice(%d): %s", (ctx)->device,  \
+                       hipGetErrorString(e__));                                 \
+  } while (0)
+
+int ensure_scratch(cp_ctx *ctx, size_t bytes) {
+  if (ctx->scratch_bytes >= bytes) return CP_OK;
+  if (ctx->scratch) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+  }
+  HIP_TRY(ctx, hipMalloc(&ctx->scratch, bytes));
+  ctx->scratch_bytes = bytes;
+  return CP_OK;
+}
+
+// 3-level power table of `base`, cached per ctx
+int get_pow_table(cp_ctx *ctx, uint64_t base, const uint64_t **out) {
+  auto it = ctx->pow_tables.find(base);
+  if (it != ctx->pow_tables.end()) {
+    *out = it->second.dev;
+    return CP_OK;
+  }
+  std::vector<uint64_t> h(3 * ntt::PT_SIZE);
+  uint64_t b = base;
+  for (int lvl = 0; lvl < 3; lvl++) {
+    uint64_t acc = 1;
+    for (int j = 0; j < ntt::PT_SIZE; j++) {
+      h[lvl * ntt::PT_SIZE + j] = acc;
+      acc = gl::mul(acc, b);
+    }
+    b = acc;  // base^(2048^(lvl+1))
+  }
+  PowTable t;
+  HIP_TRY(ctx, hipMalloc((void **)&t.dev, h.size() * sizeof(uint64_t)));
+  HIP_TRY(ctx, hipMemcpyAsync(t.dev, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice,
+                              ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // h goes out of scope
+  ctx->pow_tables[base] = t;
+  *out = t.dev;
+  return CP_OK;
+}
+
+uint64_t root_of_unity(int log_n, bool inverse) {
+  return inverse ? GL_ROOTS_INV[log_n] : GL_ROOTS[log_n];
+}
+
+int upload_constants(cp_ctx *ctx) {
+  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_RC), POSEIDON_RC, sizeof POSEIDON_RC));
+  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_FAST_FIRST), POSEIDON_FAST_FIRST,
+                                 sizeof POSEIDON_FAST_FIRST));
+  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_FAST_K), POSEIDON_FAST_K,
+                                 sizeof POSEIDON_FAST_K));
+  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_FAST_VS), POSEIDON_FAST_VS,
+                                 sizeof POSEIDON_FAST_VS));
+  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_FAST_WHATS), POSEIDON_FAST_WHATS,
+                                 sizeof POSEIDON_FAST_WHATS));
+  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_FAST_INIT), POSEIDON_FAST_INIT,
+                                 sizeof POSEIDON_FAST_INIT));
+  return CP_OK;
+}
+
+inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
+
+// ---- NTT driver ---------------------------------------------------------------------------
+
+// DIF passes, natural in -> bit-reversed out, in place.
+int run_dif(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stride, bool inverse,
+            uint64_t scale, const uint64_t *stab_pre) {
+  if (log_n == 0) return CP_OK;
+  const uint64_t *wtab;
+  CP_TRY(get_pow_table(ctx, root_of_unity(log_n, inverse), &wtab));
+  // pass plan: top passes take L = min(remaining, cap) bits; the last pass has q = 0
+  int q = log_n;
+  bool first = true;
+  while (q > 0) {
+    int L, c;
+    // choose L so that every pass keeps c <= q_after (coalescing rule q >= c) or is the last
+    int remaining = q;
+    if (remaining <= ntt::LOG_TILE_MAX) {
+      L = remaining;  // last pass, q_after = 0
+    } else {
+      // leave at least ... split as evenly as possible over ceil(remaining / 10) passes
+      int passes = (remaining + 9) / 10;
+      L = (remaining + passes - 1) / passes;
+    }
+    int q_after = q - L;
+    c = ntt::LOG_TILE_MAX - L;
+    int outer_bits = log_n - L;  // number of outer-index bits
+    if (c > outer_bits) c = outer_bits;
+    if (q_after > 0 && c > q_after) c = q_after;
+    ntt::PassArgs a;
+    a.data = data;
+    a.stride = stride;
+    a.wtab = wtab;
+    a.stab = stab_pre;
+    a.log_n = log_n;
+    a.q = q_after;
+    a.L = L;
+    a.c = c;
+    a.first = first;
+    a.last = (q_after == 0);
+    a.scale = scale;
+    a.coset_pre = stab_pre != nullptr;
+    a.coset_post = 0;
+    dim3 grid((unsigned)(((size_t)1 << outer_bits) >> c), (unsigned)batch);
+    if (q_after == 0)
+      hipLaunchKernelGGL(ntt::k_dif_pass<true>, grid, dim3(ntt::THREADS), 0, ctx->stream, a);
+    else
+      hipLaunchKernelGGL(ntt::k_dif_pass<false>, grid, dim3(ntt::THREADS), 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    q = q_after;
+    first = false;
+  }
+  return CP_OK;
+}
+
+int bitrev_copy(cp_ctx *ctx, const uint64_t *src, uint64_t *dst, size_t src_stride,
+                size_t dst_stride, int log_n, size_t batch, const uint64_t *stab) {
+  size_t n = (size_t)1 << log_n;
+  dim3 grid(blocks_for(n, 256), (unsigned)batch);
+  hipLaunchKernelGGL(ntt::k_bitrev_copy, grid, dim3(256), 0, ctx->stream, src, dst, src_stride,
+                     dst_stride, log_n, stab);
+  HIP_TRY(ctx, hipGetLastError());
+  return CP_OK;
+}
+
+int merkle_from_digests(cp_ctx *ctx, uint64_t *level0, size_t n_leaves, int cap_height,
+                        uint64_t *digests_dev, uint64_t *cap_dev, bool level0_in_digests) {
+  // levels live in digests_dev (if given) or in a ping-pong scratch
+  size_t cap_n = (size_t)1 << cap_height;
+  uint64_t *cur = level0;
+  size_t n = n_leaves;
+  uint64_t *next_slot = nullptr;
+  if (digests_dev) {
+    next_slot = digests_dev + (level0_in_digests ? n_leaves * 4 : 0);
+  }
+  uint64_t *pp[2] = {nullptr, nullptr};
+  int pi = 0;
+  if (!digests_dev && n > cap_n) {
+    // scratch ping-pong beyond the leaf level: n/2*4 + n/4*4 u64
+    // (allocated by caller via ensure_scratch; level0 sits at the start of scratch)
+    pp[0] = level0 + n_leaves * 4;
+    pp[1] = pp[0] + (n_leaves / 2) * 4;
+  }
+  while (n > cap_n) {
+    size_t np = n / 2;
+    uint64_t *dst;
+    if (np == cap_n) dst = cap_dev;
+    else if (digests_dev) { dst = next_slot; next_slot += np * 4; }
+    else { dst = pp[pi]; pi ^= 1; }
+    hipLaunchKernelGGL(merkle::k_level, dim3(blocks_for(np, merkle::THREADS)),
+                       dim3(merkle::THREADS), 0, ctx->stream, cur, np, dst);
+    HIP_TRY(ctx, hipGetLastError());
+    cur = dst;
+    n = np;
+  }
+  if (n_leaves == cap_n) {
+    HIP_TRY(ctx, hipMemcpyAsync(cap_dev, level0, cap_n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return CP_OK;
+}
+
+bool valid_merkle_shape(size_t n_leaves, int cap_height) {
+  if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return false;
+  if (cap_height < 0 || cap_height > 40) return false;
+  return ((size_t)1 << cap_height) <= n_leaves;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cp_abi_version(void) { return CP_ABI_VERSION; }
+
+int cp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *cp_last_error(cp_ctx *ctx) { return ctx ? ctx->error.c_str() : g_tls_error.c_str(); }
+
+cp_ctx *cp_ctx_create(int device) {
+  int n = cp_device_count();
+  if (n <= 0) {
+    set_error(nullptr, CP_ERR_NO_DEVICE,
+              "no HIP device visible: libcityprover_hip has no CPU fallback");
+    return nullptr;
+  }
+  if (device < 0 || device >= n) {
+    set_error(nullptr, CP_ERR_INVALID_ARG, "device %d out of range (have %d)", device, n);
+    return nullptr;
+  }
+  cp_ctx *ctx = new (std::nothrow) cp_ctx();
+  if (!ctx) {
+    set_error(nullptr, CP_ERR_OOM, "out of host memory");
+    return nullptr;
+  }
+  ctx->device = device;
+  auto fail = [&](const char *what, hipError_t e) {
+    set_error(nullptr, CP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    delete ctx;
+    return (cp_ctx *)nullptr;
+  };
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail("hipSetDevice", e);
+  e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) return fail("hipStreamCreate", e);
+  if (upload_constants(ctx) != CP_OK) {
+    std::string msg = ctx->error;
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    g_tls_error = msg;
+    return nullptr;
+  }
+  return ctx;
+}
+
+void cp_ctx_destroy(cp_ctx *ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  for (auto &kv : ctx->pow_tables) hipFree(kv.second.dev);
+  if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int cp_dev_alloc(cp_ctx *ctx, size_t bytes, void **out) {
+  CHECK_CTX(ctx);
+  if (!out) return set_error(ctx, CP_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (bytes == 0) return CP_OK;
+  HIP_TRY(ctx, hipMalloc(out, bytes));
+  return CP_OK;
+}
+int cp_dev_free(cp_ctx *ctx, void *ptr) {
+  CHECK_CTX(ctx);
+  if (!ptr) return CP_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipFree(ptr));
+  return CP_OK;
+}
+int cp_h2d(cp_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  CHECK_CTX(ctx);
+  if (bytes == 0) return CP_OK;
+  if (!dst || !src) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CP_OK;
+}
+int cp_d2h(cp_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  CHECK_CTX(ctx);
+  if (bytes == 0) return CP_OK;
+  if (!dst || !src) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CP_OK;
+}
+int cp_d2d(cp_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  CHECK_CTX(ctx);
+  if (bytes == 0) return CP_OK;
+  if (!dst || !src) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return CP_OK;
+}
+int cp_sync(cp_ctx *ctx) {
+  CHECK_CTX(ctx);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CP_OK;
+}
+int cp_event_create(cp_ctx *ctx, void **event_out) {
+  CHECK_CTX(ctx);
+  if (!event_out) return set_error(ctx, CP_ERR_INVALID_ARG, "event_out is NULL");
+  hipEvent_t ev;
+  HIP_TRY(ctx, hipEventCreate(&ev));
+  *event_out = (void *)ev;
+  return CP_OK;
+}
+int cp_event_destroy(cp_ctx *ctx, void *event) {
+  CHECK_CTX(ctx);
+  if (event) HIP_TRY(ctx, hipEventDestroy((hipEvent_t)event));
+  return CP_OK;
+}
+int cp_event_record(cp_ctx *ctx, void *event) {
+  CHECK_CTX(ctx);
+  if (!event) return set_error(ctx, CP_ERR_INVALID_ARG, "event is NULL");
+  HIP_TRY(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
+  return CP_OK;
+}
+int cp_event_elapsed_ms(cp_ctx *ctx, void *start, void *stop, float *ms_out) {
+  CHECK_CTX(ctx);
+  if (!start || !stop || !ms_out) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL argument");
+  HIP_TRY(ctx, hipEventSynchronize((hipEvent_t)stop));
+  HIP_TRY(ctx, hipEventElapsedTime(ms_out, (hipEvent_t)start, (hipEvent_t)stop));
+  return CP_OK;
+}
+
+// ---- NTT ------------------------------------------------------------------------------------
+
+int cp_ntt_dev(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stride, unsigned flags,
+               uint64_t coset_shift) {
+  CHECK_CTX(ctx);
+  if (batch == 0) return CP_OK;
+  if (!data) return set_error(ctx, CP_ERR_INVALID_ARG, "data is NULL");
+  if (log_n < 0 || log_n > 32) return set_error(ctx, CP_ERR_INVALID_ARG, "log_n %d out of range [0,32]", log_n);
+  size_t n = (size_t)1 << log_n;
+  if (stride < n) return set_error(ctx, CP_ERR_INVALID_ARG, "stride %zu < n %zu", stride, n);
+  if (batch > 65535) return set_error(ctx, CP_ERR_INVALID_ARG, "batch %zu > 65535", batch);
+  if (flags & ~(CP_NTT_INVERSE | CP_NTT_BITREV_OUT | CP_NTT_COSET | CP_NTT_BITREV_IN))
+    return set_error(ctx, CP_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+  const bool inverse = flags & CP_NTT_INVERSE, coset = flags & CP_NTT_COSET;
+  if (coset && (coset_shift == 0 || coset_shift >= gl::P))
+    return set_error(ctx, CP_ERR_INVALID_ARG, "coset shift must be a non-zero canonical element");
+  if (log_n == 0) return CP_OK;
+
+  const uint64_t *stab = nullptr;
+  if (coset) CP_TRY(get_pow_table(ctx, inverse ? gl::inv(coset_shift) : coset_shift, &stab));
+
+  const bool need_tmp = (flags & CP_NTT_BITREV_IN) || !(flags & CP_NTT_BITREV_OUT) || (coset && inverse);
+  uint64_t *tmp = nullptr;
+  if (need_tmp) {
+    CP_TRY(ensure_scratch(ctx, batch * n * sizeof(uint64_t)));
+    tmp = (uint64_t *)ctx->scratch;
+  }
+  if (flags & CP_NTT_BITREV_IN) {  // un-permute the input first (v1: explicit pass)
+    CP_TRY(bitrev_copy(ctx, data, tmp, stride, n, log_n, batch, nullptr));
+    for (size_t b = 0; b < batch; b++)
+      HIP_TRY(ctx, hipMemcpyAsync(data + b * stride, tmp + b * n, n * sizeof(uint64_t),
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  uint64_t scale = 0;
+  if (inverse) scale = gl::inv((uint64_t)n % gl::P);
+  CP_TRY(run_dif(ctx, data, log_n, batch, stride, inverse, scale, (coset && !inverse) ? stab : nullptr));
+  if (!(flags & CP_NTT_BITREV_OUT)) {
+    CP_TRY(bitrev_copy(ctx, data, tmp, stride, n, log_n, batch, (coset && inverse) ? stab : nullptr));
+    for (size_t b = 0; b < batch; b++)
+      HIP_TRY(ctx, hipMemcpyAsync(data + b * stride, tmp + b * n, n * sizeof(uint64_t),
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+  } else if (coset && inverse) {
+    return set_error(ctx, CP_ERR_UNSUPPORTED, "inverse coset NTT with bit-reversed output is not supported");
+  }
+  return CP_OK;
+}
+
+int cp_ntt(cp_ctx *ctx, uint64_t *data_host, int log_n, size_t batch, unsigned flags,
+           uint64_t coset_shift) {
+  CHECK_CTX(ctx);
+  if (batch == 0) return CP_OK;
+  if (!data_host) return set_error(ctx, CP_ERR_INVALID_ARG, "data is NULL");
+  if (log_n < 0 || log_n > 32) return set_error(ctx, CP_ERR_INVALID_ARG, "log_n %d out of range [0,32]", log_n);
+  size_t n = (size_t)1 << log_n, bytes = batch * n * sizeof(uint64_t);
+  uint64_t *d = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&d, bytes));
+  int rc = cp_h2d(ctx, d, data_host, bytes);
+  if (rc == CP_OK) rc = cp_ntt_dev(ctx, d, log_n, batch, n, flags, coset_shift);
+  if (rc == CP_OK) rc = cp_d2h(ctx, data_host, d, bytes);
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d);
+  return rc;
+}
+
+int cp_lde_dev(cp_ctx *ctx, const uint64_t *coeffs, size_t in_stride, int log_n, int rate_bits,
+               size_t batch, uint64_t coset_shift, unsigned flags, uint64_t *out, size_t out_stride) {
+  CHECK_CTX(ctx);
+  if (batch == 0) return CP_OK;
+  if (!coeffs || !out) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
+  if (log_n < 0 || rate_bits < 0 || log_n + rate_bits > 32)
+    return set_error(ctx, CP_ERR_INVALID_ARG, "log_n %d + rate_bits %d out of range", log_n, rate_bits);
+  size_t n = (size_t)1 << log_n, N = n << rate_bits;
+  if (in_stride < n || out_stride < N) return set_error(ctx, CP_ERR_INVALID_ARG, "stride too small");
+  if (batch > 65535) return set_error(ctx, CP_ERR_INVALID_ARG, "batch %zu > 65535", batch);
+  if (flags & ~CP_NTT_BITREV_OUT) return set_error(ctx, CP_ERR_INVALID_ARG, "unsupported flags 0x%x", flags);
+  dim3 grid(blocks_for(N, 256), (unsigned)batch);
+  hipLaunchKernelGGL(ntt::k_pad_copy, grid, dim3(256), 0, ctx->stream, coeffs, out, in_stride,
+                     out_stride, n, N);
+  HIP_TRY(ctx, hipGetLastError());
+  return cp_ntt_dev(ctx, out, log_n + rate_bits, batch, out_stride,
+                    (flags & CP_NTT_BITREV_OUT) | CP_NTT_COSET, coset_shift);
+}
+
+// ---- Poseidon -------------------------------------------------------------------------------
+
+int cp_poseidon_permute_dev(cp_ctx *ctx, uint64_t *states, size_t count) {
+  CHECK_CTX(ctx);
+  if (count == 0) return CP_OK;
+  if (!states) return set_error(ctx, CP_ERR_INVALID_ARG, "states is NULL");
+  hipLaunchKernelGGL(merkle::k_permute, dim3(blocks_for(count, merkle::THREADS)),
+                     dim3(merkle::THREADS), 0, ctx->stream, states, count);
+  HIP_TRY(ctx, hipGetLastError());
+  return CP_OK;
+}
+
+int cp_poseidon_permute(cp_ctx *ctx, uint64_t *states_host, size_t count) {
+  CHECK_CTX(ctx);
+  if (count == 0) return CP_OK;
+  if (!states_host) return set_error(ctx, CP_ERR_INVALID_ARG, "states is NULL");
+  size_t bytes = count * 12 * sizeof(uint64_t);
+  CP_TRY(ensure_scratch(ctx, bytes));
+  CP_TRY(cp_h2d(ctx, ctx->scratch, states_host, bytes));
+  CP_TRY(cp_poseidon_permute_dev(ctx, (uint64_t *)ctx->scratch, count));
+  return cp_d2h(ctx, states_host, ctx->scratch, bytes);
+}
+
+int cp_hash_no_pad(cp_ctx *ctx, const uint64_t *in_host, size_t count, size_t len,
+                   uint64_t *digests_host) {
+  CHECK_CTX(ctx);
+  if (count == 0) return CP_OK;
+  if (!digests_host || (!in_host && len)) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
+  if (len > (1u << 30)) return set_error(ctx, CP_ERR_INVALID_ARG, "len too large");
+  size_t in_bytes = count * len * sizeof(uint64_t), out_bytes = count * 32;
+  size_t in_al = (in_bytes + 255) & ~(size_t)255;
+  CP_TRY(ensure_scratch(ctx, in_al + out_bytes));
+  uint64_t *din = (uint64_t *)ctx->scratch, *dout = (uint64_t *)((char *)ctx->scratch + in_al);
+  if (in_bytes) CP_TRY(cp_h2d(ctx, din, in_host, in_bytes));
+  hipLaunchKernelGGL(merkle::k_leaf_hash_rows, dim3(blocks_for(count, merkle::THREADS)),
+                     dim3(merkle::THREADS), 0, ctx->stream, din, count, (int)len, dout, 1);
+  HIP_TRY(ctx, hipGetLastError());
+  return cp_d2h(ctx, digests_host, dout, out_bytes);
+}
+
+int cp_two_to_one(cp_ctx *ctx, const uint64_t *left_host, const uint64_t *right_host, size_t count,
+                  uint64_t *out_host) {
+  CHECK_CTX(ctx);
+  if (count == 0) return CP_OK;
+  if (!left_host || !right_host || !out_host) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
+  size_t b = count * 32;
+  CP_TRY(ensure_scratch(ctx, 3 * b));
+  uint64_t *l = (uint64_t *)ctx->scratch, *r = l + count * 4, *o = r + count * 4;
+  CP_TRY(cp_h2d(ctx, l, left_host, b));
+  CP_TRY(cp_h2d(ctx, r, right_host, b));
+  hipLaunchKernelGGL(merkle::k_two_to_one, dim3(blocks_for(count, merkle::THREADS)),
+                     dim3(merkle::THREADS), 0, ctx->stream, l, r, count, o);
+  HIP_TRY(ctx, hipGetLastError());
+  return cp_d2h(ctx, out_host, o, b);
+}
+
+// ---- Merkle ---------------------------------------------------------------------------------
+
+int cp_merkle_cols_dev(cp_ctx *ctx, const uint64_t *cols, size_t n_leaves, size_t leaf_len,
+                       size_t col_stride, int cap_height, uint64_t *digests_dev, uint64_t *cap_dev) {
+  CHECK_CTX(ctx);
+  if (!cols || !cap_dev) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
+  if (!valid_merkle_shape(n_leaves, cap_height))
+    return set_error(ctx, CP_ERR_INVALID_ARG, "n_leaves %zu must be a power of two >= 2^cap_height (%d)",
+                     n_leaves, cap_height);
+  if (leaf_len == 0 || leaf_len > (1u << 20)) return set_error(ctx, CP_ERR_INVALID_ARG, "leaf_len %zu out of range", leaf_len);
+  if (col_stride < n_leaves) return set_error(ctx, CP_ERR_INVALID_ARG, "col_stride < n_leaves");
+  uint64_t *level0;
+  size_t cap_n = (size_t)1 << cap_height;
+  if (digests_dev && n_leaves > cap_n) {
+    level0 = digests_dev;
+  } else {
+    CP_TRY(ensure_scratch(ctx, n_leaves * 32 * 2));
+    level0 = (uint64_t *)ctx->scratch;
+  }
+  hipLaunchKernelGGL(merkle::k_leaf_hash_cols, dim3(blocks_for(n_leaves, merkle::THREADS)),
+                     dim3(merkle::THREADS), 0, ctx->stream, cols, n_leaves, (int)leaf_len, col_stride,
+                     level0);
+  HIP_TRY(ctx, hipGetLastError());
+  return merkle_from_digests(ctx, level0, n_leaves, cap_height,
+                             (digests_dev && n_leaves > cap_n) ? digests_dev : nullptr, cap_dev, true);
+}
+
+int cp_merkle_cap(cp_ctx *ctx, const uint64_t *rows_host, size_t n_leaves, size_t leaf_len,
+                  int cap_height, uint64_t *cap_host) {
+  CHECK_CTX(ctx);
+  if (!rows_host || !cap_host) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
+  if (!valid_merkle_shape(n_leaves, cap_height))
+    return set_error(ctx, CP_ERR_INVALID_ARG, "n_leaves %zu must be a power of two >= 2^cap_height (%d)",
+                     n_leaves, cap_height);
+  if (leaf_len == 0 || leaf_len > (1u << 20)) return set_error(ctx, CP_ERR_INVALID_ARG, "leaf_len %zu out of range", leaf_len);
+  size_t cap_n = (size_t)1 << cap_height;
+  size_t rows_bytes = n_leaves * leaf_len * sizeof(uint64_t);
+  uint64_t *rows = nullptr, *cap = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&rows, rows_bytes));
+  hipError_t e = hipMalloc((void **)&cap, cap_n * 32);
+  if (e != hipSuccess) { hipFree(rows); return set_error(ctx, CP_ERR_OOM, "hipMalloc: %s", hipGetErrorString(e)); }
+  int rc = cp_h2d(ctx, rows, rows_host, rows_bytes);
+  if (rc == CP_OK) rc = ensure_scratch(ctx, n_leaves * 32 * 2);
+  if (rc == CP_OK) {
+    uint64_t *level0 = (uint64_t *)ctx->scratch;
+    hipLaunchKernelGGL(merkle::k_leaf_hash_rows, dim3(blocks_for(n_leaves, merkle::THREADS)),
+                       dim3(merkle::THREADS), 0, ctx->stream, rows, n_leaves, (int)leaf_len, level0, 0);
+    if (hipGetLastError() != hipSuccess) rc = set_error(ctx, CP_ERR_HIP, "leaf hash launch failed");
+    if (rc == CP_OK) rc = merkle_from_digests(ctx, level0, n_leaves, cap_height, nullptr, cap, true);
+  }
+  if (rc == CP_OK) rc = cp_d2h(ctx, cap_host, cap, cap_n * 32);
+  hipStreamSynchronize(ctx->stream);
+  hipFree(rows);
+  hipFree(cap);
+  return rc;
+}
+
+// ---- commit ---------------------------------------------------------------------------------
+
+int cp_commit_dev(cp_ctx *ctx, const uint64_t *values, size_t k, int log_n, int rate_bits,
+                  int cap_height, uint64_t *coeffs_dev, uint64_t *lde_dev, uint64_t *digests_dev,
+                  uint64_t *cap_dev) {
+  CHECK_CTX(ctx);
+  if (!values || !lde_dev || !cap_dev) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
+  if (k == 0 || k > 65535) return set_error(ctx, CP_ERR_INVALID_ARG, "k %zu out of range", k);
+  if (log_n < 0 || rate_bits < 0 || log_n + rate_bits > 32)
+    return set_error(ctx, CP_ERR_INVALID_ARG, "log_n/rate_bits out of range");
+  size_t n = (size_t)1 << log_n, N = n << rate_bits;
+  if (!valid_merkle_shape(N, cap_height)) return set_error(ctx, CP_ERR_INVALID_ARG, "cap_height %d too large", cap_height);
+  uint64_t *coeffs = coeffs_dev;
+  uint64_t *own = nullptr;
+  if (!coeffs) {
+    HIP_TRY(ctx, hipMalloc((void **)&own, k * n * sizeof(uint64_t)));
+    coeffs = own;
+  }
+  int rc = cp_d2d(ctx, coeffs, values, k * n * sizeof(uint64_t));
+  if (rc == CP_OK) rc = cp_ntt_dev(ctx, coeffs, log_n, k, n, CP_NTT_INVERSE, 0);
+  if (rc == CP_OK)
+    rc = cp_lde_dev(ctx, coeffs, n, log_n, rate_bits, k, 7, CP_NTT_BITREV_OUT, lde_dev, N);
+  if (rc == CP_OK) rc = cp_merkle_cols_dev(ctx, lde_dev, N, k, N, cap_height, digests_dev, cap_dev);
+  if (own) {
+    hipStreamSynchronize(ctx->stream);
+    hipFree(own);
+  }
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+/*
+ * cityprover — C ABI of the MI355X-native Plonky2 prover backend for city-rollup.
+ *
+ * This is the drop-in boundary: the entry points a
+ * Rust `extern "C"` shim inside a patched `plonky2` crate binds so that
+ *   plonky2::plonk::circuit_data::CircuitData::prove / ::verify
+ * (called at e.g. city_common_circuit/src/proof_minifier/pm_core.rs:143-154,
+ *  city_common_circuit/src/treeprover/aggregation/state_transition/mod.rs:260-304,
+ *  city_rollup_circuit/src/block_circuits/ops/l2_transfer/circuit.rs:209-235)
+ * and the primitives underneath it run on the GPU. Plain pointers and sizes only.
+ *
+ * Conventions
+ *  - every field element is a canonical Goldilocks u64 (little-endian on the wire), p = 2^64-2^32+1
+ *  - all functions return 0 on success, a negative cp_status otherwise, and NEVER abort or throw;
+ *    the message is available from cp_last_error() (the Rust shim turns it into anyhow::bail!,
+ *    matching the `anyhow::Result` convention of city_rollup_circuit/src/worker/traits.rs:16-43)
+ *  - a cp_ctx is bound to one device and is thread-compatible (one caller at a time); multi-GPU =
+ *    one ctx per device, one host thread / process each (city_rollup_core_worker/src/lib.rs:131-145
+ *    scales the same way: one worker process per consumer)
+ *  - "_dev" entry points take device pointers (operands already resident in HBM, obtained from
+ *    cp_dev_alloc or from any other HIP allocation on the same device, e.g. a torch tensor);
+ *    the plain entry points take host pointers and stage through HBM.
+ */
+#ifndef CITYPROVER_H
+#define CITYPROVER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CP_ABI_VERSION 1
+
+typedef enum cp_status {
+  CP_OK = 0,
+  CP_ERR_INVALID_ARG = -1,
+  CP_ERR_NO_DEVICE = -2,
+  CP_ERR_HIP = -3,
+  CP_ERR_OOM = -4,
+  CP_ERR_UNSUPPORTED = -5,
+  CP_ERR_INTERNAL = -6
+} cp_status;
+
+typedef struct cp_ctx cp_ctx;
+
+/* ---- library / context ------------------------------------------------------------- */
+int cp_abi_version(void);
+/* number of visible HIP devices; 0 when there is none (never an error) */
+int cp_device_count(void);
+/* Create a context on `device`. Returns NULL on failure (see cp_last_error(NULL)). Fails loudly
+ * when no GPU is present: there is no CPU fallback in this library. */
+cp_ctx *cp_ctx_create(int device);
+void cp_ctx_destroy(cp_ctx *ctx);
+/* last error message of `ctx`, or of the calling thread when ctx == NULL. Never NULL. */
+const char *cp_last_error(cp_ctx *ctx);
+
+/* ---- device memory & stream ---------------------------------------------------------- */
+int cp_dev_alloc(cp_ctx *ctx, size_t bytes, void **out);
+int cp_dev_free(cp_ctx *ctx, void *ptr);
+int cp_h2d(cp_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int cp_d2h(cp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int cp_d2d(cp_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
+int cp_sync(cp_ctx *ctx);
+/* HIP events on the context's stream (the stream every kernel of this ctx is launched on) */
+int cp_event_create(cp_ctx *ctx, void **event_out);
+int cp_event_destroy(cp_ctx *ctx, void *event);
+int cp_event_record(cp_ctx *ctx, void *event);
+int cp_event_elapsed_ms(cp_ctx *ctx, void *start, void *stop, float *ms_out); /* syncs on `stop` */
+
+/* ---- NTT over Goldilocks -------------------------------------------------------------
+ * Replaces plonky2_field's `fft_with_options` / `ifft_with_options` / `PolynomialCoeffs::
+ * coset_fft_with_options` as used by `PolynomialBatch::from_values` inside CircuitData::prove
+ * (SURVEY.md §8(a) A3). omega_n = 7^((p-1)/n).
+ *
+ * data: `batch` polynomials of n = 2^log_n elements, polynomial b at data + b*stride (stride >= n).
+ * flags: */
+#define CP_NTT_INVERSE 1u        /* inverse transform (includes the 1/n scaling) */
+#define CP_NTT_BITREV_OUT 2u     /* leave the output in bit-reversed index order (Merkle leaf order) */
+#define CP_NTT_COSET 4u          /* forward only: evaluate on shift*<omega> (input coefficient i is  \
+                                    multiplied by shift^i first); inverse only: divide coefficient i \
+                                    by shift^i afterwards */
+#define CP_NTT_BITREV_IN 8u      /* the input is in bit-reversed index order */
+int cp_ntt_dev(cp_ctx *ctx, uint64_t *data_dev, int log_n, size_t batch, size_t stride,
+               unsigned flags, uint64_t coset_shift);
+int cp_ntt(cp_ctx *ctx, uint64_t *data_host, int log_n, size_t batch, unsigned flags,
+           uint64_t coset_shift);
+
+/* Low-degree extension: coefficients (n = 2^log_n each, polynomial b at coeffs + b*in_stride) ->
+ * evaluations on coset_shift*<omega_{n<<rate_bits}>, polynomial b at out + b*out_stride
+ * (out_stride >= n<<rate_bits). Output order: natural, or bit-reversed with CP_NTT_BITREV_OUT.
+ * (plonky2 `PolynomialCoeffs::lde` + `coset_fft_with_options`) */
+int cp_lde_dev(cp_ctx *ctx, const uint64_t *coeffs_dev, size_t in_stride, int log_n, int rate_bits,
+               size_t batch, uint64_t coset_shift, unsigned flags, uint64_t *out_dev,
+               size_t out_stride);
+
+/* ---- Poseidon-Goldilocks -------------------------------------------------------------
+ * Replaces plonky2 `PoseidonPermutation::permute`, `PoseidonHash::{hash_no_pad, two_to_one}`
+ * (reference call sites city_crypto/src/hash/traits/hasher.rs:77-159).
+ * states: count x 12 u64, permuted in place. */
+int cp_poseidon_permute_dev(cp_ctx *ctx, uint64_t *states_dev, size_t count);
+int cp_poseidon_permute(cp_ctx *ctx, uint64_t *states_host, size_t count);
+/* hash_no_pad of `count` inputs of `len` felts each (row-major), digests out: count x 4 */
+int cp_hash_no_pad(cp_ctx *ctx, const uint64_t *in_host, size_t count, size_t len,
+                   uint64_t *digests_host);
+/* two_to_one over `count` pairs: left/right count x 4 -> out count x 4 */
+int cp_two_to_one(cp_ctx *ctx, const uint64_t *left_host, const uint64_t *right_host, size_t count,
+                  uint64_t *out_host);
+
+/* ---- Merkle tree with cap ------------------------------------------------------------
+ * Replaces plonky2 `MerkleTree::new(leaves, cap_height)`: leaf digest =
+ * hash_or_noop(row) (rows of <= 4 felts are zero-padded, not hashed), node = two_to_one,
+ * the tree stops at the 2^cap_height-entry cap.
+ *
+ * Leaves are given COLUMN-MAJOR (the HBM layout of a polynomial batch): element j of leaf i is
+ * cols[j*col_stride + i]; leaf order is the caller's (the prover passes bit-reversed LDE columns).
+ * digests_dev (nullable): all levels below the cap, level 0 (n_leaves digests) first, then
+ * n_leaves/2, ... ; total (2*n_leaves - 2^(cap_height+1)) x 4 u64. cap_dev: 2^cap_height x 4. */
+int cp_merkle_cols_dev(cp_ctx *ctx, const uint64_t *cols_dev, size_t n_leaves, size_t leaf_len,
+                       size_t col_stride, int cap_height, uint64_t *digests_dev,
+                       uint64_t *cap_dev);
+/* host convenience, ROW-MAJOR leaves (n_leaves x leaf_len) as plonky2's API takes them */
+int cp_merkle_cap(cp_ctx *ctx, const uint64_t *rows_host, size_t n_leaves, size_t leaf_len,
+                  int cap_height, uint64_t *cap_host);
+
+/* ---- PolynomialBatch::from_values (commit) --------------------------------------------
+ * values: k polynomials of n = 2^log_n evaluations over <omega_n> (natural order), poly-major.
+ * Produces coefficient form (k x n), the rate-2^rate_bits coset LDE on 7*<omega_{n<<rate_bits}>
+ * in bit-reversed order (k x N, poly-major == column-major leaves), the Merkle digests and the cap.
+ * Any of coeffs_dev / digests_dev may be NULL. (SURVEY.md §3.3 step 3, §8(a) A3+A4.) */
+int cp_commit_dev(cp_ctx *ctx, const uint64_t *values_dev, size_t k, int log_n, int rate_bits,
+                  int cap_height, uint64_t *coeffs_dev, uint64_t *lde_dev, uint64_t *digests_dev,
+                  uint64_t *cap_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CITYPROVER_H */

@@ -1,0 +1,47 @@
+"""CPU-side checks of the drop-in boundary: the HIP library builds, loads, and exports every
+symbol include/cityprover.h declares. No compute calls (there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+import cityprover
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "cityprover.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = cityprover.load_library()
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/cityprover.h but not exported"
+    # and the python binding table covers the header exactly
+    assert sorted(cityprover.ABI.keys()) == syms
+
+
+def test_abi_version_and_no_gpu_fails_loudly():
+    lib = cityprover.load_library()
+    assert lib.cp_abi_version() == 1
+    if lib.cp_device_count() == 0:
+        assert not lib.cp_ctx_create(0)
+        assert b"no HIP device" in lib.cp_last_error(None)
+        with pytest.raises(cityprover.CityProverError):
+            cityprover.Prover()
+
+
+def test_product_does_not_reference_oracle():
+    # the product path must never import / link / call the oracle
+    pkg = os.path.join(ROOT, "city-rollup_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "libcityoracle" not in txt and "oracle_lib" not in txt, os.path.join(dp, f)
+                assert not re.search(r"#include\s+\"[^\"]*oracle", txt), os.path.join(dp, f)
