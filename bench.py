@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json configs[1]: "single 2^20-row Goldilocks NTT + Poseidon Merkle cap".
+
+One step = one commit-shaped pass over a synthetic 2^20-row x 135-column trace that is already
+resident in HBM: 135 forward NTTs of size 2^20 (natural in -> bit-reversed out, in place,
+column-major) followed by the Poseidon Merkle cap (height 4) over the 2^20 bit-reversed rows.
+Metric: ms per 2^20 NTT, whole job = elapsed / (steps * 135 * n_gpus); weak scaling (every GPU
+commits its own trace; the path has no data-path collective).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "city-rollup_amd"))
+
+import numpy as np  # noqa: E402
+
+LOG_N = 20
+COLS = 135
+CAP_H = 4
+SEED = 0x243F6A8885A308D3
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def splitmix64_felts(seed, n):
+    P = np.uint64(0xFFFFFFFF00000001)
+    i = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + i + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z % P
+
+
+def cpu_baseline(cols_host, log_n, cap_h):
+    """The oracle (a port, not the Rust reference — which cannot be built offline) timed on this
+    box's host cores on the same workload: ONE full step (135 NTTs of 2^20 + the Merkle cap)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    cores = min(len(os.sched_getaffinity(0)), 64)
+    L = O.lib()
+    L.or_set_threads(cores)
+    k, n = cols_host.shape
+    work = cols_host.copy()
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(p):
+        L.or_ntt(O.ptr(work[p]), log_n)  # ctypes releases the GIL
+        L.or_bit_reverse(O.ptr(work[p]), log_n)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(one, range(k)))
+    t1 = time.perf_counter()
+    cap = np.zeros((1 << cap_h, 4), np.uint64)
+    L.or_merkle_tree_cols(O.ptr(work), n, k, n, cap_h, None, O.ptr(cap))
+    t2 = time.perf_counter()
+    L.or_set_threads(1)
+    return {
+        "value": (t2 - t0) * 1e3 / k, "unit": "ms/NTT", "cores": cores, "kind": "port",
+        "sample": f"one full step on the host: {k} x 2^{log_n} NTT (+bit-reverse) = {(t1 - t0):.2f} s, "
+                  f"Poseidon Merkle cap over 2^{log_n} x {k} = {(t2 - t1):.2f} s; C oracle, "
+                  f"{cores} threads",
+        "ntt_ms": (t1 - t0) * 1e3 / k, "merkle_cap_s": t2 - t1,
+    }, work, cap
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cols", type=int, default=COLS)
+    ap.add_argument("--log-n", type=int, default=LOG_N)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # control plane only (barrier + max-reduce of the timing)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import cityprover as cp
+
+    prover = cp.Prover(local_rank)
+    k, log_n, n = args.cols, args.log_n, 1 << args.log_n
+    host = splitmix64_felts(SEED + rank * 0x1000003, k * n).reshape(k, n)
+    data = prover.to_device(host)
+    cap = prover.alloc(4 << CAP_H)
+
+    def sync():
+        prover.sync()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except ImportError:
+            pass
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        prover.ntt_dev(data.ptr, log_n, k, n, cp.NTT_BITREV_OUT)
+        prover.merkle_cols_dev(data.ptr, n, k, CAP_H, cap.ptr)
+
+    # correctness gate on this rank's first step (rank 0 also times the CPU baseline with it)
+    base = None
+    if rank == 0 and not args.no_cpu_baseline:
+        base, want_cols, want_cap = cpu_baseline(host, log_n, CAP_H)
+        step()
+        sync()
+        got_cap = cap.download().reshape(-1, 4)
+        assert (got_cap == want_cap).all(), "GPU Merkle cap != CPU oracle"
+        got_col = data.download(n, offset=(k - 1) * n)
+        assert (got_col == want_cols[k - 1]).all(), "GPU NTT != CPU oracle"
+        del want_cols
+        data.upload(host)
+    del host
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    barrier()
+    prover.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    barrier()
+    t1 = time.perf_counter()
+    prof = prover.profile_end()
+    elapsed = t1 - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    if rank == 0:
+        ms_step = elapsed * 1e3 / args.steps
+        ntts = k * world
+        value = ms_step / ntts
+
+        def kern(name):
+            d = prof.get(name)
+            return (d["total_ms"] / d["launches"], d["launches"]) if d else (None, 0)
+
+        leaf_ms, _ = kern("leaf_hash_cols")
+        cols_ms, cols_l = kern("ntt_dif_pass_cols")
+        rows_ms, rows_l = kern("ntt_dif_pass_rows")
+        lvl = prof.get("merkle_level", {"total_ms": 0.0, "launches": 0})
+        # dominant kernel by time: the Poseidon leaf hash. Algorithmic bytes per launch:
+        # 8*R*k read + 32*R digests written.
+        leaf_bytes = 8.0 * n * k + 32.0 * n
+        perms = n * ((k + 7) // 8)
+        roof = {"kernel": "leaf_hash_cols", "bound": "hbm",
+                "achieved": leaf_bytes / (leaf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "traffic": None,
+                "note": "integer-VALU bound (Poseidon: no MFMA-shaped work); see roofline_ntt for the "
+                        "HBM-bound kernel of this step"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        # NTT: one pass reads + writes the batch once -> 16 B per element per pass
+        pass_bytes = 16.0 * n * k
+        ntt_ms = (cols_ms or 0) * (cols_l / max(args.steps, 1)) + (rows_ms or 0) * (rows_l / max(args.steps, 1))
+        roof_ntt = {"kernel": "ntt_dif_pass_*", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_ntt": 16.0 * n,
+                    "achieved": 16.0 * n * k / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
+                    "per_pass_GBs": {"cols": pass_bytes / (cols_ms * 1e-3) / 1e9 if cols_ms else None,
+                                     "rows": pass_bytes / (rows_ms * 1e-3) / 1e9 if rows_ms else None},
+                    "ms_per_ntt_kernel_only": ntt_ms / k if ntt_ms else None}
+        if roof_ntt["achieved"]:
+            roof_ntt["frac"] = roof_ntt["achieved"] / HBM_PEAK_GBS
+        out = {
+            "metric": "ms/NTT at 2^20 Goldilocks (commit-shaped step: 135-column 2^20-row NTT + Poseidon Merkle cap)",
+            "value": value, "unit": "ms/NTT", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 (Goldilocks mod 2^64-2^32+1)", "data": "synthetic",
+            "config": {"workload": "configs[1]: 2^%d-row x %d-column trace, forward NTT per column "
+                                   "(natural->bit-reversed) + Poseidon Merkle cap height %d" % (log_n, k, CAP_H),
+                       "log_n": log_n, "columns": k, "cap_height": CAP_H, "sharding": "independent traces per GPU"},
+            "roofline": roof, "roofline_ntt": roof_ntt,
+            "kernels_ms_per_step": {name: d["total_ms"] / args.steps for name, d in prof.items()},
+            "poseidon_perms_per_s": (perms / (leaf_ms * 1e-3)) if leaf_ms else None,
+            "merkle_levels_ms": lvl["total_ms"] / args.steps,
+            "cpu_baseline": base,
+        }
+        print(json.dumps(out))
+    data.free()
+    cap.free()
+    prover.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,8 @@ ABI = {
     "cp_event_destroy": (ctypes.c_int, [_vp, _vp]),
     "cp_event_record": (ctypes.c_int, [_vp, _vp]),
     "cp_event_elapsed_ms": (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(ctypes.c_float)]),
+    "cp_profile_begin": (ctypes.c_int, [_vp]),
+    "cp_profile_end": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
     "cp_ntt_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
                                   ctypes.c_uint, ctypes.c_uint64]),
     "cp_ntt": (ctypes.c_int, [_vp, _u64p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint,
@@ -171,6 +173,15 @@ class Prover:
         ms = ctypes.c_float()
         self._check(self.lib.cp_event_elapsed_ms(self.ctx, e0, e1, ctypes.byref(ms)))
         return ms.value
+
+    def profile_begin(self):
+        self._check(self.lib.cp_profile_begin(self.ctx))
+
+    def profile_end(self):
+        import json
+        buf = ctypes.create_string_buffer(1 << 16)
+        self._check(self.lib.cp_profile_end(self.ctx, buf, len(buf)))
+        return json.loads(buf.value.decode())
 
     # ---- device-resident entry points ----------------------------------------------------
     def ntt_dev(self, buf_ptr, log_n, batch=1, stride=None, flags=0, shift=0):

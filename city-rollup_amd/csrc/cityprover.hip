@@ -35,6 +35,12 @@ struct cp_ctx {
   // scratch buffer reused by natural-order NTT epilogues / merkle host paths
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
+  // optional per-kernel hipEvent timing (cp_profile_begin / cp_profile_end)
+  bool profiling = false;
+  struct ProfRec { const char *name; hipEvent_t e0, e1; };
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> prof_pool;
+  std::map<std::string, std::pair<uint64_t, double>> prof_acc;  // name -> (launches, total ms)
 };
 
 namespace {
@@ -86,6 +92,48 @@ int ensure_scratch(cp_ctx *ctx, size_t bytes) {
   ctx->scratch_bytes = bytes;
   return CP_OK;
 }
+
+hipEvent_t prof_event(cp_ctx *ctx) {
+  if (!ctx->prof_pool.empty()) {
+    hipEvent_t e = ctx->prof_pool.back();
+    ctx->prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void prof_flush(cp_ctx *ctx) {
+  for (auto &r : ctx->prof_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      auto &acc = ctx->prof_acc[r.name];
+      acc.first += 1;
+      acc.second += ms;
+    }
+    ctx->prof_pool.push_back(r.e0);
+    ctx->prof_pool.push_back(r.e1);
+  }
+  ctx->prof_recs.clear();
+}
+
+// Launch `kernel` on the context stream; when profiling is on, bracket it with HIP events.
+#define LAUNCH(ctx, name, kernel, grid, block, ...)                                      \
+  do {                                                                                   \
+    cp_ctx::ProfRec pr__{name, nullptr, nullptr};                                        \
+    if ((ctx)->profiling) {                                                              \
+      if ((ctx)->prof_recs.size() >= 8192) prof_flush(ctx);                              \
+      pr__.e0 = prof_event(ctx);                                                         \
+      pr__.e1 = prof_event(ctx);                                                         \
+      (void)hipEventRecord(pr__.e0, (ctx)->stream);                                      \
+    }                                                                                    \
+    hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);              \
+    if ((ctx)->profiling) {                                                              \
+      (void)hipEventRecord(pr__.e1, (ctx)->stream);                                      \
+      (ctx)->prof_recs.push_back(pr__);                                                  \
+    }                                                                                    \
+    HIP_TRY(ctx, hipGetLastError());                                                     \
+  } while (0)
 
 // 3-level power table of `base`, cached per ctx
 int get_pow_table(cp_ctx *ctx, uint64_t base, const uint64_t **out) {
@@ -178,10 +226,9 @@ int run_dif(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stride,
     a.coset_post = 0;
     dim3 grid((unsigned)(((size_t)1 << outer_bits) >> c), (unsigned)batch);
     if (q_after == 0)
-      hipLaunchKernelGGL(ntt::k_dif_pass<true>, grid, dim3(ntt::THREADS), 0, ctx->stream, a);
+      LAUNCH(ctx, "ntt_dif_pass_rows", ntt::k_dif_pass<true>, grid, dim3(ntt::THREADS), a);
     else
-      hipLaunchKernelGGL(ntt::k_dif_pass<false>, grid, dim3(ntt::THREADS), 0, ctx->stream, a);
-    HIP_TRY(ctx, hipGetLastError());
+      LAUNCH(ctx, "ntt_dif_pass_cols", ntt::k_dif_pass<false>, grid, dim3(ntt::THREADS), a);
     q = q_after;
     first = false;
   }
@@ -192,9 +239,8 @@ int bitrev_copy(cp_ctx *ctx, const uint64_t *src, uint64_t *dst, size_t src_stri
                 size_t dst_stride, int log_n, size_t batch, const uint64_t *stab) {
   size_t n = (size_t)1 << log_n;
   dim3 grid(blocks_for(n, 256), (unsigned)batch);
-  hipLaunchKernelGGL(ntt::k_bitrev_copy, grid, dim3(256), 0, ctx->stream, src, dst, src_stride,
-                     dst_stride, log_n, stab);
-  HIP_TRY(ctx, hipGetLastError());
+  LAUNCH(ctx, "ntt_bitrev_copy", ntt::k_bitrev_copy, grid, dim3(256), src, dst, src_stride, dst_stride,
+         log_n, stab);
   return CP_OK;
 }
 
@@ -222,9 +268,8 @@ int merkle_from_digests(cp_ctx *ctx, uint64_t *level0, size_t n_leaves, int cap_
     if (np == cap_n) dst = cap_dev;
     else if (digests_dev) { dst = next_slot; next_slot += np * 4; }
     else { dst = pp[pi]; pi ^= 1; }
-    hipLaunchKernelGGL(merkle::k_level, dim3(blocks_for(np, merkle::THREADS)),
-                       dim3(merkle::THREADS), 0, ctx->stream, cur, np, dst);
-    HIP_TRY(ctx, hipGetLastError());
+    LAUNCH(ctx, "merkle_level", merkle::k_level, dim3(blocks_for(np, merkle::THREADS)),
+           dim3(merkle::THREADS), cur, np, dst);
     cur = dst;
     n = np;
   }
@@ -294,6 +339,8 @@ void cp_ctx_destroy(cp_ctx *ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  prof_flush(ctx);
+  for (auto e : ctx->prof_pool) hipEventDestroy(e);
   for (auto &kv : ctx->pow_tables) hipFree(kv.second.dev);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -367,6 +414,35 @@ int cp_event_elapsed_ms(cp_ctx *ctx, void *start, void *stop, float *ms_out) {
   if (!start || !stop || !ms_out) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL argument");
   HIP_TRY(ctx, hipEventSynchronize((hipEvent_t)stop));
   HIP_TRY(ctx, hipEventElapsedTime(ms_out, (hipEvent_t)start, (hipEvent_t)stop));
+  return CP_OK;
+}
+
+int cp_profile_begin(cp_ctx *ctx) {
+  CHECK_CTX(ctx);
+  prof_flush(ctx);
+  ctx->prof_acc.clear();
+  ctx->profiling = true;
+  return CP_OK;
+}
+int cp_profile_end(cp_ctx *ctx, char *json_out, size_t cap) {
+  CHECK_CTX(ctx);
+  ctx->profiling = false;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  prof_flush(ctx);
+  std::string js = "{";
+  bool first = true;
+  for (auto &kv : ctx->prof_acc) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s\"%s\": {\"launches\": %llu, \"total_ms\": %.6f}", first ? "" : ", ",
+             kv.first.c_str(), (unsigned long long)kv.second.first, kv.second.second);
+    js += buf;
+    first = false;
+  }
+  js += "}";
+  if (json_out && cap) {
+    if (js.size() + 1 > cap) return set_error(ctx, CP_ERR_INVALID_ARG, "profile buffer too small (%zu needed)", js.size() + 1);
+    memcpy(json_out, js.c_str(), js.size() + 1);
+  }
   return CP_OK;
 }
 
@@ -446,9 +522,7 @@ int cp_lde_dev(cp_ctx *ctx, const uint64_t *coeffs, size_t in_stride, int log_n,
   if (batch > 65535) return set_error(ctx, CP_ERR_INVALID_ARG, "batch %zu > 65535", batch);
   if (flags & ~CP_NTT_BITREV_OUT) return set_error(ctx, CP_ERR_INVALID_ARG, "unsupported flags 0x%x", flags);
   dim3 grid(blocks_for(N, 256), (unsigned)batch);
-  hipLaunchKernelGGL(ntt::k_pad_copy, grid, dim3(256), 0, ctx->stream, coeffs, out, in_stride,
-                     out_stride, n, N);
-  HIP_TRY(ctx, hipGetLastError());
+  LAUNCH(ctx, "lde_pad_copy", ntt::k_pad_copy, grid, dim3(256), coeffs, out, in_stride, out_stride, n, N);
   return cp_ntt_dev(ctx, out, log_n + rate_bits, batch, out_stride,
                     (flags & CP_NTT_BITREV_OUT) | CP_NTT_COSET, coset_shift);
 }
@@ -459,9 +533,8 @@ int cp_poseidon_permute_dev(cp_ctx *ctx, uint64_t *states, size_t count) {
   CHECK_CTX(ctx);
   if (count == 0) return CP_OK;
   if (!states) return set_error(ctx, CP_ERR_INVALID_ARG, "states is NULL");
-  hipLaunchKernelGGL(merkle::k_permute, dim3(blocks_for(count, merkle::THREADS)),
-                     dim3(merkle::THREADS), 0, ctx->stream, states, count);
-  HIP_TRY(ctx, hipGetLastError());
+  LAUNCH(ctx, "poseidon_permute", merkle::k_permute, dim3(blocks_for(count, merkle::THREADS)),
+         dim3(merkle::THREADS), states, count);
   return CP_OK;
 }
 
@@ -487,9 +560,8 @@ int cp_hash_no_pad(cp_ctx *ctx, const uint64_t *in_host, size_t count, size_t le
   CP_TRY(ensure_scratch(ctx, in_al + out_bytes));
   uint64_t *din = (uint64_t *)ctx->scratch, *dout = (uint64_t *)((char *)ctx->scratch + in_al);
   if (in_bytes) CP_TRY(cp_h2d(ctx, din, in_host, in_bytes));
-  hipLaunchKernelGGL(merkle::k_leaf_hash_rows, dim3(blocks_for(count, merkle::THREADS)),
-                     dim3(merkle::THREADS), 0, ctx->stream, din, count, (int)len, dout, 1);
-  HIP_TRY(ctx, hipGetLastError());
+  LAUNCH(ctx, "leaf_hash_rows", merkle::k_leaf_hash_rows, dim3(blocks_for(count, merkle::THREADS)),
+         dim3(merkle::THREADS), din, count, (int)len, dout, 1);
   return cp_d2h(ctx, digests_host, dout, out_bytes);
 }
 
@@ -503,9 +575,8 @@ int cp_two_to_one(cp_ctx *ctx, const uint64_t *left_host, const uint64_t *right_
   uint64_t *l = (uint64_t *)ctx->scratch, *r = l + count * 4, *o = r + count * 4;
   CP_TRY(cp_h2d(ctx, l, left_host, b));
   CP_TRY(cp_h2d(ctx, r, right_host, b));
-  hipLaunchKernelGGL(merkle::k_two_to_one, dim3(blocks_for(count, merkle::THREADS)),
-                     dim3(merkle::THREADS), 0, ctx->stream, l, r, count, o);
-  HIP_TRY(ctx, hipGetLastError());
+  LAUNCH(ctx, "two_to_one", merkle::k_two_to_one, dim3(blocks_for(count, merkle::THREADS)),
+         dim3(merkle::THREADS), l, r, count, o);
   return cp_d2h(ctx, out_host, o, b);
 }
 
@@ -528,10 +599,8 @@ int cp_merkle_cols_dev(cp_ctx *ctx, const uint64_t *cols, size_t n_leaves, size_
     CP_TRY(ensure_scratch(ctx, n_leaves * 32 * 2));
     level0 = (uint64_t *)ctx->scratch;
   }
-  hipLaunchKernelGGL(merkle::k_leaf_hash_cols, dim3(blocks_for(n_leaves, merkle::THREADS)),
-                     dim3(merkle::THREADS), 0, ctx->stream, cols, n_leaves, (int)leaf_len, col_stride,
-                     level0);
-  HIP_TRY(ctx, hipGetLastError());
+  LAUNCH(ctx, "leaf_hash_cols", merkle::k_leaf_hash_cols, dim3(blocks_for(n_leaves, merkle::THREADS)),
+         dim3(merkle::THREADS), cols, n_leaves, (int)leaf_len, col_stride, level0);
   return merkle_from_digests(ctx, level0, n_leaves, cap_height,
                              (digests_dev && n_leaves > cap_n) ? digests_dev : nullptr, cap_dev, true);
 }

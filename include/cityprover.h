@@ -69,6 +69,14 @@ int cp_event_destroy(cp_ctx *ctx, void *event);
 int cp_event_record(cp_ctx *ctx, void *event);
 int cp_event_elapsed_ms(cp_ctx *ctx, void *start, void *stop, float *ms_out); /* syncs on `stop` */
 
+/* Per-kernel timing with HIP events on the context stream: between cp_profile_begin and
+ * cp_profile_end every kernel launch of this ctx is bracketed by an event pair. cp_profile_end
+ * syncs and writes a JSON object {"<kernel>": {"launches": n, "total_ms": t}, ...} (NUL-terminated)
+ * into json_out. (Counterpart of the reference's per-job TraceTimer,
+ * city_common/src/logging/trace_timer.rs:32-70, at kernel granularity.) */
+int cp_profile_begin(cp_ctx *ctx);
+int cp_profile_end(cp_ctx *ctx, char *json_out, size_t cap);
+
 /* ---- NTT over Goldilocks -------------------------------------------------------------
  * Replaces plonky2_field's `fft_with_options` / `ifft_with_options` / `PolynomialCoeffs::
  * coset_fft_with_options` as used by `PolynomialBatch::from_values` inside CircuitData::prove
