@@ -168,16 +168,6 @@ uint64_t root_of_unity(int log_n, bool inverse) {
 
 int upload_constants(cp_ctx *ctx) {
   HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_RC), POSEIDON_RC, sizeof POSEIDON_RC));
-  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_FAST_FIRST), POSEIDON_FAST_FIRST,
-                                 sizeof POSEIDON_FAST_FIRST));
-  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_FAST_K), POSEIDON_FAST_K,
-                                 sizeof POSEIDON_FAST_K));
-  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_FAST_VS), POSEIDON_FAST_VS,
-                                 sizeof POSEIDON_FAST_VS));
-  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_FAST_WHATS), POSEIDON_FAST_WHATS,
-                                 sizeof POSEIDON_FAST_WHATS));
-  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_FAST_INIT), POSEIDON_FAST_INIT,
-                                 sizeof POSEIDON_FAST_INIT));
   return CP_OK;
 }
 

@@ -4,10 +4,18 @@
 // reference; call sites: city_crypto/src/hash/traits/hasher.rs:77-159 and every Merkle tree /
 // challenger use inside `CircuitData::prove`).
 //
-// One lane owns one 12-element state (24 VGPRs): no cross-lane traffic, the work is pure
-// 32-bit integer VALU. The MDS layer has entries <= 41, so it is evaluated on the 32-bit halves
-// of each element with 64-bit accumulators and a single 96-bit reduction per output instead of
-// 144 modular multiplications.
+// One lane owns one 12-element state (24 VGPRs): no cross-lane traffic, pure 32-bit integer VALU.
+// What shapes the code (measured on MI355X, profiles/r01_*): `v_mad_u64_u32` is quarter rate
+// (8 cycles per wave64) and everything else is full rate (2 cycles), so
+//   * the S-box (x^7 = 4 modular multiplications, 14 mads) keeps 64-bit multiplies, but
+//   * the MDS layer (circulant, entries <= 41, + diag 8) uses NO multiplies at all: each element
+//     is split into three 22-bit limbs and the length-12 cyclic convolution is evaluated per limb
+//     in wrap-around 32-bit arithmetic through the CRT split
+//         x^12-1 = (x^6-1)(x^6+1),  x^6-1 = (x^3-1)(x^3+1)
+//     whose transformed kernels are all +-powers of two ([16,16,32], [-1,-8,2], [2,-4,16,1,-1,-1])
+//     -> ~96 shift-adds per limb instead of 288 quarter-rate mads per state.
+//   * state is carried lazily (any u64 congruent to the value); the next round's constant is
+//     folded into the 96-bit recombination, and only the final output is canonicalised.
 #pragma once
 #include "gl.h"
 #include "poseidon_tables.h"
@@ -20,138 +28,163 @@ constexpr int HALF_FULL = 4;
 constexpr int PARTIAL = 22;
 constexpr int ROUNDS = 2 * HALF_FULL + PARTIAL;
 
-// device copies of the tables (uniform indices -> scalar loads)
+// device copy of the round constants (uniform index -> scalar loads)
 __constant__ uint64_t d_RC[ROUNDS * W];
-__constant__ uint64_t d_FAST_FIRST[W];
-__constant__ uint64_t d_FAST_K[PARTIAL];
-__constant__ uint64_t d_FAST_VS[PARTIAL * 11];
-__constant__ uint64_t d_FAST_WHATS[PARTIAL * 11];
-__constant__ uint64_t d_FAST_INIT[11 * 11];
 
-// value = lo + 2^32 * hi_acc  (lo_acc, hi_acc < 2^44)  -> canonical
-__device__ __forceinline__ uint64_t reduce_split(uint64_t lo_acc, uint64_t hi_acc) {
-  uint64_t lo = lo_acc + (hi_acc << 32);
-  uint64_t hi = (hi_acc >> 32) + (lo < lo_acc ? 1 : 0);  // < 2^13
-  // hi * 2^64 == hi * EPS
-  uint64_t t = (hi << 32) - hi;
-  uint64_t r = lo + t;
-  if (r < t) r += gl::EPS;
-  return gl::canon(r);
+GL_HD uint64_t rc(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return d_RC[i];
+#else
+  return POSEIDON_RC[i];
+#endif
 }
 
-__device__ __forceinline__ void mds_layer(uint64_t (&s)[W]) {
-  uint32_t lo[W], hi[W];
+// ---- lazy field helpers: inputs/outputs are arbitrary u64 congruent to the value ----------
+// 128-bit (w3:w2:w1:w0) -> lazy u64, explicit 32-bit carry chains (no 64-bit compares/selects):
+//   r = (w1:w0) - w3 + w2*(2^32-1), each wrap of 2^64 compensated by -+(2^32-1)
+GL_HD uint64_t reduce_words_lazy(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+  unsigned b, c;
+  uint32_t t0l = __builtin_subc(w0, w3, 0u, &b);
+  uint32_t t0h = __builtin_subc(w1, 0u, b, &b);
+  uint32_t m = 0u - b;  // borrowed 2^64 == EPS: subtract EPS (== m)
+  t0l = __builtin_subc(t0l, m, 0u, &b);
+  t0h = __builtin_subc(t0h, 0u, b, &b);
+  uint32_t t1l = __builtin_subc(0u, w2, 0u, &b);  // w2 * (2^32 - 1) = (w2 << 32) - w2
+  uint32_t t1h = __builtin_subc(w2, 0u, b, &b);
+  uint32_t rl = __builtin_addc(t0l, t1l, 0u, &c);
+  uint32_t rh = __builtin_addc(t0h, t1h, c, &c);
+  uint32_t m2 = 0u - c;  // carried 2^64 == EPS: add EPS (== m2)
+  rl = __builtin_addc(rl, m2, 0u, &c);
+  rh = __builtin_addc(rh, 0u, c, &c);
+  return ((uint64_t)rh << 32) | rl;
+}
+GL_HD uint64_t reduce128_lazy(uint64_t lo, uint64_t hi) {
+  return reduce_words_lazy((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+// 64x64 -> 128 as exactly four 32x32+64 multiply-adds (v_mad_u64_u32), then the lazy reduction
+GL_HD uint64_t mul_lazy(uint64_t a, uint64_t b) {
+  uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+  uint64_t p00 = (uint64_t)a0 * b0;
+  uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);
+  uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
+  uint64_t p11 = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+  return reduce_words_lazy((uint32_t)p00, (uint32_t)p10, (uint32_t)p11, (uint32_t)(p11 >> 32));
+}
+GL_HD uint64_t sbox_lazy(uint64_t x) {
+  uint64_t x2 = mul_lazy(x, x), x4 = mul_lazy(x2, x2), x3 = mul_lazy(x, x2);
+  return mul_lazy(x3, x4);
+}
+GL_HD uint64_t add_const_lazy(uint64_t a, uint64_t c) {  // c canonical
+  uint64_t s = a + c;
+  if (s < a) {  // wrapped: 2^64 == EPS
+    s += gl::EPS;
+    if (s < gl::EPS) s += gl::EPS;  // (cannot happen for c < p, kept for safety)
+  }
+  return s;
+}
+
+// ---- MDS layer on one 22-bit limb plane, arithmetic mod 2^32 (exact: true results < 2^31) ----
+// y[r] = sum_i C[i] * s[(i+r) % 12] + 8*s[0]*[r==0],  C = {17,15,41,16,2,28,13,13,39,18,34,20}
+GL_HD void mds_limb(const uint32_t (&s)[W], uint32_t (&y)[W]) {
+  uint32_t a[6], b[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    a[i] = s[i] + s[i + 6];
+    b[i] = s[i] - s[i + 6];
+  }
+  // cyclic-6 part: a (*) [15,24,18,17,40,14]  via  (x^3-1)(x^3+1)
+  uint32_t aa0 = a[0] + a[3], aa1 = a[1] + a[4], aa2 = a[2] + a[5];
+  uint32_t ab0 = a[0] - a[3], ab1 = a[1] - a[4], ab2 = a[2] - a[5];
+  uint32_t T16 = (aa0 + aa1 + aa2) << 4;
+  uint32_t E0 = T16 + (aa2 << 4), E1 = T16 + (aa0 << 4), E2 = T16 + (aa1 << 4);
+  uint32_t F0 = (ab2 << 3) - ab0 - (ab1 << 1);
+  uint32_t F1 = 0u - (ab0 << 3) - ab1 - (ab2 << 1);
+  uint32_t F2 = (ab0 << 1) - (ab1 << 3) - ab2;
+  uint32_t pc[6] = {E0 + F0, E1 + F1, E2 + F2, E0 - F0, E1 - F1, E2 - F2};
+  // negacyclic-6 part: b (*) [2,-4,16,1,-1,-1] mod (x^6+1)
+  // V[k] = sum_{i+j=k} b[i]N[j] - sum_{i+j=k+6} b[i]N[j]
+  uint32_t nb[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) nb[i] = 0u - b[i];
+  uint32_t v[6];
+  // N0=2 (<<1), N1=-4 (<<2, neg), N2=16 (<<4), N3=1, N4=-1, N5=-1
+  // k=0: b0N0 - (b1N5 + b2N4 + b3N3 + b4N2 + b5N1)
+  v[0] = (b[0] << 1) + b[1] + b[2] + nb[3] + (nb[4] << 4) + (b[5] << 2);
+  // k=1: b0N1 + b1N0 - (b2N5 + b3N4 + b4N3 + b5N2)
+  v[1] = (nb[0] << 2) + (b[1] << 1) + b[2] + b[3] + nb[4] + (nb[5] << 4);
+  // k=2: b0N2 + b1N1 + b2N0 - (b3N5 + b4N4 + b5N3)
+  v[2] = (b[0] << 4) + (nb[1] << 2) + (b[2] << 1) + b[3] + b[4] + nb[5];
+  // k=3: b0N3 + b1N2 + b2N1 + b3N0 - (b4N5 + b5N4)
+  v[3] = b[0] + (b[1] << 4) + (nb[2] << 2) + (b[3] << 1) + b[4] + b[5];
+  // k=4: b0N4 + b1N3 + b2N2 + b3N1 + b4N0 - (b5N5)
+  v[4] = nb[0] + b[1] + (b[2] << 4) + (nb[3] << 2) + (b[4] << 1) + b[5];
+  // k=5: b0N5 + b1N4 + b2N3 + b3N2 + b4N1 + b5N0
+  v[5] = nb[0] + nb[1] + b[2] + (b[3] << 4) + (nb[4] << 2) + (b[5] << 1);
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    y[i] = pc[i] + v[i];
+    y[i + 6] = pc[i] - v[i];
+  }
+  y[0] += s[0] << 3;
+}
+
+// y = y0 + 2^22 y1 + 2^44 y2 + c  (y* < 2^31, c < 2^64)  ->  lazy u64
+GL_HD uint64_t recombine(uint32_t y0, uint32_t y1, uint32_t y2, uint64_t c) {
+  uint64_t v = (uint64_t)y0 + ((uint64_t)y1 << 22);  // < 2^54
+  uint64_t w_lo = (uint64_t)y2 << 44;
+  uint32_t top = y2 >> 20;                            // weight 2^64
+  uint64_t t = v + w_lo;
+  top += (t < w_lo);
+  uint64_t t2 = t + c;
+  top += (t2 < c);
+  uint64_t u = ((uint64_t)top << 32) - top;           // top * (2^32 - 1)
+  uint64_t r = t2 + u;
+  if (r < u) r += gl::EPS;
+  return r;
+}
+
+// s <- MDS * s + next_rc   (next_rc_base < 0: no constant)
+GL_HD void mds_layer(uint64_t (&s)[W], int next_rc_base) {
+  uint32_t l0[W], l1[W], l2[W];
 #pragma unroll
   for (int i = 0; i < W; i++) {
-    lo[i] = (uint32_t)s[i];
-    hi[i] = (uint32_t)(s[i] >> 32);
+    uint32_t lo = (uint32_t)s[i], hi = (uint32_t)(s[i] >> 32);
+    l0[i] = lo & 0x3FFFFFu;
+    l1[i] = ((lo >> 22) | (hi << 10)) & 0x3FFFFFu;
+    l2[i] = hi >> 12;
   }
-  constexpr uint32_t C[W] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  uint32_t y0[W], y1[W], y2[W];
+  mds_limb(l0, y0);
+  mds_limb(l1, y1);
+  mds_limb(l2, y2);
 #pragma unroll
-  for (int r = 0; r < W; r++) {
-    uint64_t al = 0, ah = 0;
-#pragma unroll
-    for (int i = 0; i < W; i++) {
-      al += (uint64_t)lo[(i + r) % W] * C[i];
-      ah += (uint64_t)hi[(i + r) % W] * C[i];
-    }
-    if (r == 0) {
-      al += (uint64_t)lo[0] << 3;
-      ah += (uint64_t)hi[0] << 3;
-    }
-    s[r] = reduce_split(al, ah);
-  }
+  for (int i = 0; i < W; i++)
+    s[i] = recombine(y0[i], y1[i], y2[i], next_rc_base >= 0 ? rc(next_rc_base + i) : 0);
 }
 
-template <bool FULL>
-__device__ __forceinline__ void round_naive(uint64_t (&s)[W], int rnd) {
+// Textbook round structure: 30 x (constants, S-box, MDS); state lazy, canonical on exit.
+GL_HD void permute(uint64_t (&s)[W]) {
 #pragma unroll
-  for (int i = 0; i < W; i++) s[i] = gl::add(s[i], d_RC[rnd * W + i]);
-  if (FULL) {
+  for (int i = 0; i < W; i++) s[i] = add_const_lazy(s[i], rc(i));
+#pragma unroll 1
+  for (int r = 0; r < HALF_FULL; r++) {
 #pragma unroll
-    for (int i = 0; i < W; i++) s[i] = gl::pow7(s[i]);
-  } else {
-    s[0] = gl::pow7(s[0]);
-  }
-  mds_layer(s);
-}
-
-// Textbook form: 30 x (constants, S-box, dense small-coefficient MDS).
-__device__ __forceinline__ void permute_naive(uint64_t (&s)[W]) {
-#pragma unroll 1
-  for (int r = 0; r < HALF_FULL; r++) round_naive<true>(s, r);
-#pragma unroll 1
-  for (int r = HALF_FULL; r < HALF_FULL + PARTIAL; r++) round_naive<false>(s, r);
-#pragma unroll 1
-  for (int r = HALF_FULL + PARTIAL; r < ROUNDS; r++) round_naive<true>(s, r);
-}
-
-// Sparse-factorised partial rounds (tables from gen_tables.py::fast_partial).
-__device__ __forceinline__ void permute_fast(uint64_t (&s)[W]) {
-#pragma unroll 1
-  for (int r = 0; r < HALF_FULL; r++) round_naive<true>(s, r);
-#pragma unroll
-  for (int i = 0; i < W; i++) s[i] = gl::add(s[i], d_FAST_FIRST[i]);
-  {
-    uint64_t t[11];
-#pragma unroll 1
-    for (int rr = 0; rr < 11; rr++) {
-      // 11-term dot product with a 128+ bit accumulator, one reduction
-      uint64_t alo = 0, ahi = 0, acar = 0;
-#pragma unroll
-      for (int cc = 0; cc < 11; cc++) {
-        uint64_t lo, hi;
-        gl::mul_wide(d_FAST_INIT[rr * 11 + cc], s[1 + cc], lo, hi);
-        alo += lo;
-        uint64_t c = alo < lo;
-        ahi += hi;
-        acar += (ahi < hi);
-        ahi += c;
-        acar += (ahi < c);
-      }
-      // value = alo + 2^64 ahi + 2^128 acar ; 2^128 == 2^32 * 2^96 == -2^32
-      uint64_t r = gl::reduce128(alo, ahi);
-      r = gl::sub(r, gl::canon(acar << 32));
-      t[rr] = r;
-    }
-#pragma unroll
-    for (int i = 0; i < 11; i++) s[1 + i] = t[i];
+    for (int i = 0; i < W; i++) s[i] = sbox_lazy(s[i]);
+    mds_layer(s, (r + 1) * W);
   }
 #pragma unroll 1
-  for (int i = 0; i < PARTIAL; i++) {
-    uint64_t s0 = gl::add(gl::pow7(s[0]), d_FAST_K[i]);
-    uint64_t alo, ahi, acar = 0;
-    gl::mul_wide(s0, 25, alo, ahi);  // m00 = 17 + 8
-#pragma unroll
-    for (int j = 0; j < 11; j++) {
-      uint64_t lo, hi;
-      gl::mul_wide(d_FAST_WHATS[i * 11 + j], s[1 + j], lo, hi);
-      alo += lo;
-      uint64_t c = alo < lo;
-      ahi += hi;
-      acar += (ahi < hi);
-      ahi += c;
-      acar += (ahi < c);
-    }
-    uint64_t d = gl::sub(gl::reduce128(alo, ahi), gl::canon(acar << 32));
-#pragma unroll
-    for (int j = 0; j < 11; j++) s[1 + j] = gl::add(s[1 + j], gl::mul(s0, d_FAST_VS[i * 11 + j]));
-    s[0] = d;
+  for (int r = HALF_FULL; r < HALF_FULL + PARTIAL; r++) {
+    s[0] = sbox_lazy(s[0]);
+    mds_layer(s, (r + 1) * W);
   }
 #pragma unroll 1
-  for (int r = HALF_FULL + PARTIAL; r < ROUNDS; r++) round_naive<true>(s, r);
-}
-
-#ifndef POSEIDON_VARIANT
-#define POSEIDON_VARIANT 0
-#endif
-
-__device__ __forceinline__ void permute(uint64_t (&s)[W]) {
-#if POSEIDON_VARIANT == 1
-  permute_fast(s);
-#else
-  permute_naive(s);
-#endif
+  for (int r = HALF_FULL + PARTIAL; r < ROUNDS; r++) {
+#pragma unroll
+    for (int i = 0; i < W; i++) s[i] = sbox_lazy(s[i]);
+    mds_layer(s, r + 1 < ROUNDS ? (r + 1) * W : -1);
+  }
+#pragma unroll
+  for (int i = 0; i < W; i++) s[i] = gl::canon(s[i]);
 }
 
 }  // namespace poseidon
