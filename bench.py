@@ -163,8 +163,8 @@ def main():
             return (d["total_ms"] / d["launches"], d["launches"]) if d else (None, 0)
 
         leaf_ms, _ = kern("leaf_hash_cols")
-        cols_ms, cols_l = kern("ntt_dif_pass_cols")
-        rows_ms, rows_l = kern("ntt_dif_pass_rows")
+        cols_ms, cols_l = kern("ntt16_cols")
+        rows_ms, rows_l = kern("ntt16_rows")
         lvl = prof.get("merkle_level", {"total_ms": 0.0, "launches": 0})
         # dominant kernel by time: the Poseidon leaf hash. Algorithmic bytes per launch:
         # 8*R*k read + 32*R digests written.
@@ -179,7 +179,7 @@ def main():
         # NTT: one pass reads + writes the batch once -> 16 B per element per pass
         pass_bytes = 16.0 * n * k
         ntt_ms = (cols_ms or 0) * (cols_l / max(args.steps, 1)) + (rows_ms or 0) * (rows_l / max(args.steps, 1))
-        roof_ntt = {"kernel": "ntt_dif_pass_*", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+        roof_ntt = {"kernel": "ntt16_cols + ntt16_rows (k_dif_pass16)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                     "algorithmic_bytes_per_ntt": 16.0 * n,
                     "achieved": 16.0 * n * k / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
                     "per_pass_GBs": {"cols": pass_bytes / (cols_ms * 1e-3) / 1e9 if cols_ms else None,

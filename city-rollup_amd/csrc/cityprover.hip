@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -15,6 +16,7 @@
 #include "gl.h"
 #include "merkle.h"
 #include "ntt.h"
+#include "ntt16.h"
 #include "poseidon.h"
 
 namespace {
@@ -191,9 +193,14 @@ int run_dif(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stride,
     if (remaining <= ntt::LOG_TILE_MAX) {
       L = remaining;  // last pass, q_after = 0
     } else {
-      // leave at least ... split as evenly as possible over ceil(remaining / 10) passes
-      int passes = (remaining + 9) / 10;
-      L = (remaining + passes - 1) / passes;
+      // keep the contiguous last pass at 12 bits when what is left in front of it is >= 4 bits
+      // (register radix-16 kernels need L >= 4); otherwise split evenly
+      int front = remaining - ntt::LOG_TILE_MAX;
+      if (front >= 4 && front <= ntt::LOG_TILE_MAX - 4) L = front;  // c = 12 - L >= 4: 128-B segments
+      else {
+        int passes = (remaining + 9) / 10;
+        L = (remaining + passes - 1) / passes;
+      }
     }
     int q_after = q - L;
     c = ntt::LOG_TILE_MAX - L;
@@ -215,10 +222,32 @@ int run_dif(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stride,
     a.coset_pre = stab_pre != nullptr;
     a.coset_post = 0;
     dim3 grid((unsigned)(((size_t)1 << outer_bits) >> c), (unsigned)batch);
-    if (q_after == 0)
-      LAUNCH(ctx, "ntt_dif_pass_rows", ntt::k_dif_pass<true>, grid, dim3(ntt::THREADS), a);
-    else
-      LAUNCH(ctx, "ntt_dif_pass_cols", ntt::k_dif_pass<false>, grid, dim3(ntt::THREADS), a);
+    bool done = false;
+    if (L >= 4 && L + c == ntt16::LOG_TILE && !getenv("CITYPROVER_NTT_V1")) {
+      // register radix-16 pass (ntt16.h)
+#define PASS16(LL)                                                                                   \
+  case LL:                                                                                           \
+    if (q_after == 0) {                                                                              \
+      if (inverse) LAUNCH(ctx, "ntt16_rows", (ntt16::k_dif_pass16<LL, 12 - LL, true, true>), grid, dim3(ntt16::THREADS), a);  \
+      else LAUNCH(ctx, "ntt16_rows", (ntt16::k_dif_pass16<LL, 12 - LL, true, false>), grid, dim3(ntt16::THREADS), a);        \
+    } else {                                                                                         \
+      if (inverse) LAUNCH(ctx, "ntt16_cols", (ntt16::k_dif_pass16<LL, 12 - LL, false, true>), grid, dim3(ntt16::THREADS), a); \
+      else LAUNCH(ctx, "ntt16_cols", (ntt16::k_dif_pass16<LL, 12 - LL, false, false>), grid, dim3(ntt16::THREADS), a);       \
+    }                                                                                                \
+    done = true;                                                                                     \
+    break;
+      switch (L) {
+        PASS16(4) PASS16(5) PASS16(6) PASS16(7) PASS16(8) PASS16(9) PASS16(10) PASS16(11) PASS16(12)
+        default: break;
+      }
+#undef PASS16
+    }
+    if (!done) {
+      if (q_after == 0)
+        LAUNCH(ctx, "ntt_dif_pass_rows", ntt::k_dif_pass<true>, grid, dim3(ntt::THREADS), a);
+      else
+        LAUNCH(ctx, "ntt_dif_pass_cols", ntt::k_dif_pass<false>, grid, dim3(ntt::THREADS), a);
+    }
     q = q_after;
     first = false;
   }

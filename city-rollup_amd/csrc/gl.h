@@ -20,48 +20,55 @@ constexpr uint64_t EPS = 0xFFFFFFFFULL;  // 2^64 mod p
 
 GL_HD uint64_t canon(uint64_t x) { return x >= P ? x - P : x; }
 
-// a, b canonical -> canonical
-GL_HD uint64_t add(uint64_t a, uint64_t b) {
-  uint64_t s = a + b;
-  // overflow past 2^64 or landing in [p, 2^64): subtract p (== add EPS mod 2^64)
-  return (s < a || s >= P) ? s + EPS : s;
-}
+GL_HD uint32_t lo32(uint64_t x) { return (uint32_t)x; }
+GL_HD uint32_t hi32(uint64_t x) { return (uint32_t)(x >> 32); }
+GL_HD uint64_t pack(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// The helpers below are phrased through unsigned __int128 so that LLVM legalises them into plain
+// v_sub_co/v_subb_co (v_add_co/v_addc_co) carry chains: 5 instructions per modular subtraction,
+// 7 per addition, no 64-bit compares/selects.
+typedef unsigned __int128 u128;
+
+// a, b canonical -> canonical.  a - b, plus p when it borrowed (p == -EPS mod 2^64)
 GL_HD uint64_t sub(uint64_t a, uint64_t b) {
-  uint64_t d = a - b;
-  return (a < b) ? d - EPS : d;
+  u128 d = (u128)a - b;
+  uint64_t borrowed = (uint64_t)(d >> 64);  // 0 or all ones
+  return (uint64_t)d - (borrowed & EPS);
 }
 GL_HD uint64_t neg(uint64_t a) { return a ? P - a : 0; }
+// a, b canonical -> canonical.  a + b == a - (p - b)
+GL_HD uint64_t add(uint64_t a, uint64_t b) { return sub(a, P - b); }
 
 // lazy add: a any u64, b any u64 -> u64 congruent to a+b (not canonical)
 GL_HD uint64_t add_lazy(uint64_t a, uint64_t b) {
   uint64_t s = a + b;
   if (s < a) {          // wrapped: + 2^64 == + EPS
-    s += EPS;           // cannot wrap twice unless s >= 2^64-EPS, handled below
+    s += EPS;
     if (s < EPS) s += EPS;
   }
   return s;
 }
 
-// 128-bit (hi:lo) -> canonical
-GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) {
-  uint64_t hh = hi >> 32, hl = hi & EPS;
-  uint64_t t0 = lo - hh;
-  if (lo < hh) t0 -= EPS;
-  uint64_t t1 = (hl << 32) - hl;  // hl * (2^32 - 1)
-  uint64_t r = t0 + t1;
-  if (r < t1) r += EPS;
-  return canon(r);
+// 128-bit (hi:lo) -> lazy u64 (any representative):  lo - hi_hi + hi_lo*(2^32-1),
+// every wrap of 2^64 repaid by -+EPS
+GL_HD uint64_t reduce128_lazy(uint64_t lo, uint64_t hi) {
+  uint32_t w2 = lo32(hi), w3 = hi32(hi);
+  u128 t = (u128)lo - w3;
+  uint64_t t0 = (uint64_t)t - ((uint64_t)(t >> 64) & EPS);
+  u128 s = (u128)t0 + (((uint64_t)w2 << 32) - w2);
+  return (uint64_t)s + ((0 - (uint64_t)(s >> 64)) & EPS);
 }
+GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) { return canon(reduce128_lazy(lo, hi)); }
 
+// 64x64 -> 128 as exactly four 32x32+64 multiply-adds (v_mad_u64_u32)
 GL_HD void mul_wide(uint64_t a, uint64_t b, uint64_t &lo, uint64_t &hi) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  lo = a * b;
-  hi = __umul64hi(a, b);
-#else
-  unsigned __int128 m = (unsigned __int128)a * b;
-  lo = (uint64_t)m;
-  hi = (uint64_t)(m >> 64);
-#endif
+  uint32_t a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+  uint64_t p00 = (uint64_t)a0 * b0;
+  uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);
+  uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
+  uint64_t p11 = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+  lo = pack(lo32(p00), lo32(p10));
+  hi = p11;
 }
 
 GL_HD uint64_t mul(uint64_t a, uint64_t b) {

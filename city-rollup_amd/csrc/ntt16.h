@@ -1,0 +1,200 @@
+// Register radix-16 DIF passes for the Goldilocks NTT (gfx950).
+//
+// Same pass decomposition as ntt.h (one pass = L butterfly stages over index bits [q, q+L) of a
+// 4096-element tile, then the inter-pass twiddle), but the stages run in REGISTERS: every thread
+// owns 16 elements and executes up to four radix-2 DIF stages on them per round, so the tile
+// crosses LDS once per round (<= 2 exchanges per pass) instead of once per stage, and the first
+// load / last store go straight between HBM and registers.
+//
+// Twiddles inside a round split into (a) a power of omega_16, which in Goldilocks is +-2^(12k)
+// (2 has order 192 mod p and omega_16 = 2^156): a shift, never a multiplication; and (b) one
+// thread-uniform factor per stage, omega_{2^(f+b+1)}^(r_lo): one table lookup and three squarings
+// per round. The last round of a pass (f = 0) needs no multiplications at all.
+#pragma once
+#include "gl.h"
+#include "ntt.h"
+
+namespace ntt16 {
+
+// x * 2^K mod p for a compile-time 0 <= K < 96, x canonical -> canonical
+template <int K>
+GL_HD uint64_t mul_pow2(uint64_t x) {
+  static_assert(K >= 0 && K < 96, "shift out of range");
+  if constexpr (K == 0) {
+    return x;
+  } else if constexpr (K < 64) {
+    return gl::reduce128(x << K, x >> (64 - K));
+  } else {
+    constexpr int J = K - 64;  // x*2^K = (x << J) * 2^64 ;  x << J = y0 + y1*2^64
+    uint64_t y0 = J ? (x << J) : x;
+    uint64_t y1 = J ? (x >> (64 - J)) : 0;           // < 2^J <= 2^31
+    uint64_t t = gl::reduce128(0, y0);               // y0 * 2^64
+    return gl::sub(t, y1 << 32);                     // y1 * 2^128 == -y1 * 2^32
+  }
+}
+
+// (u - v) * omega_16^E  (forward: omega_16 = 2^156, inverse: omega_16^-1 = 2^36), canonical
+template <bool INV, int E>
+GL_HD uint64_t diff_times_w16(uint64_t u, uint64_t v) {
+  constexpr int SH = ((INV ? 36 : 156) * (E & 15)) % 192;
+  constexpr bool NEG = SH >= 96;  // 2^96 == -1
+  constexpr int K = SH % 96;
+  uint64_t d = NEG ? gl::sub(v, u) : gl::sub(u, v);
+  return mul_pow2<K>(d);
+}
+
+// One DIF stage on the 16 registers at field bit B (pairs m, m + 2^B), with the thread-uniform
+// twiddle T (skipped when UNIT_T).
+template <bool INV, int B, bool UNIT_T>
+GL_HD void stage(uint64_t (&x)[16], uint64_t T) {
+#pragma unroll
+  for (int m = 0; m < 16; m++) {
+    if (m & (1 << B)) continue;
+    const int i = m & ((1 << B) - 1);  // position inside the half block
+    uint64_t u = x[m], v = x[m + (1 << B)];
+    x[m] = gl::add(u, v);
+    uint64_t d;
+    // omega_{2^(B+1)}^i = omega_16^(i << (3 - B))
+    switch (i << (3 - B)) {
+      case 0: d = diff_times_w16<INV, 0>(u, v); break;
+      case 1: d = diff_times_w16<INV, 1>(u, v); break;
+      case 2: d = diff_times_w16<INV, 2>(u, v); break;
+      case 3: d = diff_times_w16<INV, 3>(u, v); break;
+      case 4: d = diff_times_w16<INV, 4>(u, v); break;
+      case 5: d = diff_times_w16<INV, 5>(u, v); break;
+      case 6: d = diff_times_w16<INV, 6>(u, v); break;
+      default: d = diff_times_w16<INV, 7>(u, v); break;
+    }
+    x[m + (1 << B)] = UNIT_T ? d : gl::mul(d, T);
+  }
+}
+
+// NSTAGES DIF stages on the top bits of the 4-bit register field. T3 = omega_{2^(f+4)}^(r_lo).
+template <bool INV, int NSTAGES, bool UNIT_T>
+GL_HD void round16(uint64_t (&x)[16], uint64_t T3) {
+  uint64_t T2 = UNIT_T ? 1 : gl::sqr(T3);
+  stage<INV, 3, UNIT_T>(x, T3);
+  if constexpr (NSTAGES >= 2) {
+    stage<INV, 2, UNIT_T>(x, T2);
+  }
+  if constexpr (NSTAGES >= 3) {
+    uint64_t T1 = UNIT_T ? 1 : gl::sqr(T2);
+    stage<INV, 1, UNIT_T>(x, T1);
+    if constexpr (NSTAGES >= 4) {
+      uint64_t T0 = UNIT_T ? 1 : gl::sqr(T1);
+      stage<INV, 0, UNIT_T>(x, T0);
+    }
+  }
+}
+
+constexpr int LOG_TILE = 12;
+constexpr int THREADS = 1 << (LOG_TILE - 4);  // 256
+
+__device__ __forceinline__ int pad(int p) { return p + (p >> 4); }
+
+// global element index of tile position `pos`
+template <int L, int C, bool ROWS>
+__device__ __forceinline__ size_t gidx(int pos, uint32_t tile_id, int q) {
+  if (ROWS) return ((size_t)tile_id << LOG_TILE) + pos;  // q == 0: the tile is contiguous
+  uint32_t r = pos >> C, o = (tile_id << C) + (pos & ((1 << C) - 1));
+  return ((size_t)(o >> q) << (q + L)) | ((size_t)r << q) | (o & ((1u << q) - 1));
+}
+
+// One pass, L stages, tile = 2^L rows x 2^C outer indices (L + C == 12).
+template <int L, int C, bool ROWS, bool INV>
+__global__ __launch_bounds__(THREADS) void k_dif_pass16(ntt::PassArgs a) {
+  static_assert(L + C == LOG_TILE && L >= 4, "tile shape");
+  __shared__ uint64_t tile[(1 << LOG_TILE) + (1 << (LOG_TILE - 4))];
+  constexpr int B0 = ((L - 1) % 4) + 1;       // stages of the first round; the rest are full rounds
+  constexpr int NROUNDS = 1 + (L - B0) / 4;
+  const int t = threadIdx.x;
+  const int q = a.q;
+  uint64_t *poly = a.data + (size_t)blockIdx.y * a.stride;
+  uint64_t x[16];
+
+  // ---- round 0: field = r-bits [L-4, L) --------------------------------------------------
+  {
+    constexpr int f = L - 4;                  // r-bit position of the field
+    constexpr int F = ROWS ? f : C + f;       // position in tile-position space
+    const int P = ((t >> F) << (F + 4)) | (t & ((1 << F) - 1));
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+      size_t idx = gidx<L, C, ROWS>(P + (m << F), blockIdx.x, q);
+      uint64_t v = poly[idx];
+      if (a.coset_pre && a.first) v = gl::mul(v, ntt::pow_table(a.stab, idx));
+      x[m] = v;
+    }
+    if constexpr (f == 0) {
+      round16<INV, B0, true>(x, 1);
+    } else {
+      const int r = ROWS ? (P & ((1 << L) - 1)) : (P >> C);
+      const uint32_t r_lo = r & ((1 << f) - 1);
+      uint64_t T3 = ntt::pow_table(a.wtab, (uint64_t)r_lo << (a.log_n - f - 4));
+      round16<INV, B0, false>(x, T3);
+    }
+    if constexpr (NROUNDS > 1) {
+#pragma unroll
+      for (int m = 0; m < 16; m++) tile[pad(P + (m << F))] = x[m];
+    }
+  }
+  // ---- middle / last rounds -----------------------------------------------------------------
+  int Plast = 0;
+  constexpr int Flast = ROWS ? 0 : C;
+  if constexpr (NROUNDS == 1) {
+    constexpr int F = ROWS ? (L - 4) : C + (L - 4);
+    Plast = ((t >> F) << (F + 4)) | (t & ((1 << F) - 1));
+  }
+#pragma unroll
+  for (int k = 1; k < NROUNDS; k++) {
+    const int f = L - B0 - 4 * k;             // compile-time after unrolling
+    const int F = ROWS ? f : C + f;
+    const int P = ((t >> F) << (F + 4)) | (t & ((1 << F) - 1));
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = tile[pad(P + (m << F))];
+    if (f == 0) {
+      round16<INV, 4, true>(x, 1);
+      Plast = P;
+    } else {
+      const int r = ROWS ? (P & ((1 << L) - 1)) : (P >> C);
+      const uint32_t r_lo = r & ((1 << f) - 1);
+      uint64_t T3 = ntt::pow_table(a.wtab, (uint64_t)r_lo << (a.log_n - f - 4));
+      round16<INV, 4, false>(x, T3);
+#pragma unroll
+      for (int m = 0; m < 16; m++) tile[pad(P + (m << F))] = x[m];
+    }
+  }
+  // ---- epilogue: inter-pass twiddle, scaling, store -----------------------------------------
+  // the thread holds r = r_base + m (m = 0..15) for one (cc): k_loc(m) = rev_L(r_base) + rev4(m) << (L-4)
+  {
+    const int P = Plast;
+    if (!ROWS && q > 0) {
+      const uint32_t cc = P & ((1 << C) - 1);
+      const uint32_t r_base = P >> C;
+      const uint32_t o = (blockIdx.x << C) + cc;
+      const uint32_t lo = o & ((1u << q) - 1);
+      if (lo) {
+        // omega_{2^(q+L)}^(lo * k_loc) = W0 * G^rev4(m),  W0 = w^(lo*rev_L(r_base)),  G = w^(lo << (L-4))
+        const int sh = a.log_n - q - L;
+        uint64_t W0 = ntt::pow_table(a.wtab, ((uint64_t)lo * ntt::bitrev(r_base, L)) << sh);
+        uint64_t G = ntt::pow_table(a.wtab, ((uint64_t)lo << (L - 4)) << sh);
+        // walk j = 0..15 and apply to register m = rev4(j)
+        uint64_t w = W0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const int m = ((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3);
+          x[m] = gl::mul(x[m], w);
+          if (j < 15) w = gl::mul(w, G);
+        }
+      }
+    }
+    if (a.last && a.scale) {
+#pragma unroll
+      for (int m = 0; m < 16; m++) x[m] = gl::mul(x[m], a.scale);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) poly[gidx<L, C, ROWS>(P + (m << Flast), blockIdx.x, q)] = x[m];
+  }
+}
+
+}  // namespace ntt16

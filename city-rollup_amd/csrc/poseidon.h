@@ -40,35 +40,10 @@ GL_HD uint64_t rc(int i) {
 }
 
 // ---- lazy field helpers: inputs/outputs are arbitrary u64 congruent to the value ----------
-// 128-bit (w3:w2:w1:w0) -> lazy u64, explicit 32-bit carry chains (no 64-bit compares/selects):
-//   r = (w1:w0) - w3 + w2*(2^32-1), each wrap of 2^64 compensated by -+(2^32-1)
-GL_HD uint64_t reduce_words_lazy(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
-  unsigned b, c;
-  uint32_t t0l = __builtin_subc(w0, w3, 0u, &b);
-  uint32_t t0h = __builtin_subc(w1, 0u, b, &b);
-  uint32_t m = 0u - b;  // borrowed 2^64 == EPS: subtract EPS (== m)
-  t0l = __builtin_subc(t0l, m, 0u, &b);
-  t0h = __builtin_subc(t0h, 0u, b, &b);
-  uint32_t t1l = __builtin_subc(0u, w2, 0u, &b);  // w2 * (2^32 - 1) = (w2 << 32) - w2
-  uint32_t t1h = __builtin_subc(w2, 0u, b, &b);
-  uint32_t rl = __builtin_addc(t0l, t1l, 0u, &c);
-  uint32_t rh = __builtin_addc(t0h, t1h, c, &c);
-  uint32_t m2 = 0u - c;  // carried 2^64 == EPS: add EPS (== m2)
-  rl = __builtin_addc(rl, m2, 0u, &c);
-  rh = __builtin_addc(rh, 0u, c, &c);
-  return ((uint64_t)rh << 32) | rl;
-}
-GL_HD uint64_t reduce128_lazy(uint64_t lo, uint64_t hi) {
-  return reduce_words_lazy((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-}
-// 64x64 -> 128 as exactly four 32x32+64 multiply-adds (v_mad_u64_u32), then the lazy reduction
 GL_HD uint64_t mul_lazy(uint64_t a, uint64_t b) {
-  uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
-  uint64_t p00 = (uint64_t)a0 * b0;
-  uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);
-  uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
-  uint64_t p11 = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);
-  return reduce_words_lazy((uint32_t)p00, (uint32_t)p10, (uint32_t)p11, (uint32_t)(p11 >> 32));
+  uint64_t lo, hi;
+  gl::mul_wide(a, b, lo, hi);
+  return gl::reduce128_lazy(lo, hi);
 }
 GL_HD uint64_t sbox_lazy(uint64_t x) {
   uint64_t x2 = mul_lazy(x, x), x4 = mul_lazy(x2, x2), x3 = mul_lazy(x, x2);

@@ -24,3 +24,19 @@ void hs_mds_limb(const uint32_t *s, uint32_t *y) {
   for (int i = 0; i < 12; i++) y[i] = b[i];
 }
 }
+#include "../../city-rollup_amd/csrc/ntt16.h"
+extern "C" {
+#define MP(K) case K: return ntt16::mul_pow2<K>(x);
+uint64_t hs_mul_pow2(uint64_t x, int k) {
+  switch (k) {
+    MP(0) MP(1) MP(5) MP(12) MP(24) MP(31) MP(32) MP(33) MP(36) MP(48) MP(60) MP(63) MP(64) MP(65) MP(72) MP(84) MP(95)
+    default: return ~0ull;
+  }
+}
+void hs_round16(uint64_t *x, int inverse) {
+  uint64_t r[16];
+  for (int i = 0; i < 16; i++) r[i] = x[i];
+  if (inverse) ntt16::round16<true, 4, true>(r, 1); else ntt16::round16<false, 4, true>(r, 1);
+  for (int i = 0; i < 16; i++) x[i] = r[i];
+}
+}

@@ -66,3 +66,29 @@ def test_permutation_matches_oracle(hs):
     got = st.copy()
     hs.hs_poseidon_permute(got.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), got.shape[0])
     assert (got == O.permute_many(st).reshape(-1, 12)).all()
+
+
+def test_mul_pow2_shifts(hs):
+    hs.hs_mul_pow2.restype = ctypes.c_uint64
+    hs.hs_mul_pow2.argtypes = [ctypes.c_uint64, ctypes.c_int]
+    rng = np.random.default_rng(2)
+    vals = [int(x) % P for x in rng.integers(0, 2**64, 200, dtype=np.uint64)] + [0, 1, P - 1, P - 2, 0xFFFFFFFF,
+                                                                                 0xFFFFFFFF00000000, 1 << 63]
+    for k in (0, 1, 5, 12, 24, 31, 32, 33, 36, 48, 60, 63, 64, 65, 72, 84, 95):
+        for x in vals:
+            assert hs.hs_mul_pow2(x, k) == (x << k) % P, (x, k)
+
+
+def test_radix16_register_butterfly_is_a_16_point_dif_ntt(hs):
+    hs.hs_round16.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+    x = O.splitmix64_felts(5, 16)
+    x[0], x[1], x[2] = P - 1, 0, 1
+    got = x.copy()
+    hs.hs_round16(got.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 0)
+    assert (got == O.bit_reverse(O.ntt(x))).all()
+    # inverse direction: same network with omega^-1 (no 1/n scaling)
+    got = x.copy()
+    hs.hs_round16(got.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1)
+    inv16 = pow(16, P - 2, P)
+    want = O.bit_reverse(O.intt(x))
+    assert [int(v) * inv16 % P for v in got] == [int(v) for v in want]
