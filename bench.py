@@ -86,20 +86,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # control plane only (barrier + max-reduce of the timing)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-
     import cityprover as cp
+    from cityprover import dist as D
+
+    rank, local_rank, world = D.env_rank()
+    dist = D.init("gloo")  # control plane only: barrier + max-reduce of the timing, no data path
 
     prover = cp.Prover(local_rank)
     k, log_n, n = args.cols, args.log_n, 1 << args.log_n
-    host = splitmix64_felts(SEED + rank * 0x1000003, k * n).reshape(k, n)
+    # weak scaling: rank r commits its own trace (unit r of `world` independent units)
+    host = splitmix64_felts(D.unit_seed(SEED, D.shard_units(world, rank, world)[0]), k * n).reshape(k, n)
     data = prover.to_device(host)
     cap = prover.alloc(4 << CAP_H)
 
@@ -113,8 +109,7 @@ def main():
             pass
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        D.barrier(dist)
 
     def step():
         prover.ntt_dev(data.ptr, log_n, k, n, cp.NTT_BITREV_OUT)
@@ -146,12 +141,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     prof = prover.profile_end()
-    elapsed = t1 - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed = D.max_over_ranks(dist, t1 - t0)
 
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
