@@ -56,6 +56,8 @@ ABI = {
                                      _u64p]),
     "cp_commit_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "cp_commit_batch_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
 }
 
 
@@ -206,6 +208,11 @@ class Prover:
                    coeffs_ptr=None, digests_ptr=None):
         self._check(self.lib.cp_commit_dev(self.ctx, values_ptr, k, log_n, rate_bits, cap_height,
                                            coeffs_ptr, lde_ptr, digests_ptr, cap_ptr))
+
+    def commit_batch_dev(self, values_ptr, k, n_trees, log_n, rate_bits, cap_height, lde_ptr, caps_ptr,
+                         coeffs_ptr=None, digests_ptr=None):
+        self._check(self.lib.cp_commit_batch_dev(self.ctx, values_ptr, k, n_trees, log_n, rate_bits,
+                                                 cap_height, coeffs_ptr, lde_ptr, digests_ptr, caps_ptr))
 
     # ---- host-array conveniences (numpy in / numpy out) -----------------------------------
     def ntt(self, a, flags=0, shift=0):

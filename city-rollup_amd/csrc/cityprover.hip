@@ -10,6 +10,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/cityprover.h"
@@ -34,6 +35,9 @@ struct cp_ctx {
   hipStream_t stream = nullptr;
   std::string error;
   std::map<uint64_t, PowTable> pow_tables;  // keyed by base
+  struct PreKey { int log_n, rate_bits; uint64_t shift; bool operator<(const PreKey &o) const {
+    return std::tie(log_n, rate_bits, shift) < std::tie(o.log_n, o.rate_bits, o.shift); } };
+  std::map<PreKey, uint64_t *> prescale_tables;  // LDE pre-scale tables [2^rate_bits][n]
   // scratch buffer reused by natural-order NTT epilogues / merkle host paths
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -168,6 +172,27 @@ uint64_t root_of_unity(int log_n, bool inverse) {
   return inverse ? GL_ROOTS_INV[log_n] : GL_ROOTS[log_n];
 }
 
+// LDE pre-scale table T[r][j] = (shift * omega_N^r)^j  (r < 2^rate_bits, j < n), cached per ctx
+int get_prescale_table(cp_ctx *ctx, int log_n, int rate_bits, uint64_t shift, const uint64_t **out) {
+  cp_ctx::PreKey key{log_n, rate_bits, shift};
+  auto it = ctx->prescale_tables.find(key);
+  if (it != ctx->prescale_tables.end()) {
+    *out = it->second;
+    return CP_OK;
+  }
+  const uint64_t *stab, *wtabN;
+  CP_TRY(get_pow_table(ctx, shift, &stab));
+  CP_TRY(get_pow_table(ctx, root_of_unity(log_n + rate_bits, false), &wtabN));
+  size_t N = (size_t)1 << (log_n + rate_bits);
+  uint64_t *T = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&T, N * sizeof(uint64_t)));
+  LAUNCH(ctx, "lde_fill_prescale", ntt16::k_fill_prescale, dim3((unsigned)((N + 255) / 256)), dim3(256), T,
+         log_n, rate_bits, stab, wtabN);
+  ctx->prescale_tables[key] = T;
+  *out = T;
+  return CP_OK;
+}
+
 int upload_constants(cp_ctx *ctx) {
   HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_RC), POSEIDON_RC, sizeof POSEIDON_RC));
   return CP_OK;
@@ -178,8 +203,17 @@ inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + 
 // ---- NTT driver ---------------------------------------------------------------------------
 
 // DIF passes, natural in -> bit-reversed out, in place.
+struct DifExtra {
+  const uint64_t *src = nullptr;  // first pass reads from here
+  size_t src_stride = 0;
+  const uint64_t *ptab = nullptr;
+  size_t block_stride = 0;
+  int n_blocks = 1, block_bits = 0;
+  bool natural_out = false;
+};
+
 int run_dif(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stride, bool inverse,
-            uint64_t scale, const uint64_t *stab_pre) {
+            uint64_t scale, const uint64_t *stab_pre, const DifExtra &ex = DifExtra()) {
   if (log_n == 0) return CP_OK;
   const uint64_t *wtab;
   CP_TRY(get_pow_table(ctx, root_of_unity(log_n, inverse), &wtab));
@@ -221,9 +255,16 @@ int run_dif(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stride,
     a.scale = scale;
     a.coset_pre = stab_pre != nullptr;
     a.coset_post = 0;
-    dim3 grid((unsigned)(((size_t)1 << outer_bits) >> c), (unsigned)batch);
+    a.src = ex.src;
+    a.src_stride = ex.src_stride;
+    a.ptab = ex.ptab;
+    a.block_stride = ex.block_stride;
+    a.block_bits = ex.block_bits;
+    a.natural_out = ex.natural_out ? 1 : 0;
+    dim3 grid((unsigned)(((size_t)1 << outer_bits) >> c), (unsigned)batch, (unsigned)ex.n_blocks);
     bool done = false;
-    if (L >= 4 && L + c == ntt16::LOG_TILE && !getenv("CITYPROVER_NTT_V1")) {
+    const bool need16 = ex.src || ex.ptab || ex.n_blocks > 1 || ex.natural_out;
+    if (L >= 4 && L + c == ntt16::LOG_TILE && (need16 || !getenv("CITYPROVER_NTT_V1"))) {
       // register radix-16 pass (ntt16.h)
 #define PASS16(LL)                                                                                   \
   case LL:                                                                                           \
@@ -242,6 +283,7 @@ int run_dif(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stride,
       }
 #undef PASS16
     }
+    if (!done && need16) return set_error(ctx, CP_ERR_INTERNAL, "radix-16 pass required but unavailable (L=%d c=%d)", L, c);
     if (!done) {
       if (q_after == 0)
         LAUNCH(ctx, "ntt_dif_pass_rows", ntt::k_dif_pass<true>, grid, dim3(ntt::THREADS), a);
@@ -263,39 +305,51 @@ int bitrev_copy(cp_ctx *ctx, const uint64_t *src, uint64_t *dst, size_t src_stri
   return CP_OK;
 }
 
-int merkle_from_digests(cp_ctx *ctx, uint64_t *level0, size_t n_leaves, int cap_height,
-                        uint64_t *digests_dev, uint64_t *cap_dev, bool level0_in_digests) {
-  // levels live in digests_dev (if given) or in a ping-pong scratch
+// u64 words of digest storage per tree: every level below the cap (>= the leaf level itself)
+size_t merkle_words_per_tree(size_t n_leaves, int cap_height) {
   size_t cap_n = (size_t)1 << cap_height;
-  uint64_t *cur = level0;
-  size_t n = n_leaves;
-  uint64_t *next_slot = nullptr;
-  if (digests_dev) {
-    next_slot = digests_dev + (level0_in_digests ? n_leaves * 4 : 0);
-  }
-  uint64_t *pp[2] = {nullptr, nullptr};
-  int pi = 0;
-  if (!digests_dev && n > cap_n) {
-    // scratch ping-pong beyond the leaf level: n/2*4 + n/4*4 u64
-    // (allocated by caller via ensure_scratch; level0 sits at the start of scratch)
-    pp[0] = level0 + n_leaves * 4;
-    pp[1] = pp[0] + (n_leaves / 2) * 4;
-  }
+  size_t nodes = n_leaves > cap_n ? 2 * n_leaves - 2 * cap_n : n_leaves;
+  return nodes * 4;
+}
+
+// Levels above the leaf digests for `n_trees` trees laid out per tree at D + t*per_tree (level 0 first).
+int merkle_levels(cp_ctx *ctx, uint64_t *D, size_t per_tree, size_t n_leaves, size_t n_trees,
+                  int cap_height, uint64_t *caps) {
+  size_t cap_n = (size_t)1 << cap_height;
+  size_t n = n_leaves, off = 0;
   while (n > cap_n) {
     size_t np = n / 2;
-    uint64_t *dst;
-    if (np == cap_n) dst = cap_dev;
-    else if (digests_dev) { dst = next_slot; next_slot += np * 4; }
-    else { dst = pp[pi]; pi ^= 1; }
-    LAUNCH(ctx, "merkle_level", merkle::k_level, dim3(blocks_for(np, merkle::THREADS)),
-           dim3(merkle::THREADS), cur, np, dst);
-    cur = dst;
+    const uint64_t *child = D + off;
+    uint64_t *parent;
+    size_t pstride;
+    if (np == cap_n) { parent = caps; pstride = cap_n * 4; }
+    else { parent = D + off + n * 4; pstride = per_tree; }
+    LAUNCH(ctx, "merkle_level", merkle::k_level, dim3(blocks_for(np, merkle::THREADS), (unsigned)n_trees),
+           dim3(merkle::THREADS), child, np, parent, per_tree, pstride);
+    off += n * 4;
     n = np;
   }
   if (n_leaves == cap_n) {
-    HIP_TRY(ctx, hipMemcpyAsync(cap_dev, level0, cap_n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpy2DAsync(caps, cap_n * 32, D, per_tree * 8, cap_n * 32, n_trees,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
   }
   return CP_OK;
+}
+
+// n_trees Merkle trees over column-major leaves; tree t reads cols + t*tree_cols_stride.
+int merkle_cols_batch(cp_ctx *ctx, const uint64_t *cols, size_t n_leaves, size_t leaf_len,
+                      size_t col_stride, size_t n_trees, size_t tree_cols_stride, int cap_height,
+                      uint64_t *digests, uint64_t *caps) {
+  size_t per_tree = merkle_words_per_tree(n_leaves, cap_height);
+  uint64_t *D = digests;
+  if (!D) {
+    CP_TRY(ensure_scratch(ctx, n_trees * per_tree * sizeof(uint64_t)));
+    D = (uint64_t *)ctx->scratch;
+  }
+  LAUNCH(ctx, "leaf_hash_cols", merkle::k_leaf_hash_cols,
+         dim3(blocks_for(n_leaves, merkle::THREADS), (unsigned)n_trees), dim3(merkle::THREADS), cols, n_leaves,
+         (int)leaf_len, col_stride, D, tree_cols_stride, per_tree);
+  return merkle_levels(ctx, D, per_tree, n_leaves, n_trees, cap_height, caps);
 }
 
 bool valid_merkle_shape(size_t n_leaves, int cap_height) {
@@ -361,6 +415,7 @@ void cp_ctx_destroy(cp_ctx *ctx) {
   prof_flush(ctx);
   for (auto e : ctx->prof_pool) hipEventDestroy(e);
   for (auto &kv : ctx->pow_tables) hipFree(kv.second.dev);
+  for (auto &kv : ctx->prescale_tables) hipFree(kv.second);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -500,6 +555,12 @@ int cp_ntt_dev(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stri
   }
   uint64_t scale = 0;
   if (inverse) scale = gl::inv((uint64_t)n % gl::P);
+  // a 4096-point transform is one workgroup-resident pass: natural order comes out of its LDS epilogue
+  if (log_n == ntt16::LOG_TILE && !(flags & CP_NTT_BITREV_OUT) && !(coset && inverse)) {
+    DifExtra ex;
+    ex.natural_out = true;
+    return run_dif(ctx, data, log_n, batch, stride, inverse, scale, (coset && !inverse) ? stab : nullptr, ex);
+  }
   CP_TRY(run_dif(ctx, data, log_n, batch, stride, inverse, scale, (coset && !inverse) ? stab : nullptr));
   if (!(flags & CP_NTT_BITREV_OUT)) {
     CP_TRY(bitrev_copy(ctx, data, tmp, stride, n, log_n, batch, (coset && inverse) ? stab : nullptr));
@@ -540,6 +601,23 @@ int cp_lde_dev(cp_ctx *ctx, const uint64_t *coeffs, size_t in_stride, int log_n,
   if (in_stride < n || out_stride < N) return set_error(ctx, CP_ERR_INVALID_ARG, "stride too small");
   if (batch > 65535) return set_error(ctx, CP_ERR_INVALID_ARG, "batch %zu > 65535", batch);
   if (flags & ~CP_NTT_BITREV_OUT) return set_error(ctx, CP_ERR_INVALID_ARG, "unsupported flags 0x%x", flags);
+  if (coset_shift == 0 || coset_shift >= gl::P)
+    return set_error(ctx, CP_ERR_INVALID_ARG, "coset shift must be a non-zero canonical element");
+  // Product shape (n = 4096): the zero-padded size-N transform is 2^rate_bits independent coset NTTs of
+  // size n (the first rate_bits stages only copy), each one workgroup-resident pass reading the
+  // coefficients once and writing its block of the bit-reversed LDE directly.
+  if (log_n == ntt16::LOG_TILE && (flags & CP_NTT_BITREV_OUT) && rate_bits <= 6) {
+    const uint64_t *ptab;
+    CP_TRY(get_prescale_table(ctx, log_n, rate_bits, coset_shift, &ptab));
+    DifExtra ex;
+    ex.src = coeffs;
+    ex.src_stride = in_stride;
+    ex.ptab = ptab;
+    ex.block_stride = n;
+    ex.n_blocks = 1 << rate_bits;
+    ex.block_bits = rate_bits;
+    return run_dif(ctx, out, log_n, batch, out_stride, false, 0, nullptr, ex);
+  }
   dim3 grid(blocks_for(N, 256), (unsigned)batch);
   LAUNCH(ctx, "lde_pad_copy", ntt::k_pad_copy, grid, dim3(256), coeffs, out, in_stride, out_stride, n, N);
   return cp_ntt_dev(ctx, out, log_n + rate_bits, batch, out_stride,
@@ -610,18 +688,9 @@ int cp_merkle_cols_dev(cp_ctx *ctx, const uint64_t *cols, size_t n_leaves, size_
                      n_leaves, cap_height);
   if (leaf_len == 0 || leaf_len > (1u << 20)) return set_error(ctx, CP_ERR_INVALID_ARG, "leaf_len %zu out of range", leaf_len);
   if (col_stride < n_leaves) return set_error(ctx, CP_ERR_INVALID_ARG, "col_stride < n_leaves");
-  uint64_t *level0;
   size_t cap_n = (size_t)1 << cap_height;
-  if (digests_dev && n_leaves > cap_n) {
-    level0 = digests_dev;
-  } else {
-    CP_TRY(ensure_scratch(ctx, n_leaves * 32 * 2));
-    level0 = (uint64_t *)ctx->scratch;
-  }
-  LAUNCH(ctx, "leaf_hash_cols", merkle::k_leaf_hash_cols, dim3(blocks_for(n_leaves, merkle::THREADS)),
-         dim3(merkle::THREADS), cols, n_leaves, (int)leaf_len, col_stride, level0);
-  return merkle_from_digests(ctx, level0, n_leaves, cap_height,
-                             (digests_dev && n_leaves > cap_n) ? digests_dev : nullptr, cap_dev, true);
+  return merkle_cols_batch(ctx, cols, n_leaves, leaf_len, col_stride, 1, 0, cap_height,
+                           (digests_dev && n_leaves > cap_n) ? digests_dev : nullptr, cap_dev);
 }
 
 int cp_merkle_cap(cp_ctx *ctx, const uint64_t *rows_host, size_t n_leaves, size_t leaf_len,
@@ -639,13 +708,14 @@ int cp_merkle_cap(cp_ctx *ctx, const uint64_t *rows_host, size_t n_leaves, size_
   hipError_t e = hipMalloc((void **)&cap, cap_n * 32);
   if (e != hipSuccess) { hipFree(rows); return set_error(ctx, CP_ERR_OOM, "hipMalloc: %s", hipGetErrorString(e)); }
   int rc = cp_h2d(ctx, rows, rows_host, rows_bytes);
-  if (rc == CP_OK) rc = ensure_scratch(ctx, n_leaves * 32 * 2);
+  size_t per_tree = merkle_words_per_tree(n_leaves, cap_height);
+  if (rc == CP_OK) rc = ensure_scratch(ctx, per_tree * sizeof(uint64_t));
   if (rc == CP_OK) {
     uint64_t *level0 = (uint64_t *)ctx->scratch;
     hipLaunchKernelGGL(merkle::k_leaf_hash_rows, dim3(blocks_for(n_leaves, merkle::THREADS)),
                        dim3(merkle::THREADS), 0, ctx->stream, rows, n_leaves, (int)leaf_len, level0, 0);
     if (hipGetLastError() != hipSuccess) rc = set_error(ctx, CP_ERR_HIP, "leaf hash launch failed");
-    if (rc == CP_OK) rc = merkle_from_digests(ctx, level0, n_leaves, cap_height, nullptr, cap, true);
+    if (rc == CP_OK) rc = merkle_levels(ctx, level0, per_tree, n_leaves, 1, cap_height, cap);
   }
   if (rc == CP_OK) rc = cp_d2h(ctx, cap_host, cap, cap_n * 32);
   hipStreamSynchronize(ctx->stream);
@@ -656,32 +726,51 @@ int cp_merkle_cap(cp_ctx *ctx, const uint64_t *rows_host, size_t n_leaves, size_
 
 // ---- commit ---------------------------------------------------------------------------------
 
-int cp_commit_dev(cp_ctx *ctx, const uint64_t *values, size_t k, int log_n, int rate_bits,
-                  int cap_height, uint64_t *coeffs_dev, uint64_t *lde_dev, uint64_t *digests_dev,
-                  uint64_t *cap_dev) {
+int cp_commit_batch_dev(cp_ctx *ctx, const uint64_t *values, size_t k, size_t n_trees, int log_n,
+                        int rate_bits, int cap_height, uint64_t *coeffs_dev, uint64_t *lde_dev,
+                        uint64_t *digests_dev, uint64_t *caps_dev) {
   CHECK_CTX(ctx);
-  if (!values || !lde_dev || !cap_dev) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
-  if (k == 0 || k > 65535) return set_error(ctx, CP_ERR_INVALID_ARG, "k %zu out of range", k);
+  if (!values || !lde_dev || !caps_dev) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
+  if (k == 0 || n_trees == 0 || k * n_trees > 65535 || n_trees > 65535)
+    return set_error(ctx, CP_ERR_INVALID_ARG, "k %zu x n_trees %zu out of range", k, n_trees);
   if (log_n < 0 || rate_bits < 0 || log_n + rate_bits > 32)
     return set_error(ctx, CP_ERR_INVALID_ARG, "log_n/rate_bits out of range");
-  size_t n = (size_t)1 << log_n, N = n << rate_bits;
+  size_t n = (size_t)1 << log_n, N = n << rate_bits, polys = k * n_trees;
   if (!valid_merkle_shape(N, cap_height)) return set_error(ctx, CP_ERR_INVALID_ARG, "cap_height %d too large", cap_height);
   uint64_t *coeffs = coeffs_dev;
   uint64_t *own = nullptr;
   if (!coeffs) {
-    HIP_TRY(ctx, hipMalloc((void **)&own, k * n * sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMalloc((void **)&own, polys * n * sizeof(uint64_t)));
     coeffs = own;
   }
-  int rc = cp_d2d(ctx, coeffs, values, k * n * sizeof(uint64_t));
-  if (rc == CP_OK) rc = cp_ntt_dev(ctx, coeffs, log_n, k, n, CP_NTT_INVERSE, 0);
+  int rc;
+  if (log_n == ntt16::LOG_TILE) {
+    // one launch: values -> natural-order coefficients (read from `values`, written to `coeffs`)
+    DifExtra ex;
+    ex.src = values;
+    ex.src_stride = n;
+    ex.natural_out = true;
+    rc = run_dif(ctx, coeffs, log_n, polys, n, true, gl::inv((uint64_t)n), nullptr, ex);
+  } else {
+    rc = cp_d2d(ctx, coeffs, values, polys * n * sizeof(uint64_t));
+    if (rc == CP_OK) rc = cp_ntt_dev(ctx, coeffs, log_n, polys, n, CP_NTT_INVERSE, 0);
+  }
   if (rc == CP_OK)
-    rc = cp_lde_dev(ctx, coeffs, n, log_n, rate_bits, k, 7, CP_NTT_BITREV_OUT, lde_dev, N);
-  if (rc == CP_OK) rc = cp_merkle_cols_dev(ctx, lde_dev, N, k, N, cap_height, digests_dev, cap_dev);
+    rc = cp_lde_dev(ctx, coeffs, n, log_n, rate_bits, polys, 7, CP_NTT_BITREV_OUT, lde_dev, N);
+  if (rc == CP_OK)
+    rc = merkle_cols_batch(ctx, lde_dev, N, k, N, n_trees, k * N, cap_height, digests_dev, caps_dev);
   if (own) {
     hipStreamSynchronize(ctx->stream);
     hipFree(own);
   }
   return rc;
+}
+
+int cp_commit_dev(cp_ctx *ctx, const uint64_t *values, size_t k, int log_n, int rate_bits,
+                  int cap_height, uint64_t *coeffs_dev, uint64_t *lde_dev, uint64_t *digests_dev,
+                  uint64_t *cap_dev) {
+  return cp_commit_batch_dev(ctx, values, k, 1, log_n, rate_bits, cap_height, coeffs_dev, lde_dev,
+                             digests_dev, cap_dev);
 }
 
 }  // extern "C"

@@ -15,12 +15,17 @@ namespace merkle {
 constexpr int THREADS = 256;
 
 // leaf digests: digest[i] = hash_or_noop(leaf i)
+// blockIdx.y = tree index (batched commitments: tree t reads cols + t*tree_cols_stride)
 __global__ __launch_bounds__(THREADS) void k_leaf_hash_cols(const uint64_t *__restrict__ cols,
                                                             size_t n_leaves, int leaf_len,
                                                             size_t col_stride,
-                                                            uint64_t *__restrict__ digests) {
+                                                            uint64_t *__restrict__ digests,
+                                                            size_t tree_cols_stride,
+                                                            size_t tree_dig_stride) {
   size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
   if (i >= n_leaves) return;
+  cols += (size_t)blockIdx.y * tree_cols_stride;
+  digests += (size_t)blockIdx.y * tree_dig_stride;
   uint64_t s[poseidon::W];
 #pragma unroll
   for (int k = 0; k < poseidon::W; k++) s[k] = 0;
@@ -72,9 +77,13 @@ __global__ __launch_bounds__(THREADS) void k_leaf_hash_rows(const uint64_t *__re
 // one tree level: parent[i] = two_to_one(child[2i], child[2i+1])
 __global__ __launch_bounds__(THREADS) void k_level(const uint64_t *__restrict__ child,
                                                    size_t n_parents,
-                                                   uint64_t *__restrict__ parent) {
+                                                   uint64_t *__restrict__ parent,
+                                                   size_t child_tree_stride,
+                                                   size_t parent_tree_stride) {
   size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
   if (i >= n_parents) return;
+  child += (size_t)blockIdx.y * child_tree_stride;
+  parent += (size_t)blockIdx.y * parent_tree_stride;
   uint64_t s[poseidon::W];
   const uint64_t *c = child + 8 * i;
 #pragma unroll

@@ -45,6 +45,13 @@ struct PassArgs {
   uint64_t scale;          // multiplied into every output of the last pass (1/n for inverse), 0 = none
   int coset_pre;           // forward coset: multiply input i by shift^i on load in the first pass
   int coset_post;          // inverse coset: multiply output (natural index) by shift^-i — only with natural-order epilogue
+  // --- first-pass source redirection (register radix-16 kernels only) ---
+  const uint64_t *src;     // if non-null the first pass reads src (polynomial b at src + b*src_stride) instead of data
+  size_t src_stride;
+  const uint64_t *ptab;    // per-block pre-scale table [block][2^log_n]; applied on the first-pass load
+  size_t block_stride;     // blockIdx.z selects an output block: data + b*stride + z*block_stride
+  int block_bits;          // ptab row = bitrev(z, block_bits)  (output block z holds coset rev(z))
+  int natural_out;         // ROWS single-pass transforms only: store in natural order
 };
 
 // position of (r, cc) inside the LDS tile == order of the tile's elements in memory

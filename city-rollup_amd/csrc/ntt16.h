@@ -109,7 +109,10 @@ __global__ __launch_bounds__(THREADS) void k_dif_pass16(ntt::PassArgs a) {
   constexpr int NROUNDS = 1 + (L - B0) / 4;
   const int t = threadIdx.x;
   const int q = a.q;
-  uint64_t *poly = a.data + (size_t)blockIdx.y * a.stride;
+  uint64_t *poly = a.data + (size_t)blockIdx.y * a.stride + (size_t)blockIdx.z * a.block_stride;
+  const uint64_t *in = (a.first && a.src) ? a.src + (size_t)blockIdx.y * a.src_stride : poly;
+  const uint64_t *ptab =
+      (a.first && a.ptab) ? a.ptab + ((size_t)ntt::bitrev(blockIdx.z, a.block_bits) << a.log_n) : nullptr;
   uint64_t x[16];
 
   // ---- round 0: field = r-bits [L-4, L) --------------------------------------------------
@@ -120,8 +123,9 @@ __global__ __launch_bounds__(THREADS) void k_dif_pass16(ntt::PassArgs a) {
 #pragma unroll
     for (int m = 0; m < 16; m++) {
       size_t idx = gidx<L, C, ROWS>(P + (m << F), blockIdx.x, q);
-      uint64_t v = poly[idx];
-      if (a.coset_pre && a.first) v = gl::mul(v, ntt::pow_table(a.stab, idx));
+      uint64_t v = in[idx];
+      if (ptab) v = gl::mul(v, ptab[idx]);
+      else if (a.coset_pre && a.first) v = gl::mul(v, ntt::pow_table(a.stab, idx));
       x[m] = v;
     }
     if constexpr (f == 0) {
@@ -192,9 +196,31 @@ __global__ __launch_bounds__(THREADS) void k_dif_pass16(ntt::PassArgs a) {
 #pragma unroll
       for (int m = 0; m < 16; m++) x[m] = gl::mul(x[m], a.scale);
     }
+    if (ROWS && a.natural_out) {
+      // single-pass transform: position r holds X[rev_L(r)]; un-permute through LDS, store coalesced
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 16; m++) tile[pad((int)ntt::bitrev((uint32_t)(P + m), L))] = x[m];
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 16; m++) {
+        int pos = t + (m << (LOG_TILE - 4));
+        poly[((size_t)blockIdx.x << LOG_TILE) + pos] = tile[pad(pos)];
+      }
+      return;
+    }
 #pragma unroll
     for (int m = 0; m < 16; m++) poly[gidx<L, C, ROWS>(P + (m << Flast), blockIdx.x, q)] = x[m];
   }
+}
+
+// pre-scale table for the LDE: T[r][j] = (shift * omega_N^r)^j, r < 2^rate_bits, j < n
+__global__ void k_fill_prescale(uint64_t *__restrict__ T, int log_n, int rate_bits,
+                                const uint64_t *__restrict__ stab, const uint64_t *__restrict__ wtabN) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> (log_n + rate_bits)) return;
+  uint64_t j = i & (((size_t)1 << log_n) - 1), r = i >> log_n;
+  T[i] = gl::mul(ntt::pow_table(stab, j), ntt::pow_table(wtabN, (r * j) & (((uint64_t)1 << (log_n + rate_bits)) - 1)));
 }
 
 }  // namespace ntt16

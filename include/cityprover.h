@@ -141,6 +141,14 @@ int cp_commit_dev(cp_ctx *ctx, const uint64_t *values_dev, size_t k, int log_n, 
                   int cap_height, uint64_t *coeffs_dev, uint64_t *lde_dev, uint64_t *digests_dev,
                   uint64_t *cap_dev);
 
+/* Batched form: n_trees independent commitments of k polynomials each (e.g. the same oracle of
+ * n_trees proofs in flight). values: n_trees*k polynomials, tree t owns polynomials [t*k, (t+1)*k).
+ * lde_dev: n_trees*k x N; digests_dev (nullable): per tree (2N - 2^(cap_height+1)) x 4 (or N x 4 when
+ * N == 2^cap_height); caps_dev: n_trees x 2^cap_height x 4. */
+int cp_commit_batch_dev(cp_ctx *ctx, const uint64_t *values_dev, size_t k, size_t n_trees, int log_n,
+                        int rate_bits, int cap_height, uint64_t *coeffs_dev, uint64_t *lde_dev,
+                        uint64_t *digests_dev, uint64_t *caps_dev);
+
 #ifdef __cplusplus
 }
 #endif
