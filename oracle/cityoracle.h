@@ -84,6 +84,53 @@ void or_commit_batch(const uint64_t *values, size_t k, int log_n, int rate_bits,
                      int cap_height, uint64_t *coeffs_out, uint64_t *lde_out,
                      uint64_t *digests_out, uint64_t *cap_out);
 
+/* ---- transcript / openings / FRI / proof bytes (plonky2_tail.c) ---- */
+typedef struct {
+  uint64_t state[12];
+  uint64_t in[8];
+  int n_in;
+  uint64_t out[8];
+  int n_out;
+} or_challenger;
+void or_ch_init(or_challenger *c);
+void or_ch_observe(or_challenger *c, const uint64_t *elems, size_t n);
+uint64_t or_ch_challenge(or_challenger *c);
+
+/* circuit shape: CommonCircuitData scalars the prover tail needs
+ * (fields mirrored from city_common_circuit/src/verify_template/ser_data.rs:55-123) */
+typedef struct {
+  int degree_bits, num_constants, num_routed_wires, num_wires, num_challenges, num_partial_products,
+      quotient_degree_factor;
+  int rate_bits, cap_height, pow_bits, num_query_rounds;
+  int n_arity;
+  int arity_bits[8];
+} or_shape;
+
+typedef struct {
+  uint64_t betas[8], gammas[8], alphas[8];
+  uint64_t zeta[2];
+  uint64_t fri_betas[8][2];
+  uint64_t pow_response;
+  uint64_t query_indices[64];
+} or_tail_debug;
+
+/* Everything of CircuitData::prove after the polynomials are known. cs_values: (constants+sigmas) x n
+ * values; wires_values: num_wires x n; zs_pp_values: num_challenges*(1+num_partial_products) x n
+ * (Z polynomials first); quotient_coeffs: num_challenges*quotient_degree_factor x n COEFFICIENTS.
+ * Produces bincode ProofWithPublicInputs bytes (malloc'd, free with or_free). */
+int or_prove_tail(const or_shape *sh, const uint64_t circuit_digest[4], const uint64_t *public_inputs,
+                  size_t n_pi, const uint64_t *cs_values, const uint64_t *wires_values,
+                  const uint64_t *zs_pp_values, const uint64_t *quotient_coeffs, int use_pow_override,
+                  uint64_t pow_override, uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg);
+/* Verifier side of the same: transcript, PoW, all Merkle paths, fri_combine_initial vs the openings,
+ * fold consistency, final polynomial. cs_cap: the circuit's constants_sigmas cap. 0 = accepted. */
+int or_verify_tail(const or_shape *sh, const uint64_t circuit_digest[4], const uint64_t *cs_cap,
+                   const uint8_t *proof, size_t len, or_tail_debug *dbg);
+void or_fri_compute_evaluation(uint64_t x, size_t x_index_within_coset, int arity_bits,
+                               const uint64_t *evals, const uint64_t beta[2], uint64_t out[2]);
+uint64_t or_fri_query_point(size_t x_index, int log_n);
+void or_free(void *p);
+
 /* number of worker threads the oracle uses for the batch entry points
  * (or_poseidon_permute_many, or_merkle_tree*, or_commit_batch); default 1 */
 void or_set_threads(int n);

@@ -1,0 +1,497 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY (see goldilocks.h).
+ *
+ * CPU restatement of the part of plonky2 0.2.2 `prove_with_partition_witness` that follows the
+ * computation of the polynomials: transcript (Challenger), the three oracle commitments, openings at
+ * zeta / g*zeta, the FRI opening proof (batch polynomial, commit phase, proof of work, query rounds),
+ * bincode serialisation of ProofWithPublicInputs, and the matching verifier side for the FRI part.
+ * plonky2 is an un-vendored dependency (QEDProtocol/plonky2-hwa @ 6a8ca008, Cargo.lock:4174-4223):
+ * the algorithm is restated from its published definition (SURVEY.md §3.3 steps 3-4, 6, 8-11,
+ * Appendix B). What the reference tree pins: the proof shape and byte layout, Merkle paths, the FRI
+ * leaf layout and the FRI fold / final-polynomial relation of the 3 reference proofs in
+ * tests/golden (tests/test_oracle_fri_reference.py). Transcript order and the batching order of the
+ * opened polynomials are NOT pinned by reference data ("parity unpinned" for those two facts).
+ */
+#include "cityoracle.h"
+#include "goldilocks.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* Challenger: Poseidon duplex, overwrite mode, rate 8; challenges are popped from the END of the
+ * squeezed rate block. */
+
+void or_ch_init(or_challenger *c) { memset(c, 0, sizeof *c); }
+
+static void ch_duplex(or_challenger *c) {
+  for (int i = 0; i < c->n_in; i++) c->state[i] = c->in[i];
+  c->n_in = 0;
+  or_poseidon_permute(c->state);
+  memcpy(c->out, c->state, 8 * sizeof(uint64_t));
+  c->n_out = 8;
+}
+void or_ch_observe(or_challenger *c, const uint64_t *e, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    c->n_out = 0;
+    c->in[c->n_in++] = e[i];
+    if (c->n_in == 8) ch_duplex(c);
+  }
+}
+uint64_t or_ch_challenge(or_challenger *c) {
+  if (c->n_in > 0 || c->n_out == 0) ch_duplex(c);
+  return c->out[--c->n_out];
+}
+static gl2_t ch_ext(or_challenger *c) {
+  uint64_t a = or_ch_challenge(c), b = or_ch_challenge(c);
+  return gl2_make(a, b);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* polynomial batches */
+
+typedef struct {
+  size_t k;
+  int log_n, rate_bits, cap_height;
+  uint64_t *coeffs;  /* k x n */
+  uint64_t *lde;     /* k x N, bit-reversed index order */
+  uint64_t *digests; /* levels below the cap */
+  uint64_t *cap;     /* 2^cap_height x 4 */
+} batch_t;
+
+static size_t digest_nodes(size_t n_leaves, int cap_height) {
+  size_t cap_n = (size_t)1 << cap_height;
+  return n_leaves > cap_n ? 2 * n_leaves - 2 * cap_n : 0;
+}
+
+static void batch_alloc(batch_t *b, size_t k, int log_n, int rate_bits, int cap_height) {
+  size_t n = (size_t)1 << log_n, N = n << rate_bits;
+  b->k = k; b->log_n = log_n; b->rate_bits = rate_bits; b->cap_height = cap_height;
+  b->coeffs = (uint64_t *)malloc(k * n * 8);
+  b->lde = (uint64_t *)malloc(k * N * 8);
+  b->digests = (uint64_t *)malloc((digest_nodes(N, cap_height) + 1) * 32);
+  b->cap = (uint64_t *)malloc(((size_t)1 << cap_height) * 32);
+}
+static void batch_free(batch_t *b) { free(b->coeffs); free(b->lde); free(b->digests); free(b->cap); }
+
+static void batch_from_values(batch_t *b, const uint64_t *values, size_t k, int log_n, int rate_bits, int cap_height) {
+  batch_alloc(b, k, log_n, rate_bits, cap_height);
+  or_commit_batch(values, k, log_n, rate_bits, cap_height, b->coeffs, b->lde, b->digests, b->cap);
+}
+static void batch_from_coeffs(batch_t *b, const uint64_t *coeffs, size_t k, int log_n, int rate_bits, int cap_height) {
+  batch_alloc(b, k, log_n, rate_bits, cap_height);
+  size_t n = (size_t)1 << log_n, N = n << rate_bits;
+  memcpy(b->coeffs, coeffs, k * n * 8);
+  for (size_t p = 0; p < k; p++) {
+    or_coset_lde(coeffs + p * n, log_n, rate_bits, GL_GENERATOR, b->lde + p * N);
+    or_bit_reverse(b->lde + p * N, log_n + rate_bits);
+  }
+  or_merkle_tree_cols(b->lde, N, k, N, cap_height, b->digests, b->cap);
+}
+
+/* Merkle path of leaf `idx` out of the level-by-level digest array */
+static void merkle_path(const uint64_t *digests, size_t n_leaves, int cap_height, size_t idx, uint64_t *siblings /* depth x 4 */) {
+  size_t cap_n = (size_t)1 << cap_height, n = n_leaves, off = 0;
+  int lvl = 0;
+  while (n > cap_n) {
+    memcpy(siblings + 4 * lvl, digests + 4 * (off + (idx ^ 1)), 32);
+    off += n; n >>= 1; idx >>= 1; lvl++;
+  }
+}
+static int log2z(size_t x) { int l = 0; while (((size_t)1 << l) < x) l++; return l; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* byte buffer (bincode 1.3 default: LE, u64 length prefixes) */
+
+typedef struct { uint8_t *p; size_t len, cap; } buf_t;
+static void buf_put(buf_t *b, const void *src, size_t n) {
+  if (b->len + n > b->cap) { b->cap = (b->len + n) * 2 + 1024; b->p = (uint8_t *)realloc(b->p, b->cap); }
+  memcpy(b->p + b->len, src, n); b->len += n;
+}
+static void buf_u64(buf_t *b, uint64_t v) { buf_put(b, &v, 8); }
+static void buf_felts(buf_t *b, const uint64_t *v, size_t n) { buf_put(b, v, 8 * n); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* polynomial helpers */
+
+static gl2_t eval_base_poly_ext(const uint64_t *c, size_t n, gl2_t z) {
+  gl2_t acc = gl2_from_base(0);
+  for (size_t i = n; i-- > 0;) acc = gl2_add(gl2_mul(acc, z), gl2_from_base(c[i]));
+  return acc;
+}
+static gl2_t eval_ext_poly(const gl2_t *c, size_t n, gl2_t z) {
+  gl2_t acc = gl2_from_base(0);
+  for (size_t i = n; i-- > 0;) acc = gl2_add(gl2_mul(acc, z), c[i]);
+  return acc;
+}
+/* coset NTT of an extension polynomial: component-wise (the transform is F_p-linear) */
+static void ext_coset_ntt(const gl2_t *coeffs, int log_n, uint64_t shift, gl2_t *out) {
+  size_t n = (size_t)1 << log_n;
+  uint64_t *a = (uint64_t *)malloc(n * 8), *b = (uint64_t *)malloc(n * 8), *oa = (uint64_t *)malloc(n * 8), *ob = (uint64_t *)malloc(n * 8);
+  for (size_t i = 0; i < n; i++) { a[i] = coeffs[i].c[0]; b[i] = coeffs[i].c[1]; }
+  or_coset_lde(a, log_n, 0, shift, oa);
+  or_coset_lde(b, log_n, 0, shift, ob);
+  for (size_t i = 0; i < n; i++) out[i] = gl2_make(oa[i], ob[i]);
+  free(a); free(b); free(oa); free(ob);
+}
+static size_t bitrev_sz(size_t x, int bits) { size_t r = 0; for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i); return r; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* FRI prover */
+
+typedef struct {
+  int n_layers;
+  uint64_t *leaves[8];  /* n_leaves x (2*arity), row-major */
+  uint64_t *digests[8];
+  uint64_t *cap[8];
+  size_t n_leaves[8];
+} fri_trees_t;
+
+int or_prove_tail(const or_shape *sh, const uint64_t circuit_digest[4], const uint64_t *public_inputs, size_t n_pi,
+                  const uint64_t *cs_values, const uint64_t *wires_values, const uint64_t *zs_pp_values,
+                  const uint64_t *quotient_coeffs, int use_pow_override, uint64_t pow_override,
+                  uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg) {
+  const int db = sh->degree_bits, rb = sh->rate_bits, ch = sh->cap_height;
+  const size_t n = (size_t)1 << db, N = n << rb;
+  const size_t k_cs = sh->num_constants + sh->num_routed_wires, k_w = sh->num_wires;
+  const size_t k_z = (size_t)sh->num_challenges * (1 + sh->num_partial_products);
+  const size_t k_q = (size_t)sh->num_challenges * sh->quotient_degree_factor;
+  const size_t cap_n = (size_t)1 << ch;
+
+  batch_t B[4];
+  batch_from_values(&B[0], cs_values, k_cs, db, rb, ch);
+  uint64_t pi_hash[4];
+  or_hash_no_pad(public_inputs, n_pi, pi_hash);
+  batch_from_values(&B[1], wires_values, k_w, db, rb, ch);
+
+  or_challenger c;
+  or_ch_init(&c);
+  or_ch_observe(&c, circuit_digest, 4);
+  or_ch_observe(&c, pi_hash, 4);
+  or_ch_observe(&c, B[1].cap, cap_n * 4);
+  uint64_t betas[8], gammas[8], alphas[8];
+  for (int i = 0; i < sh->num_challenges; i++) betas[i] = or_ch_challenge(&c);
+  for (int i = 0; i < sh->num_challenges; i++) gammas[i] = or_ch_challenge(&c);
+  batch_from_values(&B[2], zs_pp_values, k_z, db, rb, ch);
+  or_ch_observe(&c, B[2].cap, cap_n * 4);
+  for (int i = 0; i < sh->num_challenges; i++) alphas[i] = or_ch_challenge(&c);
+  batch_from_coeffs(&B[3], quotient_coeffs, k_q, db, rb, ch);
+  or_ch_observe(&c, B[3].cap, cap_n * 4);
+  gl2_t zeta = ch_ext(&c);
+  uint64_t g = gl_root_of_unity(db);
+  gl2_t zeta_next = gl2_scale(zeta, g);
+  if (dbg) {
+    memcpy(dbg->betas, betas, sizeof betas); memcpy(dbg->gammas, gammas, sizeof gammas); memcpy(dbg->alphas, alphas, sizeof alphas);
+    dbg->zeta[0] = zeta.c[0]; dbg->zeta[1] = zeta.c[1];
+  }
+
+  /* openings: every polynomial at zeta, the Z polynomials also at g*zeta */
+  size_t k_all = k_cs + k_w + k_z + k_q;
+  gl2_t *open = (gl2_t *)malloc(k_all * sizeof(gl2_t));
+  gl2_t *open_next = (gl2_t *)malloc(sh->num_challenges * sizeof(gl2_t));
+  {
+    size_t o = 0;
+    for (int b = 0; b < 4; b++)
+      for (size_t p = 0; p < B[b].k; p++) open[o++] = eval_base_poly_ext(B[b].coeffs + p * n, n, zeta);
+    for (int i = 0; i < sh->num_challenges; i++) open_next[i] = eval_base_poly_ext(B[2].coeffs + (size_t)i * n, n, zeta_next);
+  }
+  /* observe_openings: batch zeta = [constants, sigmas, wires, zs, partial products, quotient], batch g*zeta = [zs_next] */
+  for (size_t i = 0; i < k_all; i++) or_ch_observe(&c, open[i].c, 2);
+  for (int i = 0; i < sh->num_challenges; i++) or_ch_observe(&c, open_next[i].c, 2);
+
+  /* ---- FRI batch polynomial: final = alpha^(#batch1) * Q0 + Q1 ---- */
+  gl2_t fri_alpha = ch_ext(&c);
+  gl2_t *fin = (gl2_t *)calloc(N, sizeof(gl2_t)); /* LDE-padded coefficient vector */
+  for (int batch = 0; batch < 2; batch++) {
+    gl2_t *comp = (gl2_t *)calloc(n, sizeof(gl2_t));
+    gl2_t ap = gl2_from_base(1);
+    size_t cnt = 0;
+    for (int b = 0; b < 4; b++) {
+      size_t lo = 0, hi = B[b].k;
+      if (batch == 1) { if (b != 2) continue; hi = sh->num_challenges; }
+      for (size_t p = lo; p < hi; p++) {
+        const uint64_t *f = B[b].coeffs + p * n;
+        for (size_t i = 0; i < n; i++) comp[i] = gl2_add(comp[i], gl2_scale(ap, f[i]));
+        ap = gl2_mul(ap, fri_alpha);
+        cnt++;
+      }
+    }
+    /* divide_by_linear(point): q[i-1] = comp[i] + z*q[i] */
+    gl2_t z = batch == 0 ? zeta : zeta_next;
+    gl2_t *q = (gl2_t *)calloc(n, sizeof(gl2_t));
+    gl2_t acc = gl2_from_base(0);
+    for (size_t i = n; i-- > 1;) { acc = gl2_add(gl2_mul(acc, z), comp[i]); q[i - 1] = acc; }
+    /* final = final * alpha^cnt + q */
+    gl2_t sh_f = gl2_pow(fri_alpha, cnt);
+    for (size_t i = 0; i < n; i++) fin[i] = gl2_add(gl2_mul(fin[i], sh_f), q[i]);
+    free(comp); free(q);
+  }
+  /* values on the LDE coset (natural order) */
+  gl2_t *vals = (gl2_t *)malloc(N * sizeof(gl2_t));
+  ext_coset_ntt(fin, db + rb, GL_GENERATOR, vals);
+
+  /* ---- commit phase ---- */
+  fri_trees_t T; memset(&T, 0, sizeof T);
+  T.n_layers = sh->n_arity;
+  gl2_t *coeffs = fin; size_t clen = N; int clog = db + rb;
+  uint64_t shift = GL_GENERATOR;
+  for (int l = 0; l < sh->n_arity; l++) {
+    int ab = sh->arity_bits[l]; size_t arity = (size_t)1 << ab;
+    size_t nl = clen >> ab;
+    uint64_t *leaves = (uint64_t *)malloc(clen * 16);
+    for (size_t i = 0; i < clen; i++) { /* position i of the bit-reversed value vector */
+      gl2_t v = vals[bitrev_sz(i, clog)];
+      leaves[2 * i] = v.c[0]; leaves[2 * i + 1] = v.c[1];
+    }
+    T.leaves[l] = leaves; T.n_leaves[l] = nl;
+    T.digests[l] = (uint64_t *)malloc((digest_nodes(nl, ch) + 1) * 32);
+    T.cap[l] = (uint64_t *)malloc(cap_n * 32);
+    or_merkle_tree(leaves, nl, 2 * arity, ch, T.digests[l], T.cap[l]);
+    or_ch_observe(&c, T.cap[l], cap_n * 4);
+    gl2_t beta = ch_ext(&c);
+    if (dbg && l < 8) { dbg->fri_betas[l][0] = beta.c[0]; dbg->fri_betas[l][1] = beta.c[1]; }
+    gl2_t *nc = (gl2_t *)malloc(nl * sizeof(gl2_t));
+    for (size_t j = 0; j < nl; j++) nc[j] = eval_ext_poly(coeffs + j * arity, arity, beta); /* sum beta^i c[16j+i] */
+    if (coeffs != fin) free(coeffs);
+    coeffs = nc; clen = nl; clog -= ab;
+    shift = gl_pow(shift, arity);
+    free(vals);
+    vals = (gl2_t *)malloc(clen * sizeof(gl2_t));
+    ext_coset_ntt(coeffs, clog, shift, vals);
+  }
+  size_t final_len = clen >> rb;
+  for (size_t i = 0; i < final_len; i++) or_ch_observe(&c, coeffs[i].c, 2);
+
+  /* ---- proof of work: smallest witness whose response has >= pow_bits leading zeros ---- */
+  uint64_t pow_witness = 0;
+  {
+    uint64_t st[12]; memcpy(st, c.state, sizeof st);
+    for (int i = 0; i < c.n_in; i++) st[i] = c.in[i];
+    int pos = c.n_in;
+    if (use_pow_override) pow_witness = pow_override;
+    else for (uint64_t cand = 0;; cand++) {
+      uint64_t t[12]; memcpy(t, st, sizeof t);
+      t[pos] = cand;
+      or_poseidon_permute(t);
+      if ((t[7] >> (64 - sh->pow_bits)) == 0) { pow_witness = cand; break; }
+    }
+    or_ch_observe(&c, &pow_witness, 1);
+    uint64_t resp = or_ch_challenge(&c);
+    if (dbg) dbg->pow_response = resp;
+    if (!use_pow_override && (resp >> (64 - sh->pow_bits)) != 0) return -1;
+  }
+
+  /* ---- serialise ---- */
+  buf_t out = {0};
+  for (int b = 1; b <= 3; b++) { buf_u64(&out, cap_n); buf_felts(&out, B[b].cap, cap_n * 4); }
+  {
+    size_t o = 0;
+    /* constants, plonk_sigmas */
+    buf_u64(&out, sh->num_constants); buf_put(&out, open + o, (size_t)sh->num_constants * 16); o += sh->num_constants;
+    buf_u64(&out, sh->num_routed_wires); buf_put(&out, open + o, (size_t)sh->num_routed_wires * 16); o += sh->num_routed_wires;
+    buf_u64(&out, k_w); buf_put(&out, open + o, k_w * 16); o += k_w;
+    buf_u64(&out, sh->num_challenges); buf_put(&out, open + o, (size_t)sh->num_challenges * 16);
+    buf_u64(&out, sh->num_challenges); buf_put(&out, open_next, (size_t)sh->num_challenges * 16);
+    size_t npp = k_z - sh->num_challenges;
+    buf_u64(&out, npp); buf_put(&out, open + o + sh->num_challenges, npp * 16); o += k_z;
+    buf_u64(&out, k_q); buf_put(&out, open + o, k_q * 16);
+    buf_u64(&out, 0); buf_u64(&out, 0); /* lookup_zs, lookup_zs_next */
+  }
+  buf_u64(&out, sh->n_arity);
+  for (int l = 0; l < sh->n_arity; l++) { buf_u64(&out, cap_n); buf_felts(&out, T.cap[l], cap_n * 4); }
+  buf_u64(&out, sh->num_query_rounds);
+  int depth0 = db + rb - ch;
+  uint64_t sib[64 * 4];
+  for (int qi = 0; qi < sh->num_query_rounds; qi++) {
+    size_t x = (size_t)(or_ch_challenge(&c) % N);
+    if (dbg && qi < 64) dbg->query_indices[qi] = x;
+    buf_u64(&out, 4);
+    for (int b = 0; b < 4; b++) {
+      buf_u64(&out, B[b].k);
+      for (size_t p = 0; p < B[b].k; p++) buf_u64(&out, B[b].lde[p * N + x]);
+      merkle_path(B[b].digests, N, ch, x, sib);
+      buf_u64(&out, depth0); buf_felts(&out, sib, (size_t)depth0 * 4);
+    }
+    buf_u64(&out, sh->n_arity);
+    size_t xi = x;
+    for (int l = 0; l < sh->n_arity; l++) {
+      int ab = sh->arity_bits[l]; size_t arity = (size_t)1 << ab;
+      xi >>= ab;
+      buf_u64(&out, arity); buf_felts(&out, T.leaves[l] + xi * 2 * arity, 2 * arity);
+      int depth = log2z(T.n_leaves[l]) - ch; if (depth < 0) depth = 0;
+      merkle_path(T.digests[l], T.n_leaves[l], ch, xi, sib);
+      buf_u64(&out, depth); buf_felts(&out, sib, (size_t)depth * 4);
+    }
+  }
+  buf_u64(&out, final_len); buf_put(&out, coeffs, final_len * 16);
+  buf_u64(&out, pow_witness);
+  buf_u64(&out, n_pi); buf_felts(&out, public_inputs, n_pi);
+
+  *proof_out = out.p; *proof_len = out.len;
+  for (int l = 0; l < sh->n_arity; l++) { free(T.leaves[l]); free(T.digests[l]); free(T.cap[l]); }
+  if (coeffs != fin) free(coeffs);
+  free(fin); free(vals); free(open); free(open_next);
+  for (int b = 0; b < 4; b++) batch_free(&B[b]);
+  return 0;
+}
+
+void or_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* FRI verifier side */
+
+/* Interpolate {(x*g^i, evals'[i])} (evals' = bit-reversed evals) and evaluate at beta:
+ * plonky2 `compute_evaluation`. x is the point of THIS query in the current layer's domain. */
+void or_fri_compute_evaluation(uint64_t x, size_t x_index_within_coset, int arity_bits, const uint64_t *evals /* arity x 2 */,
+                               const uint64_t beta[2], uint64_t out[2]) {
+  size_t arity = (size_t)1 << arity_bits;
+  uint64_t g = gl_root_of_unity(arity_bits);
+  gl2_t ev[64]; uint64_t pts[64];
+  for (size_t i = 0; i < arity; i++) { size_t r = bitrev_sz(i, arity_bits); ev[i] = gl2_make(evals[2 * r], evals[2 * r + 1]); }
+  size_t rev = bitrev_sz(x_index_within_coset, arity_bits);
+  uint64_t start = gl_mul(x, gl_pow(g, arity - rev));
+  uint64_t gp = 1;
+  for (size_t i = 0; i < arity; i++) { pts[i] = gl_mul(start, gp); gp = gl_mul(gp, g); }
+  /* Lagrange interpolation at beta (barycentric; exact arithmetic, any correct method agrees) */
+  gl2_t b = gl2_make(beta[0], beta[1]);
+  gl2_t acc = gl2_from_base(0);
+  for (size_t i = 0; i < arity; i++) {
+    gl2_t num = gl2_from_base(1); uint64_t den = 1;
+    for (size_t j = 0; j < arity; j++) if (j != i) {
+      num = gl2_mul(num, gl2_sub(b, gl2_from_base(pts[j])));
+      den = gl_mul(den, gl_sub(pts[i], pts[j]));
+    }
+    acc = gl2_add(acc, gl2_mul(ev[i], gl2_scale(num, gl_inv(den))));
+  }
+  out[0] = acc.c[0]; out[1] = acc.c[1];
+}
+
+/* x = g_coset * omega_N^rev(x_index) */
+uint64_t or_fri_query_point(size_t x_index, int log_n) {
+  return gl_mul(GL_GENERATOR, gl_pow(gl_root_of_unity(log_n), bitrev_sz(x_index, log_n)));
+}
+
+/* byte reader */
+typedef struct { const uint8_t *p; size_t len, o; int bad; } rd_t;
+static uint64_t rd_u64(rd_t *r) { if (r->o + 8 > r->len) { r->bad = 1; return 0; } uint64_t v; memcpy(&v, r->p + r->o, 8); r->o += 8; return v; }
+static const uint64_t *rd_felts(rd_t *r, size_t n) { if (r->o + 8 * n > r->len) { r->bad = 1; return NULL; } const uint64_t *v = (const uint64_t *)(r->p + r->o); r->o += 8 * n; return v; }
+
+/* Verify everything of a proof that does not need the gate constraints: transcript, proof of work,
+ * Merkle paths of all queries, fri_combine_initial against the openings, fold consistency, final poly.
+ * Returns 0 if ok, otherwise a negative code naming the first failing check. */
+int or_verify_tail(const or_shape *sh, const uint64_t circuit_digest[4], const uint64_t *cs_cap,
+                   const uint8_t *proof, size_t len, or_tail_debug *dbg) {
+  const int db = sh->degree_bits, rb = sh->rate_bits, ch = sh->cap_height;
+  const size_t n = (size_t)1 << db, N = n << rb, cap_n = (size_t)1 << ch;
+  const size_t k_cs = sh->num_constants + sh->num_routed_wires, k_w = sh->num_wires;
+  const size_t k_z = (size_t)sh->num_challenges * (1 + sh->num_partial_products);
+  const size_t k_q = (size_t)sh->num_challenges * sh->quotient_degree_factor;
+  rd_t r = {proof, len, 0, 0};
+  const uint64_t *caps[4]; caps[0] = cs_cap;
+  for (int b = 1; b <= 3; b++) { if (rd_u64(&r) != cap_n) return -2; caps[b] = rd_felts(&r, cap_n * 4); }
+  size_t cnt[9] = {(size_t)sh->num_constants, (size_t)sh->num_routed_wires, k_w, (size_t)sh->num_challenges, (size_t)sh->num_challenges,
+                   k_z - sh->num_challenges, k_q, 0, 0};
+  const uint64_t *op[9];
+  for (int i = 0; i < 9; i++) { if (rd_u64(&r) != cnt[i]) return -3; op[i] = rd_felts(&r, cnt[i] * 2); }
+  if (rd_u64(&r) != (uint64_t)sh->n_arity) return -4;
+  const uint64_t *fcap[8];
+  for (int l = 0; l < sh->n_arity; l++) { if (rd_u64(&r) != cap_n) return -4; fcap[l] = rd_felts(&r, cap_n * 4); }
+  if (rd_u64(&r) != (uint64_t)sh->num_query_rounds) return -5;
+  size_t q_off = r.o;
+  /* skip the queries to reach final poly / pow / public inputs */
+  int depth0 = db + rb - ch;
+  size_t kk[4] = {k_cs, k_w, k_z, k_q};
+  for (int qi = 0; qi < sh->num_query_rounds; qi++) {
+    if (rd_u64(&r) != 4) return -6;
+    for (int b = 0; b < 4; b++) { if (rd_u64(&r) != kk[b]) return -6; rd_felts(&r, kk[b]); if (rd_u64(&r) != (uint64_t)depth0) return -6; rd_felts(&r, (size_t)depth0 * 4); }
+    if (rd_u64(&r) != (uint64_t)sh->n_arity) return -6;
+    size_t nl = N;
+    for (int l = 0; l < sh->n_arity; l++) {
+      size_t arity = (size_t)1 << sh->arity_bits[l]; nl >>= sh->arity_bits[l];
+      if (rd_u64(&r) != arity) return -6; rd_felts(&r, 2 * arity);
+      int depth = log2z(nl) - ch; if (depth < 0) depth = 0;
+      if (rd_u64(&r) != (uint64_t)depth) return -6; rd_felts(&r, (size_t)depth * 4);
+    }
+  }
+  size_t final_len = rd_u64(&r);
+  const uint64_t *final_poly = rd_felts(&r, final_len * 2);
+  uint64_t pow_witness = rd_u64(&r);
+  size_t n_pi = rd_u64(&r);
+  const uint64_t *pi = rd_felts(&r, n_pi);
+  if (r.bad || r.o != len) return -7;
+
+  /* transcript */
+  uint64_t pi_hash[4]; or_hash_no_pad(pi, n_pi, pi_hash);
+  or_challenger c; or_ch_init(&c);
+  or_ch_observe(&c, circuit_digest, 4); or_ch_observe(&c, pi_hash, 4); or_ch_observe(&c, caps[1], cap_n * 4);
+  for (int i = 0; i < 2 * sh->num_challenges; i++) (void)or_ch_challenge(&c);
+  or_ch_observe(&c, caps[2], cap_n * 4);
+  for (int i = 0; i < sh->num_challenges; i++) (void)or_ch_challenge(&c);
+  or_ch_observe(&c, caps[3], cap_n * 4);
+  gl2_t zeta = ch_ext(&c);
+  gl2_t zeta_next = gl2_scale(zeta, gl_root_of_unity(db));
+  /* zeta batch order: constants, sigmas, wires, zs, partial products, quotient ; next batch: zs_next */
+  int zorder[6] = {0, 1, 2, 3, 5, 6};
+  for (int i = 0; i < 6; i++) or_ch_observe(&c, op[zorder[i]], cnt[zorder[i]] * 2);
+  or_ch_observe(&c, op[4], cnt[4] * 2);
+  gl2_t alpha = ch_ext(&c);
+  gl2_t betas[8];
+  for (int l = 0; l < sh->n_arity; l++) { or_ch_observe(&c, fcap[l], cap_n * 4); betas[l] = ch_ext(&c); }
+  or_ch_observe(&c, final_poly, final_len * 2);
+  or_ch_observe(&c, &pow_witness, 1);
+  uint64_t resp = or_ch_challenge(&c);
+  if (dbg) { dbg->zeta[0] = zeta.c[0]; dbg->zeta[1] = zeta.c[1]; dbg->pow_response = resp;
+             for (int l = 0; l < sh->n_arity; l++) { dbg->fri_betas[l][0] = betas[l].c[0]; dbg->fri_betas[l][1] = betas[l].c[1]; } }
+  if ((resp >> (64 - sh->pow_bits)) != 0) return -8;
+
+  /* reduced openings: sum alpha^j opening_j per batch */
+  gl2_t red0 = gl2_from_base(0), red1 = gl2_from_base(0);
+  for (int i = 5; i >= 0; i--) for (size_t j = cnt[zorder[i]]; j-- > 0;)
+    red0 = gl2_add(gl2_mul(red0, alpha), gl2_make(op[zorder[i]][2 * j], op[zorder[i]][2 * j + 1]));
+  for (size_t j = cnt[4]; j-- > 0;) red1 = gl2_add(gl2_mul(red1, alpha), gl2_make(op[4][2 * j], op[4][2 * j + 1]));
+
+  rd_t q = {proof, len, q_off, 0};
+  for (int qi = 0; qi < sh->num_query_rounds; qi++) {
+    size_t x_index = (size_t)(or_ch_challenge(&c) % N);
+    if (dbg && qi < 64) dbg->query_indices[qi] = x_index;
+    rd_u64(&q);
+    const uint64_t *ev[4];
+    for (int b = 0; b < 4; b++) {
+      rd_u64(&q); ev[b] = rd_felts(&q, kk[b]); rd_u64(&q);
+      const uint64_t *sibs = rd_felts(&q, (size_t)depth0 * 4);
+      if (!or_merkle_verify(ev[b], kk[b], x_index, sibs, depth0, caps[b], ch)) return -10 - b;
+    }
+    uint64_t x = or_fri_query_point(x_index, db + rb);
+    /* fri_combine_initial */
+    gl2_t sum = gl2_from_base(0);
+    {
+      gl2_t re = gl2_from_base(0);
+      for (int b = 3; b >= 0; b--) for (size_t j = kk[b]; j-- > 0;) re = gl2_add(gl2_mul(re, alpha), gl2_from_base(ev[b][j]));
+      gl2_t num = gl2_sub(re, red0), den = gl2_sub(gl2_from_base(x), zeta);
+      sum = gl2_mul(num, gl2_inv(den)); /* alpha.shift(0) = 0 */
+      gl2_t re1 = gl2_from_base(0);
+      for (size_t j = sh->num_challenges; j-- > 0;) re1 = gl2_add(gl2_mul(re1, alpha), gl2_from_base(ev[2][j]));
+      gl2_t num1 = gl2_sub(re1, red1), den1 = gl2_sub(gl2_from_base(x), zeta_next);
+      sum = gl2_add(gl2_mul(sum, gl2_pow(alpha, sh->num_challenges)), gl2_mul(num1, gl2_inv(den1)));
+    }
+    rd_u64(&q);
+    gl2_t old = sum; size_t xi = x_index; size_t nl = N;
+    for (int l = 0; l < sh->n_arity; l++) {
+      int ab = sh->arity_bits[l]; size_t arity = (size_t)1 << ab; nl >>= ab;
+      rd_u64(&q); const uint64_t *fe = rd_felts(&q, 2 * arity);
+      int depth = log2z(nl) - ch; if (depth < 0) depth = 0;
+      rd_u64(&q); const uint64_t *sibs = rd_felts(&q, (size_t)depth * 4);
+      size_t within = xi & (arity - 1), coset = xi >> ab;
+      if (fe[2 * within] != old.c[0] || fe[2 * within + 1] != old.c[1]) return -20 - l;
+      uint64_t o2[2];
+      or_fri_compute_evaluation(x, within, ab, fe, betas[l].c, o2);
+      old = gl2_make(o2[0], o2[1]);
+      if (!or_merkle_verify(fe, 2 * arity, coset, sibs, depth, fcap[l], ch)) return -30 - l;
+      for (int s = 0; s < ab; s++) x = gl_mul(x, x);
+      xi = coset;
+    }
+    gl2_t fp = eval_ext_poly((const gl2_t *)final_poly, final_len, gl2_from_base(x));
+    if (!gl2_eq(fp, old)) return -40;
+  }
+  return 0;
+}

@@ -22,7 +22,7 @@ def lib():
     if _lib is not None:
         return _lib
     so = os.path.join(ORACLE_DIR, "libcityoracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("cityoracle.c", "cityoracle.h", "goldilocks.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("cityoracle.c", "plonky2_tail.c", "cityoracle.h", "goldilocks.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         build()
     L = ctypes.CDLL(so)
@@ -48,6 +48,9 @@ def lib():
         "or_dft_naive": (None, [_u64p, _u64p, i]),
         "or_commit_batch": (None, [_u64p, sz, i, i, i, _u64p, _u64p, _u64p, _u64p]),
         "or_set_threads": (None, [i]), "or_get_threads": (i, []),
+        "or_fri_compute_evaluation": (None, [u64, sz, i, _u64p, _u64p, _u64p]),
+        "or_fri_query_point": (u64, [sz, i]),
+        "or_free": (None, [ctypes.c_void_p]),
     }
     for name, (res, args) in sigs.items():
         f = getattr(L, name)
@@ -193,3 +196,63 @@ def splitmix64_felts(seed, n):
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
     return z % np.uint64(P)
+
+
+# ---- transcript / FRI / proof tail -----------------------------------------------------------
+class Shape(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "degree_bits", "num_constants", "num_routed_wires", "num_wires", "num_challenges",
+        "num_partial_products", "quotient_degree_factor", "rate_bits", "cap_height", "pow_bits",
+        "num_query_rounds", "n_arity")] + [("arity_bits", ctypes.c_int * 8)]
+
+
+class TailDebug(ctypes.Structure):
+    _fields_ = [("betas", ctypes.c_uint64 * 8), ("gammas", ctypes.c_uint64 * 8), ("alphas", ctypes.c_uint64 * 8),
+                ("zeta", ctypes.c_uint64 * 2), ("fri_betas", (ctypes.c_uint64 * 2) * 8),
+                ("pow_response", ctypes.c_uint64), ("query_indices", ctypes.c_uint64 * 64)]
+
+
+class Challenger(ctypes.Structure):
+    _fields_ = [("state", ctypes.c_uint64 * 12), ("inb", ctypes.c_uint64 * 8), ("n_in", ctypes.c_int),
+                ("out", ctypes.c_uint64 * 8), ("n_out", ctypes.c_int)]
+
+
+def standard_shape(degree_bits=12, num_wires=135, num_routed=80, num_constants=5, num_challenges=2,
+                   num_partial_products=9, quotient_degree_factor=8, rate_bits=3, cap_height=4, pow_bits=16,
+                   num_query_rounds=28, arity_bits=(4, 4)):
+    """standard_recursion_config shape as measured from the reference proofs."""
+    s = Shape(degree_bits, num_constants, num_routed, num_wires, num_challenges, num_partial_products,
+              quotient_degree_factor, rate_bits, cap_height, pow_bits, num_query_rounds, len(arity_bits))
+    for i, a in enumerate(arity_bits):
+        s.arity_bits[i] = a
+    return s
+
+
+def prove_tail(shape, circuit_digest, public_inputs, cs_values, wires_values, zs_pp_values, quotient_coeffs,
+               pow_override=None):
+    L = lib()
+    L.or_prove_tail.restype = ctypes.c_int
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    ln = ctypes.c_size_t()
+    dbg = TailDebug()
+    cd, pi = arr(circuit_digest), arr(public_inputs)
+    a, b, c, d = arr(cs_values), arr(wires_values), arr(zs_pp_values), arr(quotient_coeffs)
+    rc = L.or_prove_tail(ctypes.byref(shape), ptr(cd), ptr(pi), ctypes.c_size_t(pi.size), ptr(a), ptr(b), ptr(c),
+                         ptr(d), ctypes.c_int(0 if pow_override is None else 1),
+                         ctypes.c_uint64(pow_override or 0), ctypes.byref(out), ctypes.byref(ln),
+                         ctypes.byref(dbg))
+    assert rc == 0, rc
+    data = bytes(bytearray(out[:ln.value]))
+    L.or_free(out)
+    return data, dbg
+
+
+def verify_tail(shape, circuit_digest, cs_cap, proof_bytes):
+    L = lib()
+    L.or_verify_tail.restype = ctypes.c_int
+    dbg = TailDebug()
+    cd, cap = arr(circuit_digest), arr(cs_cap)
+    buf = (ctypes.c_uint8 * len(proof_bytes)).from_buffer_copy(proof_bytes)
+    rc = L.or_verify_tail(ctypes.byref(shape), ptr(cd), ptr(cap), buf, ctypes.c_size_t(len(proof_bytes)),
+                          ctypes.byref(dbg))
+    return rc, dbg
