@@ -306,3 +306,83 @@ class Prover:
                 if b:
                     b.free()
         return res
+
+
+# ---- circuits and the proof tail ---------------------------------------------------------------
+class Shape(ctypes.Structure):
+    """cp_shape (include/cityprover.h)."""
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "degree_bits", "num_constants", "num_routed_wires", "num_wires", "num_challenges",
+        "num_partial_products", "quotient_degree_factor", "rate_bits", "cap_height", "pow_bits",
+        "num_query_rounds", "n_arity")] + [("arity_bits", ctypes.c_int * 8)]
+
+
+def standard_recursion_shape(**over):
+    """CircuitConfig::standard_recursion_config() at degree 2^12, the only configuration the worker
+    circuits use (SURVEY.md §5 'Config / flags', Appendix A)."""
+    d = dict(degree_bits=12, num_constants=5, num_routed_wires=80, num_wires=135, num_challenges=2,
+             num_partial_products=9, quotient_degree_factor=8, rate_bits=3, cap_height=4, pow_bits=16,
+             num_query_rounds=28, arity_bits=(4, 4))
+    d.update(over)
+    ab = d.pop("arity_bits")
+    s = Shape(**d, n_arity=len(ab))
+    for i, a in enumerate(ab):
+        s.arity_bits[i] = a
+    return s
+
+
+ABI.update({
+    "cp_circuit_load": (_vp, [_vp, ctypes.POINTER(Shape), _u64p, _u64p]),
+    "cp_circuit_destroy": (None, [_vp]),
+    "cp_circuit_cs_cap": (ctypes.c_int, [_vp, _u64p]),
+    "cp_prove_tail": (ctypes.c_int, [_vp, _u64p, ctypes.c_size_t, _vp, _vp, _vp, ctypes.c_int, ctypes.c_uint64,
+                                     ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)),
+                                     ctypes.POINTER(ctypes.c_size_t)]),
+    "cp_free": (None, [_vp]),
+})
+
+
+class Circuit:
+    """Device-resident circuit: the mirror of a built `CircuitData` (constants/sigmas commitment)."""
+
+    def __init__(self, prover, shape, circuit_digest, cs_values):
+        self.prover, self.shape = prover, shape
+        cd, cs = _as_u64(circuit_digest), _as_u64(cs_values)
+        n = 1 << shape.degree_bits
+        assert cs.shape == (shape.num_constants + shape.num_routed_wires, n)
+        self.handle = prover.lib.cp_circuit_load(prover.ctx, ctypes.byref(shape), _ptr(cd), _ptr(cs))
+        if not self.handle:
+            raise CityProverError(prover.lib.cp_last_error(prover.ctx).decode())
+
+    def cs_cap(self):
+        cap = np.zeros((1 << self.shape.cap_height, 4), np.uint64)
+        self.prover._check(self.prover.lib.cp_circuit_cs_cap(self.handle, _ptr(cap)))
+        return cap
+
+    def prove_tail(self, public_inputs, wires_values, zs_pp_values, quotient_coeffs, pow_override=None):
+        """numpy in (uploaded here), bincode ProofWithPublicInputs bytes out."""
+        p = self.prover
+        pi = _as_u64(public_inputs)
+        bufs = [p.to_device(_as_u64(a)) for a in (wires_values, zs_pp_values, quotient_coeffs)]
+        try:
+            return self.prove_tail_dev(pi, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, pow_override)
+        finally:
+            for b in bufs:
+                b.free()
+
+    def prove_tail_dev(self, public_inputs, wires_ptr, zs_pp_ptr, quotient_ptr, pow_override=None):
+        p = self.prover
+        pi = _as_u64(public_inputs)
+        out = ctypes.POINTER(ctypes.c_uint8)()
+        ln = ctypes.c_size_t()
+        p._check(p.lib.cp_prove_tail(self.handle, _ptr(pi) if pi.size else None, pi.size, wires_ptr, zs_pp_ptr,
+                                     quotient_ptr, 0 if pow_override is None else 1, pow_override or 0,
+                                     ctypes.byref(out), ctypes.byref(ln)))
+        data = bytes(bytearray(out[:ln.value]))
+        p.lib.cp_free(out)
+        return data
+
+    def close(self):
+        if self.handle:
+            self.prover.lib.cp_circuit_destroy(self.handle)
+            self.handle = None

@@ -774,3 +774,7 @@ int cp_commit_dev(cp_ctx *ctx, const uint64_t *values, size_t k, int log_n, int 
 }
 
 }  // extern "C"
+
+// ---- circuits + proof tail (transcript, openings, FRI, proof bytes) -------------------------------
+#include "fri.h"
+#include "prover_tail.inc"

@@ -149,6 +149,51 @@ int cp_commit_batch_dev(cp_ctx *ctx, const uint64_t *values_dev, size_t k, size_
                         int rate_bits, int cap_height, uint64_t *coeffs_dev, uint64_t *lde_dev,
                         uint64_t *digests_dev, uint64_t *caps_dev);
 
+/* ---- circuits and the proof tail ----------------------------------------------------------
+ * cp_shape = the scalars of plonky2 `CommonCircuitData` the prover needs (the same fields the
+ * reference serialises at city_common_circuit/src/verify_template/ser_data.rs:55-123).
+ * standard_recursion_config as used by every worker circuit: degree_bits 12, num_constants 5
+ * (2 gate constants + 3 selectors), num_routed_wires 80, num_wires 135, num_challenges 2,
+ * num_partial_products 9, quotient_degree_factor 8, rate_bits 3, cap_height 4, pow_bits 16,
+ * num_query_rounds 28, arity_bits {4,4}. */
+typedef struct cp_shape {
+  int degree_bits, num_constants, num_routed_wires, num_wires, num_challenges, num_partial_products,
+      quotient_degree_factor;
+  int rate_bits, cap_height, pow_bits, num_query_rounds;
+  int n_arity;
+  int arity_bits[8];
+} cp_shape;
+
+typedef struct cp_circuit cp_circuit;
+
+/* Load a circuit: commits its constants+sigmas polynomials ((num_constants+num_routed_wires) x n
+ * VALUES over <omega_n>, host pointer) once and keeps coefficients / LDE / Merkle tree resident in
+ * HBM for the circuit's lifetime — the counterpart of building `CircuitData` once in
+ * `CRWorkerToolboxRootCircuits::new` (city_rollup_circuit/src/worker/toolbox/root.rs:75-139).
+ * Returns NULL on failure (cp_last_error(ctx)). */
+cp_circuit *cp_circuit_load(cp_ctx *ctx, const cp_shape *shape, const uint64_t circuit_digest[4],
+                            const uint64_t *cs_values_host);
+void cp_circuit_destroy(cp_circuit *circuit);
+/* the circuit's constants_sigmas_cap (2^cap_height x 4), i.e. VerifierOnlyCircuitData */
+int cp_circuit_cs_cap(cp_circuit *circuit, uint64_t *cap_out_host);
+
+/* Everything of `CircuitData::prove` after the polynomials are known (SURVEY.md §3.3 steps 3-4, 6,
+ * 8-11): commits wires / Z+partial-products / quotient chunks, runs the Fiat-Shamir transcript,
+ * opens every polynomial at zeta (Z polynomials also at g*zeta), builds the FRI opening proof
+ * (batch polynomial, commit phase, proof of work with the SMALLEST valid witness unless
+ * use_pow_override, query rounds) and serialises `ProofWithPublicInputs` in bincode (malloc'd;
+ * release with cp_free).
+ *   wires_values_dev : num_wires x n evaluations (device)
+ *   zs_pp_values_dev : num_challenges*(1+num_partial_products) x n evaluations, Z polynomials first
+ *   quotient_coeffs_dev : num_challenges*quotient_degree_factor x n COEFFICIENTS (degree-n chunks)
+ * The Z / quotient computation itself (gate constraints) is upstream of this
+ * entry point. */
+int cp_prove_tail(cp_circuit *circuit, const uint64_t *public_inputs_host, size_t n_public_inputs,
+                  const uint64_t *wires_values_dev, const uint64_t *zs_pp_values_dev,
+                  const uint64_t *quotient_coeffs_dev, int use_pow_override, uint64_t pow_override,
+                  uint8_t **proof_out, size_t *proof_len);
+void cp_free(void *ptr);
+
 #ifdef __cplusplus
 }
 #endif
