@@ -378,7 +378,7 @@ class Circuit:
         p._check(p.lib.cp_prove_tail(self.handle, _ptr(pi) if pi.size else None, pi.size, wires_ptr, zs_pp_ptr,
                                      quotient_ptr, 0 if pow_override is None else 1, pow_override or 0,
                                      ctypes.byref(out), ctypes.byref(ln)))
-        data = bytes(bytearray(out[:ln.value]))
+        data = ctypes.string_at(out, ln.value)
         p.lib.cp_free(out)
         return data
 
@@ -386,3 +386,32 @@ class Circuit:
         if self.handle:
             self.prover.lib.cp_circuit_destroy(self.handle)
             self.handle = None
+
+
+ABI["cp_prove_tail_batch"] = (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp), ctypes.POINTER(_u64p),
+                                             ctypes.POINTER(ctypes.c_size_t), _vp, _vp, _vp,
+                                             ctypes.POINTER(ctypes.c_int), _u64p,
+                                             ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)),
+                                             ctypes.POINTER(ctypes.c_size_t)])
+
+
+def prove_tail_batch_dev(prover, circuits, public_inputs, wires_ptr, zs_pp_ptr, quotient_ptr, pow_overrides=None):
+    """circuits: list of Circuit (same shape); public_inputs: list of u64 sequences; device pointers hold
+    [proof][poly][n]. Returns a list of proof byte strings."""
+    B = len(circuits)
+    cs = (_vp * B)(*[c.handle for c in circuits])
+    pis = [_as_u64(p) for p in public_inputs]
+    pi_ptrs = (_u64p * B)(*[_ptr(p) if p.size else None for p in pis])
+    n_pis = (ctypes.c_size_t * B)(*[p.size for p in pis])
+    use = (ctypes.c_int * B)(*[0 if (pow_overrides is None or pow_overrides[i] is None) else 1 for i in range(B)])
+    ov = np.array([0 if (pow_overrides is None or pow_overrides[i] is None) else pow_overrides[i] for i in range(B)],
+                  dtype=np.uint64)
+    outs = (ctypes.POINTER(ctypes.c_uint8) * B)()
+    lens = (ctypes.c_size_t * B)()
+    prover._check(prover.lib.cp_prove_tail_batch(prover.ctx, B, cs, pi_ptrs, n_pis, wires_ptr, zs_pp_ptr, quotient_ptr,
+                                                 use, _ptr(ov), outs, lens))
+    res = []
+    for i in range(B):
+        res.append(ctypes.string_at(outs[i], lens[i]))
+        prover.lib.cp_free(outs[i])
+    return res

@@ -41,6 +41,11 @@ struct cp_ctx {
   // scratch buffer reused by natural-order NTT epilogues / merkle host paths
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
+  // per-proof workspace arena (prover_tail.inc): chunks survive between proofs
+  struct Arena {
+    std::vector<std::pair<char *, size_t>> chunks;
+    size_t cur = 0, off = 0, used = 0;
+  } arena;
   // optional per-kernel hipEvent timing (cp_profile_begin / cp_profile_end)
   bool profiling = false;
   struct ProfRec { const char *name; hipEvent_t e0, e1; };
@@ -416,6 +421,7 @@ void cp_ctx_destroy(cp_ctx *ctx) {
   for (auto e : ctx->prof_pool) hipEventDestroy(e);
   for (auto &kv : ctx->pow_tables) hipFree(kv.second.dev);
   for (auto &kv : ctx->prescale_tables) hipFree(kv.second);
+  for (auto &ch : ctx->arena.chunks) hipFree(ch.first);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;

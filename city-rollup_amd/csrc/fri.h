@@ -4,9 +4,12 @@
 // dependency); the fold / final-polynomial / fri_combine_initial relations are pinned on the reference
 // proofs by tests/test_oracle_fri_reference.py and tests/test_oracle_fri_combine_reference.py.
 //
-// All of this is small at the product shape (n = 2^12): a few hundred KB per kernel, L2-resident and
-// latency-bound; the kernels are written for few launches and no host round-trips beyond the ones the
-// Fiat-Shamir transcript forces.
+// Every kernel carries a PROOF dimension (blockIdx.y, or .z): a call proves B independent proofs of the
+// same shape at once, so that at the product shape (n = 2^12, a few hundred KB per proof and step)
+// launches are amortised over the batch and the grids are large enough to be throughput- rather than
+// latency-bound. Per-proof buffers are laid out [proof][...] with a fixed stride; only the circuit's
+// constants/sigmas oracle is reached through a per-proof pointer table (proofs of different circuits
+// can share a batch).
 #pragma once
 #include "gl.h"
 #include "poseidon.h"
@@ -25,12 +28,11 @@ __device__ __forceinline__ Ext ext_pow(Ext b, uint64_t e) {
   return r;
 }
 
-// out[j] = z^j (and optionally inv_out[j] = z^-j), j < n
-__global__ void k_ext_powers(Ext z, Ext zinv, size_t n, Ext *__restrict__ out, Ext *__restrict__ inv_out) {
+// pts: P points; out[p][j] = pts[p]^j, j < n
+__global__ void k_ext_powers(const Ext *__restrict__ pts, size_t n, Ext *__restrict__ out) {
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  out[j] = ext_pow(z, j);
-  if (inv_out) inv_out[j] = ext_pow(zinv, j);
+  out[(size_t)blockIdx.y * n + j] = ext_pow(pts[blockIdx.y], j);
 }
 
 // block reduce of an Ext over 256 threads (result valid in thread 0)
@@ -44,76 +46,89 @@ __device__ __forceinline__ Ext block_sum(Ext v, Ext *sh) {
   return sh[0];
 }
 
-// out[p] = sum_j coeffs[p][j] * zpow[j]   (one workgroup per polynomial)
-__global__ __launch_bounds__(256) void k_eval_at_point(const uint64_t *__restrict__ coeffs, size_t stride, size_t n,
-                                                       const Ext *__restrict__ zpow, Ext *__restrict__ out) {
+// out[proof][out_off + p] = sum_j coeffs_proof[p][j] * zpow[proof*zstride + j]
+// coeffs_proof = table ? table[proof] : base + proof*proof_stride.   grid = (k, B)
+__global__ __launch_bounds__(256) void k_eval_at_point(const uint64_t *__restrict__ base, size_t proof_stride,
+                                                       const uint64_t *const *__restrict__ table, size_t n,
+                                                       const Ext *__restrict__ zpow, size_t zstride,
+                                                       Ext *__restrict__ out, size_t out_stride, size_t out_off) {
   __shared__ Ext sh[256];
-  const uint64_t *c = coeffs + (size_t)blockIdx.x * stride;
+  const size_t proof = blockIdx.y;
+  const uint64_t *c = (table ? table[proof] : base + proof * proof_stride) + (size_t)blockIdx.x * n;
+  const Ext *zp = zpow + proof * zstride;
   Ext acc{0, 0};
   for (size_t j = threadIdx.x; j < n; j += 256) {
     uint64_t v = c[j];
-    Ext z = zpow[j];
+    Ext z = zp[j];
     acc.a = gl::add(acc.a, gl::mul(v, z.a));
     acc.b = gl::add(acc.b, gl::mul(v, z.b));
   }
   Ext r = block_sum(acc, sh);
-  if (threadIdx.x == 0) out[blockIdx.x] = r;
+  if (threadIdx.x == 0) out[proof * out_stride + out_off + blockIdx.x] = r;
 }
 
 struct BatchRefs {
-  const uint64_t *base[4];  // coefficient form, polynomial p of batch b at base[b] + p*stride
-  int k[4];
-  size_t stride;
+  const uint64_t *const *table0;  // per-proof pointer to oracle 0 (constants+sigmas) coefficients
+  const uint64_t *base[4];        // oracles 1..3: base[b] + proof*proof_stride[b]
+  size_t proof_stride[4];
+  int k[4];                       // polynomials taken from each oracle, in order
+  size_t n;
 };
 
-// comp[c] = sum_{p over the listed polynomials, in order} apow[p] * f_p[c]
-__global__ __launch_bounds__(256) void k_combine(BatchRefs refs, const Ext *__restrict__ apow, size_t n,
+// comp[proof][c] = sum_{listed polynomials p, in order} apow[proof][idx(p)] * f_p[c].   grid = (n/256, B)
+__global__ __launch_bounds__(256) void k_combine(BatchRefs refs, const Ext *__restrict__ apow, size_t apow_stride,
                                                  Ext *__restrict__ comp) {
   size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (c >= n) return;
+  if (c >= refs.n) return;
+  const size_t proof = blockIdx.y;
+  const Ext *ap = apow + proof * apow_stride;
   Ext acc{0, 0};
   int idx = 0;
   for (int b = 0; b < 4; b++) {
-    const uint64_t *f = refs.base[b] + c;
+    if (!refs.k[b]) continue;
+    const uint64_t *f = (b == 0 ? refs.table0[proof] : refs.base[b] + proof * refs.proof_stride[b]) + c;
     for (int p = 0; p < refs.k[b]; p++, idx++) {
-      uint64_t v = f[(size_t)p * refs.stride];
-      Ext a = apow[idx];
+      uint64_t v = f[(size_t)p * refs.n];
+      Ext a = ap[idx];
       acc.a = gl::add(acc.a, gl::mul(v, a.a));
       acc.b = gl::add(acc.b, gl::mul(v, a.b));
     }
   }
-  comp[c] = acc;
+  comp[proof * refs.n + c] = acc;
 }
 
 // q = (comp - comp(z)) / (X - z):  q[i] = z^-(i+1) * sum_{j>i} comp[j] z^j ;  q[n-1] = 0.
-// fin = fin * shift + q  (first == 1: fin = q). One workgroup, n <= 2^16.
+// fin = fin * shift + q  (first == 1: fin = q). One workgroup per proof (grid = (1, B)).
+// zpow / zinvpow: tables of the proof's point (stride zstride per proof); fin: [proof][re | im][n].
 __global__ __launch_bounds__(256) void k_divide_linear_accumulate(const Ext *__restrict__ comp, const Ext *__restrict__ zpow,
-                                                                  const Ext *__restrict__ zinvpow, Ext zinv_n, size_t n,
-                                                                  Ext shift, int first, uint64_t *__restrict__ fin_re,
-                                                                  uint64_t *__restrict__ fin_im) {
+                                                                  const Ext *__restrict__ zinvpow, size_t zstride, size_t n,
+                                                                  const Ext *__restrict__ shifts, int first,
+                                                                  uint64_t *__restrict__ fin) {
   __shared__ Ext tot[256];
   const int t = threadIdx.x;
+  const size_t proof = blockIdx.y;
+  comp += proof * n;
+  zpow += proof * zstride;
+  zinvpow += proof * zstride;
+  uint64_t *fin_re = fin + proof * 2 * n, *fin_im = fin_re + n;
+  const Ext shift = shifts[proof];
   const size_t per = (n + 255) / 256;
   const size_t lo = (size_t)t * per < n ? (size_t)t * per : n, hi = lo + per < n ? lo + per : n;
-  // local suffix sum of G[j] = comp[j] z^j over the thread's chunk
   Ext s{0, 0};
   for (size_t j = hi; j-- > lo;) s = gl::ext_add(s, gl::ext_mul(comp[j], zpow[j]));
   tot[t] = s;
   __syncthreads();
-  // exclusive suffix scan over chunk totals (Hillis-Steele on the reversed order)
-  for (int d = 1; d < 256; d <<= 1) {
+  for (int d = 1; d < 256; d <<= 1) {  // inclusive suffix scan over chunk totals
     Ext v = tot[t];
     if (t + d < 256) v = gl::ext_add(v, tot[t + d]);
     __syncthreads();
     tot[t] = v;
     __syncthreads();
   }
-  Ext above = (t + 1 < 256) ? tot[t + 1] : Ext{0, 0};  // sum of G[j] for j >= hi
-  // walk the chunk downwards: S[i] = sum_{j>i} G[j]
-  Ext run = above;
+  Ext run = (t + 1 < 256) ? tot[t + 1] : Ext{0, 0};  // sum of comp[j] z^j for j >= hi
   for (size_t i = hi; i-- > lo;) {
-    // z^-(i+1): the table holds z^-j for j < n; index n uses zinv_n
-    Ext zi = (i + 1 < n) ? zinvpow[i + 1] : zinv_n;
+    // q[n-1] = 0 (run == 0 there), so the missing table entry z^-n is never needed
+    Ext zi = (i + 1 < n) ? zinvpow[i + 1] : Ext{0, 0};
     Ext q = gl::ext_mul(run, zi);
     Ext f{0, 0};
     if (!first) f = gl::ext_mul(Ext{fin_re[i], fin_im[i]}, shift);
@@ -124,27 +139,36 @@ __global__ __launch_bounds__(256) void k_divide_linear_accumulate(const Ext *__r
   }
 }
 
-// FRI fold in coefficient space: out[j] = sum_{i<arity} beta^i c[arity*j + i]
-__global__ void k_fold(const uint64_t *__restrict__ re, const uint64_t *__restrict__ im, size_t n_out, int arity,
-                       Ext beta, uint64_t *__restrict__ out_re, uint64_t *__restrict__ out_im) {
+// FRI fold in coefficient space: out[j] = sum_{i<arity} beta^i c[arity*j + i].
+// in: [proof][re | im][n_in], out: [proof][re | im][n_out] at out + proof*out_stride.   grid = (blocks, B)
+// (n_in = physical length of the re / im arrays; coefficients at index >= n_in are zero: the first
+// layer folds the degree-<n batch polynomial as a length-N vector without materialising the padding.)
+__global__ void k_fold(const uint64_t *__restrict__ in, size_t in_stride, size_t n_in, size_t n_out, int arity,
+                       const Ext *__restrict__ betas, uint64_t *__restrict__ out, size_t out_stride) {
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_out) return;
+  const size_t proof = blockIdx.y;
+  const uint64_t *re = in + proof * in_stride, *im = re + n_in;
+  const Ext beta = betas[proof];
   Ext acc{0, 0};
   for (int i = arity - 1; i >= 0; i--) {
     size_t idx = (size_t)arity * j + i;
-    acc = gl::ext_add(gl::ext_mul(acc, beta), Ext{re[idx], im[idx]});
+    Ext c = idx < n_in ? Ext{re[idx], im[idx]} : Ext{0, 0};
+    acc = gl::ext_add(gl::ext_mul(acc, beta), c);
   }
-  out_re[j] = acc.a;
-  out_im[j] = acc.b;
+  uint64_t *o = out + proof * out_stride;
+  o[j] = acc.a;
+  o[n_out + j] = acc.b;
 }
 
 // FRI layer leaves: leaf j = the `arity` extension values at bit-reversed positions [arity*j, arity*(j+1)),
-// flattened (a0,b0,a1,b1,...). Writes the leaf digests and (for the query phase) nothing else: the values
-// themselves stay in re/im.
-__global__ __launch_bounds__(256) void k_leaf_hash_fri(const uint64_t *__restrict__ re, const uint64_t *__restrict__ im,
-                                                       size_t n_leaves, int arity, uint64_t *__restrict__ digests) {
+// flattened (a0,b0,a1,b1,...). vals: [proof][re | im][n_vals].   grid = (blocks, B)
+__global__ __launch_bounds__(256) void k_leaf_hash_fri(const uint64_t *__restrict__ vals, size_t vals_stride, size_t n_vals,
+                                                       size_t n_leaves, int arity, uint64_t *__restrict__ digests,
+                                                       size_t dig_stride) {
   size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= n_leaves) return;
+  const uint64_t *re = vals + (size_t)blockIdx.y * vals_stride, *im = re + n_vals;
   uint64_t s[poseidon::W];
 #pragma unroll
   for (int k = 0; k < poseidon::W; k++) s[k] = 0;
@@ -161,47 +185,57 @@ __global__ __launch_bounds__(256) void k_leaf_hash_fri(const uint64_t *__restric
       poseidon::permute(s);
     }
   }
-  uint64_t *d = digests + 4 * j;
+  uint64_t *d = digests + (size_t)blockIdx.y * dig_stride + 4 * j;
   d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
 }
 
-// Proof of work: candidates start .. start+count-1; records the smallest one whose response has
-// `pow_bits` leading zero bits. state = sponge state with the pending inputs already written.
-struct PowState { uint64_t s[12]; };
-__global__ __launch_bounds__(256) void k_pow_grind(PowState st, int pos, uint64_t start, uint64_t count, int pow_bits,
+// Proof of work: candidates start .. start+count-1 for every proof still searching; records the smallest
+// witness whose response has `pow_bits` leading zero bits. st[proof] = sponge state with the pending
+// inputs already written, pos[proof] = slot the witness goes to.   grid = (count/256, B)
+struct PowState { uint64_t s[12]; int pos; int pad; };
+__global__ __launch_bounds__(256) void k_pow_grind(const PowState *__restrict__ st, uint64_t start, uint64_t count,
+                                                   int pow_bits, const unsigned long long *__restrict__ done,
                                                    unsigned long long *__restrict__ best) {
+  const size_t proof = blockIdx.y;
+  if (done[proof] != ~0ull) return;  // found in an earlier chunk
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= count) return;
   uint64_t cand = start + i;
   uint64_t s[poseidon::W];
+  const int pos = st[proof].pos;
 #pragma unroll
-  for (int k = 0; k < poseidon::W; k++) s[k] = st.s[k];
+  for (int k = 0; k < poseidon::W; k++) s[k] = st[proof].s[k];
 #pragma unroll
   for (int k = 0; k < 8; k++)
     if (k == pos) s[k] = cand;
   poseidon::permute(s);
-  if ((s[7] >> (64 - pow_bits)) == 0) atomicMin(best, (unsigned long long)cand);
+  if ((s[7] >> (64 - pow_bits)) == 0) atomicMin(best + proof, (unsigned long long)cand);
 }
 
-// Query gathering. One workgroup per query round; writes the bincode words of one FriQueryRound.
+// Query gathering: one workgroup per (query round, proof); writes the bincode words of a FriQueryRound.
 struct QueryRefs {
-  const uint64_t *lde[4];      // bit-reversed LDE, column-major, stride N
-  const uint64_t *digests[4];  // levels below the cap
+  const uint64_t *const *lde0;      // oracle 0 per-proof pointer tables
+  const uint64_t *const *digests0;
+  const uint64_t *lde[4];           // oracles 1..3: + proof*lde_stride[b]
+  const uint64_t *digests[4];       //               + proof*dig_stride[b]
+  size_t lde_stride[4], dig_stride[4];
   int k[4];
   size_t N;
-  int depth0;                  // log2(N) - cap_height
+  int depth0;                       // log2(N) - cap_height
   int n_layers;
-  const uint64_t *fre[8], *fim[8];  // FRI layer values (bit-reversed order)
+  const uint64_t *fvals[8];         // FRI layer values [proof][re | im][f_nvals]
+  size_t fvals_stride[8], f_nvals[8];
   const uint64_t *fdig[8];
+  size_t fdig_stride[8];
   size_t f_leaves[8];
   int f_arity_bits[8];
   int f_depth[8];
   size_t words_per_query;
+  int n_queries;
 };
 
 __device__ __forceinline__ void copy_path(const uint64_t *dig, size_t n_leaves, int depth, size_t idx,
                                           uint64_t *out) {
-  // level l sibling = digests[off_l + ((idx >> l) ^ 1)]
   for (int w = threadIdx.x; w < depth * 4; w += blockDim.x) {
     int l = w >> 2;
     size_t off = 0, n = n_leaves;
@@ -212,19 +246,22 @@ __device__ __forceinline__ void copy_path(const uint64_t *dig, size_t n_leaves, 
 
 __global__ __launch_bounds__(256) void k_gather_queries(QueryRefs r, const uint64_t *__restrict__ indices,
                                                         uint64_t *__restrict__ out) {
-  uint64_t *o = out + (size_t)blockIdx.x * r.words_per_query;
-  const size_t x = (size_t)indices[blockIdx.x];
+  const size_t proof = blockIdx.y;
+  uint64_t *o = out + (proof * r.n_queries + blockIdx.x) * r.words_per_query;
+  const size_t x = (size_t)indices[proof * r.n_queries + blockIdx.x];
   size_t w = 0;
   if (threadIdx.x == 0) o[w] = 4;
   w += 1;
   for (int b = 0; b < 4; b++) {
+    const uint64_t *lde = b == 0 ? r.lde0[proof] : r.lde[b] + proof * r.lde_stride[b];
+    const uint64_t *dig = b == 0 ? r.digests0[proof] : r.digests[b] + proof * r.dig_stride[b];
     if (threadIdx.x == 0) o[w] = (uint64_t)r.k[b];
     w += 1;
-    for (int p = threadIdx.x; p < r.k[b]; p += blockDim.x) o[w + p] = r.lde[b][(size_t)p * r.N + x];
+    for (int p = threadIdx.x; p < r.k[b]; p += blockDim.x) o[w + p] = lde[(size_t)p * r.N + x];
     w += r.k[b];
     if (threadIdx.x == 0) o[w] = (uint64_t)r.depth0;
     w += 1;
-    copy_path(r.digests[b], r.N, r.depth0, x, o + w);
+    copy_path(dig, r.N, r.depth0, x, o + w);
     w += (size_t)r.depth0 * 4;
   }
   if (threadIdx.x == 0) o[w] = (uint64_t)r.n_layers;
@@ -232,15 +269,16 @@ __global__ __launch_bounds__(256) void k_gather_queries(QueryRefs r, const uint6
   size_t xi = x;
   for (int l = 0; l < r.n_layers; l++) {
     const int ab = r.f_arity_bits[l], arity = 1 << ab;
+    const uint64_t *re = r.fvals[l] + proof * r.fvals_stride[l], *im = re + r.f_nvals[l];
     xi >>= ab;
     if (threadIdx.x == 0) o[w] = (uint64_t)arity;
     w += 1;
     for (int e = threadIdx.x; e < 2 * arity; e += blockDim.x)
-      o[w + e] = (e & 1) ? r.fim[l][(size_t)arity * xi + (e >> 1)] : r.fre[l][(size_t)arity * xi + (e >> 1)];
+      o[w + e] = (e & 1) ? im[(size_t)arity * xi + (e >> 1)] : re[(size_t)arity * xi + (e >> 1)];
     w += 2 * arity;
     if (threadIdx.x == 0) o[w] = (uint64_t)r.f_depth[l];
     w += 1;
-    copy_path(r.fdig[l], r.f_leaves[l], r.f_depth[l], xi, o + w);
+    copy_path(r.fdig[l] + proof * r.fdig_stride[l], r.f_leaves[l], r.f_depth[l], xi, o + w);
     w += (size_t)r.f_depth[l] * 4;
   }
 }

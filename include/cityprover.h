@@ -192,6 +192,17 @@ int cp_prove_tail(cp_circuit *circuit, const uint64_t *public_inputs_host, size_
                   const uint64_t *wires_values_dev, const uint64_t *zs_pp_values_dev,
                   const uint64_t *quotient_coeffs_dev, int use_pow_override, uint64_t pow_override,
                   uint8_t **proof_out, size_t *proof_len);
+/* Batched form — the throughput path. Proves n_proofs independent proofs of ONE shape in one call
+ * (circuits may differ, e.g. the 20 op-leaf jobs of a block): every device step is a single launch
+ * over the batch, every Fiat-Shamir step advances n_proofs transcripts. Polynomial inputs are laid
+ * out [proof][poly][n] contiguously. use_pow_override / pow_override may be NULL (= none). On success
+ * proofs_out[i] / proof_lens[i] hold malloc'd bincode proofs (cp_free each). All circuits must belong
+ * to `ctx`. */
+int cp_prove_tail_batch(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circuits,
+                        const uint64_t *const *public_inputs_host, const size_t *n_public_inputs,
+                        const uint64_t *wires_values_dev, const uint64_t *zs_pp_values_dev,
+                        const uint64_t *quotient_coeffs_dev, const int *use_pow_override,
+                        const uint64_t *pow_override, uint8_t **proofs_out, size_t *proof_lens);
 void cp_free(void *ptr);
 
 #ifdef __cplusplus

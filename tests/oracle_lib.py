@@ -242,7 +242,7 @@ def prove_tail(shape, circuit_digest, public_inputs, cs_values, wires_values, zs
                          ctypes.c_uint64(pow_override or 0), ctypes.byref(out), ctypes.byref(ln),
                          ctypes.byref(dbg))
     assert rc == 0, rc
-    data = bytes(bytearray(out[:ln.value]))
+    data = ctypes.string_at(out, ln.value)
     L.or_free(out)
     return data, dbg
 

@@ -93,3 +93,46 @@ def test_error_paths(prover):
         circ.prove_tail([O.P], w, z, q)  # non-canonical public input
     assert len(circ.prove_tail([1], w, z, q)) > 0  # still usable
     circ.close()
+
+
+def test_batched_proofs_of_different_circuits(prover):
+    """Batch of 5 proofs over 2 circuits of the same shape: each must equal its single-proof oracle bytes."""
+    import cityprover as cp
+    sh = cp.standard_recursion_shape(degree_bits=7, arity_bits=(2, 2), **SMALL)
+    osh = oracle_shape(sh)
+    csA, _, _, _ = polys(sh, 100)
+    csB, _, _, _ = polys(sh, 200)
+    circA = cp.Circuit(prover, sh, [1, 1, 1, 1], csA)
+    circB = cp.Circuit(prover, sh, [2, 2, 2, 2], csB)
+    circs = [circA, circB, circA, circB, circB]
+    ws, zs, qs, pis = [], [], [], []
+    for i in range(5):
+        _, w, z, q = polys(sh, 300 + i)
+        ws.append(w); zs.append(z); qs.append(q); pis.append(list(range(i)))
+    dw, dz, dq = prover.to_device(np.stack(ws)), prover.to_device(np.stack(zs)), prover.to_device(np.stack(qs))
+    got = cp.prove_tail_batch_dev(prover, circs, pis, dw.ptr, dz.ptr, dq.ptr)
+    for i in range(5):
+        cs, dg = (csA, [1, 1, 1, 1]) if circs[i] is circA else (csB, [2, 2, 2, 2])
+        want, _ = O.prove_tail(osh, dg, pis[i], cs, ws[i], zs[i], qs[i])
+        assert got[i] == want, f"proof {i}"
+    # nonce injection for a subset of the batch
+    n2 = parse_proof(got[2])["pow_witness"]
+    got2 = cp.prove_tail_batch_dev(prover, circs, pis, dw.ptr, dz.ptr, dq.ptr, pow_overrides=[None, None, n2, None, None])
+    assert got2 == got
+    for b in (dw, dz, dq):
+        b.free()
+    circA.close(); circB.close()
+
+
+def test_batch_rejects_mixed_shapes(prover):
+    import cityprover as cp
+    sh1 = cp.standard_recursion_shape(degree_bits=6, arity_bits=(2, 2), **SMALL)
+    sh2 = cp.standard_recursion_shape(degree_bits=6, arity_bits=(2,), **SMALL)
+    cs, w, z, q = polys(sh1, 1)
+    c1, c2 = cp.Circuit(prover, sh1, [0] * 4, cs), cp.Circuit(prover, sh2, [0] * 4, cs)
+    dw, dz, dq = prover.to_device(np.stack([w, w])), prover.to_device(np.stack([z, z])), prover.to_device(np.stack([q, q]))
+    with pytest.raises(cp.CityProverError):
+        cp.prove_tail_batch_dev(prover, [c1, c2], [[], []], dw.ptr, dz.ptr, dq.ptr)
+    for b in (dw, dz, dq):
+        b.free()
+    c1.close(); c2.close()
