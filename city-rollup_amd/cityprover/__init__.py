@@ -332,7 +332,8 @@ def standard_recursion_shape(**over):
 
 
 ABI.update({
-    "cp_circuit_load": (_vp, [_vp, ctypes.POINTER(Shape), _u64p, _u64p]),
+    "cp_circuit_load": (_vp, [_vp, ctypes.POINTER(Shape), _u64p, _u64p, _u64p]),
+    "cp_zs_partial_products_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp), _vp, _u64p, _u64p, _vp]),
     "cp_circuit_destroy": (None, [_vp]),
     "cp_circuit_cs_cap": (ctypes.c_int, [_vp, _u64p]),
     "cp_prove_tail": (ctypes.c_int, [_vp, _u64p, ctypes.c_size_t, _vp, _vp, _vp, ctypes.c_int, ctypes.c_uint64,
@@ -345,12 +346,14 @@ ABI.update({
 class Circuit:
     """Device-resident circuit: the mirror of a built `CircuitData` (constants/sigmas commitment)."""
 
-    def __init__(self, prover, shape, circuit_digest, cs_values):
+    def __init__(self, prover, shape, circuit_digest, cs_values, k_is=None):
         self.prover, self.shape = prover, shape
         cd, cs = _as_u64(circuit_digest), _as_u64(cs_values)
         n = 1 << shape.degree_bits
         assert cs.shape == (shape.num_constants + shape.num_routed_wires, n)
-        self.handle = prover.lib.cp_circuit_load(prover.ctx, ctypes.byref(shape), _ptr(cd), _ptr(cs))
+        ks = None if k_is is None else _as_u64(k_is)
+        self.handle = prover.lib.cp_circuit_load(prover.ctx, ctypes.byref(shape), _ptr(cd), _ptr(cs),
+                                                 None if ks is None else _ptr(ks))
         if not self.handle:
             raise CityProverError(prover.lib.cp_last_error(prover.ctx).decode())
 
@@ -415,3 +418,11 @@ def prove_tail_batch_dev(prover, circuits, public_inputs, wires_ptr, zs_pp_ptr, 
         res.append(ctypes.string_at(outs[i], lens[i]))
         prover.lib.cp_free(outs[i])
     return res
+
+
+def zs_partial_products_dev(prover, circuits, wires_ptr, betas, gammas, out_ptr):
+    """A7 for a batch: betas/gammas are (B, num_challenges) arrays; device buffers as in the header."""
+    B = len(circuits)
+    cs = (_vp * B)(*[c.handle for c in circuits])
+    b, g = _as_u64(betas).reshape(B, -1), _as_u64(gammas).reshape(B, -1)
+    prover._check(prover.lib.cp_zs_partial_products_dev(prover.ctx, B, cs, wires_ptr, _ptr(b), _ptr(g), out_ptr))

@@ -172,7 +172,18 @@ typedef struct cp_circuit cp_circuit;
  * `CRWorkerToolboxRootCircuits::new` (city_rollup_circuit/src/worker/toolbox/root.rs:75-139).
  * Returns NULL on failure (cp_last_error(ctx)). */
 cp_circuit *cp_circuit_load(cp_ctx *ctx, const cp_shape *shape, const uint64_t circuit_digest[4],
-                            const uint64_t *cs_values_host);
+                            const uint64_t *cs_values_host,
+                            const uint64_t *k_is_host /* num_routed_wires coset shifts
+                                                         (CommonCircuitData::k_is); NULL = 7^i */);
+
+/* A7 — permutation argument: Z and partial-product polynomials (plonky2
+ * `wires_permutation_partial_products_and_zs`) for n_proofs proofs of one shape.
+ * wires_values_dev: [proof][num_wires][n]; betas/gammas: [proof][num_challenges] (host);
+ * out_dev: [proof][num_challenges*(1+num_partial_products)][n] values over <omega_n>, in the order the
+ * batch is committed (Z polynomials first, then the partial products of challenge 0, 1, ...). */
+int cp_zs_partial_products_dev(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circuits,
+                               const uint64_t *wires_values_dev, const uint64_t *betas_host,
+                               const uint64_t *gammas_host, uint64_t *out_dev);
 void cp_circuit_destroy(cp_circuit *circuit);
 /* the circuit's constants_sigmas_cap (2^cap_height x 4), i.e. VerifierOnlyCircuitData */
 int cp_circuit_cs_cap(cp_circuit *circuit, uint64_t *cap_out_host);

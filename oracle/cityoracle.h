@@ -131,6 +131,13 @@ void or_fri_compute_evaluation(uint64_t x, size_t x_index_within_coset, int arit
 uint64_t or_fri_query_point(size_t x_index, int log_n);
 void or_free(void *p);
 
+/* A7: Z and partial-product polynomials of the permutation argument (values over <omega_n>).
+ * wires_values: num_wires x n (only the routed ones are read); sigma_values: num_routed_wires x n;
+ * out: num_challenges*(1+num_partial_products) x n in committed order (Z's first). */
+void or_zs_partial_products(const or_shape *sh, const uint64_t *wires_values, const uint64_t *sigma_values,
+                            const uint64_t *k_is, const uint64_t *betas, const uint64_t *gammas,
+                            uint64_t *out);
+
 /* number of worker threads the oracle uses for the batch entry points
  * (or_poseidon_permute_many, or_merkle_tree*, or_commit_batch); default 1 */
 void or_set_threads(int n);

@@ -495,3 +495,42 @@ int or_verify_tail(const or_shape *sh, const uint64_t circuit_digest[4], const u
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* A7: permutation argument — Z and partial products (plonky2 `wires_permutation_partial_products_and_zs`,
+ * SURVEY.md §3.3 step 5 / §8(a) A7). For every row i (x = omega^i) and routed wire j:
+ *   num_j = w_ij + beta * k_j * x + gamma ,  den_j = w_ij + beta * sigma_j(x) + gamma
+ * the 80 quotients are multiplied in chunks of `quotient_degree_factor` (10 chunk products), the running
+ * product over chunks gives the 9 partial products and Z(g x); Z(1) = 1.
+ * Output order = the committed batch: [Z_0 .. Z_{c-1}, pp(challenge 0) 0..npp-1, pp(challenge 1) ...]. */
+void or_zs_partial_products(const or_shape *sh, const uint64_t *wires_values, const uint64_t *sigma_values,
+                            const uint64_t *k_is, const uint64_t *betas, const uint64_t *gammas,
+                            uint64_t *out) {
+  const size_t n = (size_t)1 << sh->degree_bits;
+  const int R = sh->num_routed_wires, chunk = sh->quotient_degree_factor, npp = sh->num_partial_products;
+  const int nchunks = (R + chunk - 1) / chunk; /* == npp + 1 */
+  const int nc = sh->num_challenges;
+  uint64_t omega = gl_root_of_unity(sh->degree_bits);
+  for (int c = 0; c < nc; c++) {
+    uint64_t *Z = out + (size_t)c * n;
+    uint64_t *PP = out + ((size_t)nc + (size_t)c * npp) * n;
+    uint64_t z = 1, x = 1;
+    for (size_t i = 0; i < n; i++) {
+      uint64_t acc = z;
+      Z[i] = z;
+      for (int t = 0; t < nchunks; t++) {
+        uint64_t prod = 1;
+        for (int j = t * chunk; j < R && j < (t + 1) * chunk; j++) {
+          uint64_t w = wires_values[(size_t)j * n + i];
+          uint64_t num = gl_add(gl_add(w, gl_mul(betas[c], gl_mul(k_is[j], x))), gammas[c]);
+          uint64_t den = gl_add(gl_add(w, gl_mul(betas[c], sigma_values[(size_t)j * n + i])), gammas[c]);
+          prod = gl_mul(prod, gl_mul(num, gl_inv(den)));
+        }
+        acc = gl_mul(acc, prod);
+        if (t < npp) PP[(size_t)t * n + i] = acc;
+      }
+      z = acc; /* Z(g x) */
+      x = gl_mul(x, omega);
+    }
+  }
+}

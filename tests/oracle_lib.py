@@ -256,3 +256,12 @@ def verify_tail(shape, circuit_digest, cs_cap, proof_bytes):
     rc = L.or_verify_tail(ctypes.byref(shape), ptr(cd), ptr(cap), buf, ctypes.c_size_t(len(proof_bytes)),
                           ctypes.byref(dbg))
     return rc, dbg
+
+
+def zs_partial_products(shape, wires_values, sigma_values, k_is, betas, gammas):
+    L = lib()
+    w, s, k, b, g = arr(wires_values), arr(sigma_values), arr(k_is), arr(betas), arr(gammas)
+    n = 1 << shape.degree_bits
+    out = np.zeros((shape.num_challenges * (1 + shape.num_partial_products), n), np.uint64)
+    L.or_zs_partial_products(ctypes.byref(shape), ptr(w), ptr(s), ptr(k), ptr(b), ptr(g), ptr(out))
+    return out
