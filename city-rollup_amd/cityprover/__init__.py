@@ -426,3 +426,45 @@ def zs_partial_products_dev(prover, circuits, wires_ptr, betas, gammas, out_ptr)
     cs = (_vp * B)(*[c.handle for c in circuits])
     b, g = _as_u64(betas).reshape(B, -1), _as_u64(gammas).reshape(B, -1)
     prover._check(prover.lib.cp_zs_partial_products_dev(prover.ctx, B, cs, wires_ptr, _ptr(b), _ptr(g), out_ptr))
+
+
+# ---- gates and the whole proof ------------------------------------------------------------------------
+GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC = 0, 1, 2, 3
+
+
+class Gate(ctypes.Structure):
+    """cp_gate"""
+    _fields_ = [(n, ctypes.c_int) for n in ("type", "selector_index", "group_start", "group_end", "param")]
+
+
+ABI["cp_circuit_set_gates"] = (ctypes.c_int, [_vp, ctypes.POINTER(Gate), ctypes.c_size_t, ctypes.c_int])
+ABI["cp_prove_batch"] = (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp), ctypes.POINTER(_u64p),
+                                        ctypes.POINTER(ctypes.c_size_t), _vp, ctypes.POINTER(ctypes.c_int), _u64p,
+                                        ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)),
+                                        ctypes.POINTER(ctypes.c_size_t)])
+
+
+def set_gates(circuit, gate_list, num_selectors):
+    """gate_list: [(type, selector_index, group_start, group_end, param)] in gate-index order."""
+    arr = (Gate * len(gate_list))(*[Gate(*g) for g in gate_list])
+    circuit.prover._check(circuit.prover.lib.cp_circuit_set_gates(circuit.handle, arr, len(gate_list), num_selectors))
+
+
+def prove_batch_dev(prover, circuits, public_inputs, wires_ptr, pow_overrides=None):
+    """wires -> proofs for a batch (A7 + A8 + tail). wires_ptr: device [proof][num_wires][n]."""
+    B = len(circuits)
+    cs = (_vp * B)(*[c.handle for c in circuits])
+    pis = [_as_u64(p) for p in public_inputs]
+    pi_ptrs = (_u64p * B)(*[_ptr(p) if p.size else None for p in pis])
+    n_pis = (ctypes.c_size_t * B)(*[p.size for p in pis])
+    use = (ctypes.c_int * B)(*[0 if (pow_overrides is None or pow_overrides[i] is None) else 1 for i in range(B)])
+    ov = np.array([0 if (pow_overrides is None or pow_overrides[i] is None) else pow_overrides[i] for i in range(B)],
+                  dtype=np.uint64)
+    outs = (ctypes.POINTER(ctypes.c_uint8) * B)()
+    lens = (ctypes.c_size_t * B)()
+    prover._check(prover.lib.cp_prove_batch(prover.ctx, B, cs, pi_ptrs, n_pis, wires_ptr, use, _ptr(ov), outs, lens))
+    res = []
+    for i in range(B):
+        res.append(ctypes.string_at(outs[i], lens[i]))
+        prover.lib.cp_free(outs[i])
+    return res

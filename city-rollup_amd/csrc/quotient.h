@@ -1,0 +1,155 @@
+// A8: quotient / constraint batch evaluation — plonky2
+// `compute_quotient_polys` + `eval_vanishing_poly_base_batch` (un-vendored dependency). For every point
+// x = 7*omega_N^i of the LDE coset and every challenge c:
+//     t_c(x) = ( sum_t alpha_c^t * term_t(x) ) / Z_H(x)
+// with the terms in plonky2's order: L_0(x)(Z_c'(x)-1) for every challenge c', then the partial-product
+// checks of every challenge, then the gate constraints (filtered by the selector polynomials and summed
+// per constraint index over all gates).
+//
+// One lane per LDE point, in STORAGE order (bit-reversed), so that all ~240 column reads per point are
+// coalesced across the wave; the two results per point are written to their natural position (the
+// inverse transform wants natural order) — a scattered 8-byte store per challenge into an L2-resident
+// 256 KB column. The kernel is HBM/L2-streaming bound by design: ~1.9 KB read per point, ~1.2 K modular
+// multiplications (permutation argument) + the gate set.
+//
+// Parity: unpinned by reference data (see oracle/plonky2_quotient.c); bit-exact against that oracle,
+// whose verifier side checks the vanishing identity at zeta.
+#pragma once
+#include "gl.h"
+
+namespace quot {
+
+constexpr int MAXC = 4;        // num_challenges supported by the kernel
+constexpr int MAX_GATES = 32;
+constexpr uint64_t UNUSED_SELECTOR = 0xFFFFFFFFull;  // u32::MAX
+
+enum { GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3 };
+
+struct Gate { int type, selector_index, group_start, group_end, param; };
+
+struct Args {
+  const uint64_t *const *cs_lde;  // per proof: (num_constants + R) x N, bit-reversed
+  const uint64_t *wires_lde;      // [proof][W][N]
+  size_t wires_stride;
+  const uint64_t *zs_lde;         // [proof][nc*(1+npp)][N]
+  size_t zs_stride;
+  const uint64_t *k_is;           // [R]
+  const uint64_t *chal;           // [proof][2][nc]: betas, gammas
+  const uint64_t *apow;           // [proof][nc][n_terms]: alpha_c^t
+  const uint64_t *pi_hash;        // [proof][4]
+  const uint64_t *zh;             // [2^rb]  Z_H on the coset, and
+  const uint64_t *zh_inv;         // [2^rb]  its inverses
+  const uint64_t *omega_tab;      // power table of omega_N
+  uint64_t *out;                  // [proof][nc][N], NATURAL index order
+  size_t out_stride;
+  uint64_t n_field;               // n as a field element
+  size_t N;
+  int log_N, rb;
+  int ncst, R, W, nc, npp, chunk, n_gates, num_selectors, n_terms;
+  Gate gates[MAX_GATES];
+};
+
+__device__ __forceinline__ uint64_t pow_tab(const uint64_t *T, uint64_t e) {
+  uint32_t e0 = (uint32_t)e & 2047, e1 = (uint32_t)(e >> 11) & 2047, e2 = (uint32_t)(e >> 22);
+  uint64_t r = T[e0];
+  if (e1) r = gl::mul(r, T[2048 + e1]);
+  if (e2) r = gl::mul(r, T[4096 + e2]);
+  return r;
+}
+
+__device__ __forceinline__ int gate_num_constraints(const Gate &g) {
+  switch (g.type) {
+    case GATE_CONSTANT: return g.param;
+    case GATE_PUBLIC_INPUT: return 4;
+    case GATE_ARITHMETIC: return g.param;
+    default: return 0;
+  }
+}
+
+// grid = (N/256, B)
+__global__ __launch_bounds__(256) void k_quotient(Args a) {
+  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;  // storage (bit-reversed) position
+  if (s >= a.N) return;
+  const size_t proof = blockIdx.y;
+  const uint32_t i = __brev((uint32_t)s) >> (32 - a.log_N);  // natural index
+  const size_t N = a.N;
+  const uint64_t *cs = a.cs_lde[proof] + s;
+  const uint64_t *w = a.wires_lde + proof * a.wires_stride + s;
+  const uint64_t *zsb = a.zs_lde + proof * a.zs_stride;
+  const uint32_t i_next = (i + (1u << a.rb)) & (uint32_t)(N - 1);
+  const size_t s_next = __brev(i_next) >> (32 - a.log_N);
+  const uint64_t *betas = a.chal + proof * 2 * a.nc, *gammas = betas + a.nc;
+  const uint64_t *apow = a.apow + proof * (size_t)a.nc * a.n_terms;
+  const int nc = a.nc;
+
+  const uint64_t x = gl::mul(7, pow_tab(a.omega_tab, i));
+  const uint64_t zh = a.zh[i & ((1u << a.rb) - 1)], zh_inv = a.zh_inv[i & ((1u << a.rb) - 1)];
+  const uint64_t l0 = gl::mul(zh, gl::inv(gl::mul(a.n_field, gl::sub(x, 1))));
+
+  uint64_t acc[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; c++) acc[c] = 0;
+  int t = 0;
+  auto add_term = [&](uint64_t term, int idx) {
+#pragma unroll
+    for (int c = 0; c < MAXC; c++)
+      if (c < nc) acc[c] = gl::add(acc[c], gl::mul(term, apow[(size_t)c * a.n_terms + idx]));
+  };
+  // L_0(x) (Z(x) - 1)
+  for (int c = 0; c < nc; c++) add_term(gl::mul(l0, gl::sub(zsb[(size_t)c * N + s], 1)), t++);
+  // partial-product checks: prev * prod(num chunk) - next * prod(den chunk)
+  for (int c = 0; c < nc; c++) {
+    const uint64_t beta = betas[c], gamma = gammas[c];
+    const uint64_t bx = gl::mul(beta, x);
+    uint64_t prev = zsb[(size_t)c * N + s];
+    for (int k = 0; k <= a.npp; k++) {
+      uint64_t next = k == a.npp ? zsb[(size_t)c * N + s_next] : zsb[((size_t)nc + (size_t)c * a.npp + k) * N + s];
+      uint64_t pn = 1, pd = 1;
+      for (int j = k * a.chunk; j < a.R && j < (k + 1) * a.chunk; j++) {
+        uint64_t base = gl::add(w[(size_t)j * N], gamma);
+        pn = gl::mul(pn, gl::add(base, gl::mul(bx, a.k_is[j])));
+        pd = gl::mul(pd, gl::add(base, gl::mul(beta, cs[(size_t)(a.ncst + j) * N])));
+      }
+      add_term(gl::sub(gl::mul(prev, pn), gl::mul(next, pd)), t++);
+      prev = next;
+    }
+  }
+  // gate constraints: filter * unfiltered, summed per constraint index over the gates
+  const uint64_t *pih = a.pi_hash + proof * 4;
+  for (int gi = 0; gi < a.n_gates; gi++) {
+    const Gate g = a.gates[gi];
+    const int ncon = gate_num_constraints(g);
+    if (ncon == 0) continue;
+    const uint64_t sv = cs[(size_t)g.selector_index * N];
+    uint64_t f = 1;
+    for (int r = g.group_start; r < g.group_end; r++)
+      if (r != gi) f = gl::mul(f, gl::sub((uint64_t)r, sv));
+    if (a.num_selectors > 1) f = gl::mul(f, gl::sub(UNUSED_SELECTOR, sv));
+    const uint64_t *consts = cs + (size_t)a.num_selectors * N;
+    switch (g.type) {
+      case GATE_CONSTANT:
+        for (int k = 0; k < g.param; k++) add_term(gl::mul(f, gl::sub(consts[(size_t)k * N], w[(size_t)k * N])), t + k);
+        break;
+      case GATE_PUBLIC_INPUT:
+        for (int k = 0; k < 4; k++) add_term(gl::mul(f, gl::sub(w[(size_t)k * N], pih[k])), t + k);
+        break;
+      case GATE_ARITHMETIC: {
+        const uint64_t c0 = consts[0], c1 = consts[N];
+        for (int k = 0; k < g.param; k++) {
+          uint64_t m0 = w[(size_t)(4 * k) * N], m1 = w[(size_t)(4 * k + 1) * N], ad = w[(size_t)(4 * k + 2) * N],
+                   o = w[(size_t)(4 * k + 3) * N];
+          uint64_t computed = gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1));
+          add_term(gl::mul(f, gl::sub(o, computed)), t + k);
+        }
+        break;
+      }
+      default: break;
+    }
+  }
+  uint64_t *out = a.out + proof * a.out_stride + i;
+#pragma unroll
+  for (int c = 0; c < MAXC; c++)
+    if (c < nc) out[(size_t)c * N] = gl::mul(acc[c], zh_inv);
+}
+
+}  // namespace quot

@@ -214,6 +214,29 @@ int cp_prove_tail_batch(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circuit
                         const uint64_t *wires_values_dev, const uint64_t *zs_pp_values_dev,
                         const uint64_t *quotient_coeffs_dev, const int *use_pow_override,
                         const uint64_t *pow_override, uint8_t **proofs_out, size_t *proof_lens);
+/* ---- gates and the whole proof ---------------------------------------------------------------
+ * A8 needs the circuit's gate set: CommonCircuitData::gates (in order: a gate's index is its
+ * position) with its selector group (SelectorsInfo: selector_indices[gate], groups[selector]).
+ * Supported gate types so far (upstream gates pinned by
+ * city_common_circuit/src/builder/pad_circuit.rs:31-55): Noop, Constant{num_consts}, PublicInput,
+ * Arithmetic{num_ops}. The first num_selectors "constants" columns are the selector polynomials. */
+enum { CP_GATE_NOOP = 0, CP_GATE_CONSTANT = 1, CP_GATE_PUBLIC_INPUT = 2, CP_GATE_ARITHMETIC = 3 };
+typedef struct cp_gate {
+  int type;           /* CP_GATE_* */
+  int selector_index; /* selector polynomial of this gate's group */
+  int group_start, group_end; /* gate indices [start, end) sharing that selector */
+  int param;          /* Constant: num_consts, Arithmetic: num_ops */
+} cp_gate;
+int cp_circuit_set_gates(cp_circuit *circuit, const cp_gate *gates, size_t n_gates, int num_selectors);
+
+/* The whole of `CircuitData::prove` after witness generation (SURVEY.md §8(a) A1 minus A2):
+ * wires -> Z / partial products (A7) -> quotient chunks (A8) -> openings, FRI, proof bytes, for
+ * n_proofs proofs of one shape / gate set. wires_values_dev: [proof][num_wires][n] evaluations.
+ * Witness generation (A2) stays on the CPU upstream of this call. */
+int cp_prove_batch(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circuits,
+                   const uint64_t *const *public_inputs_host, const size_t *n_public_inputs,
+                   const uint64_t *wires_values_dev, const int *use_pow_override,
+                   const uint64_t *pow_override, uint8_t **proofs_out, size_t *proof_lens);
 void cp_free(void *ptr);
 
 #ifdef __cplusplus

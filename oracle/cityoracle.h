@@ -131,6 +131,38 @@ void or_fri_compute_evaluation(uint64_t x, size_t x_index_within_coset, int arit
 uint64_t or_fri_query_point(size_t x_index, int log_n);
 void or_free(void *p);
 
+/* ---- gates / quotient (plonky2_quotient.c) ---- */
+enum { OR_GATE_NOOP = 0, OR_GATE_CONSTANT = 1, OR_GATE_PUBLIC_INPUT = 2, OR_GATE_ARITHMETIC = 3 };
+typedef struct {
+  int type;           /* OR_GATE_* */
+  int selector_index; /* which selector polynomial (constants column) carries this gate's group */
+  int group_start, group_end; /* the gate indices sharing that selector */
+  int param;          /* Constant: num_consts; Arithmetic: num_ops */
+} or_gate;
+typedef struct {
+  int n_gates;
+  or_gate gates[32];  /* in CommonCircuitData::gates order: the gate's index is its position */
+  int num_selectors;  /* the first num_selectors "constants" columns are selector polynomials */
+  uint64_t k_is[256]; /* num_routed_wires coset shifts */
+} or_gates;
+int or_gates_num_constraints(const or_gates *g);
+/* A8: quotient chunk polynomials (coefficients), num_challenges*quotient_degree_factor x n, from the
+ * bit-reversed LDEs of the three oracles. */
+int or_quotient_polys(const or_shape *sh, const or_gates *G, const uint64_t pi_hash[4], const uint64_t *cs_lde,
+                      const uint64_t *wires_lde, const uint64_t *zs_lde, const uint64_t *betas,
+                      const uint64_t *gammas, const uint64_t *alphas, uint64_t *out_coeffs);
+/* verifier: Z_H(zeta) * sum_i zeta^(n i) t_i(zeta) == vanishing(zeta) from the openings. 0 = holds. */
+int or_check_vanishing(const or_shape *sh, const or_gates *G, const uint64_t pi_hash[4], const uint64_t zeta[2],
+                       const uint64_t *op_constants, const uint64_t *op_sigmas, const uint64_t *op_wires,
+                       const uint64_t *op_zs, const uint64_t *op_zs_next, const uint64_t *op_pps,
+                       const uint64_t *op_quotient, const uint64_t *betas, const uint64_t *gammas,
+                       const uint64_t *alphas);
+/* wires -> proof (A7 + A8 + tail) */
+int or_prove_full(const or_shape *sh, const or_gates *G, const uint64_t circuit_digest[4],
+                  const uint64_t *public_inputs, size_t n_pi, const uint64_t *cs_values,
+                  const uint64_t *wires_values, int use_pow_override, uint64_t pow_override,
+                  uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg);
+
 /* A7: Z and partial-product polynomials of the permutation argument (values over <omega_n>).
  * wires_values: num_wires x n (only the routed ones are read); sigma_values: num_routed_wires x n;
  * out: num_challenges*(1+num_partial_products) x n in committed order (Z's first). */

@@ -1,0 +1,201 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY (see goldilocks.h).
+ *
+ * A8: the quotient polynomials and the verifier-side vanishing
+ * check, restated from plonky2 0.2.2 `compute_quotient_polys` / `eval_vanishing_poly{,_base_batch}` /
+ * `check_partial_products` / `compute_filter` (un-vendored dependency, QEDProtocol/plonky2-hwa @
+ * 6a8ca008). PARITY UNPINNED by the reference tree: no fixture under /root/reference carries verifier
+ * data for a proof, so nothing there can check a quotient value; this file is validated by its own
+ * verifier side (the openings of a proof must satisfy Z_H(zeta) * sum zeta^(n i) t_i(zeta) == vanishing(zeta)),
+ * which is an independent formula path, and the GPU path is compared bit for bit with this file.
+ *
+ * Gate set restated here (constraint formulas of the upstream gates named in
+ * city_common_circuit/src/builder/pad_circuit.rs:31-55): Noop, Constant, PublicInput, Arithmetic.
+ */
+#include "cityoracle.h"
+#include "goldilocks.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define UNUSED_SELECTOR 0xFFFFFFFFULL /* u32::MAX */
+
+typedef struct {
+  const or_shape *sh;
+  const or_gates *g;
+  gl2_t pi_hash[4];
+} vctx_t;
+
+static int gate_num_constraints(const or_gate *g) {
+  switch (g->type) {
+    case OR_GATE_NOOP: return 0;
+    case OR_GATE_CONSTANT: return g->param;
+    case OR_GATE_PUBLIC_INPUT: return 4;
+    case OR_GATE_ARITHMETIC: return g->param;
+    default: return -1;
+  }
+}
+
+int or_gates_num_constraints(const or_gates *g) {
+  int m = 0;
+  for (int i = 0; i < g->n_gates; i++) {
+    int c = gate_num_constraints(&g->gates[i]);
+    if (c < 0) return -1;
+    if (c > m) m = c;
+  }
+  return m;
+}
+
+/* unfiltered constraints of one gate; consts = local constants AFTER the selector prefix */
+static void gate_eval(const or_gate *g, const gl2_t *consts, const gl2_t *wires, const gl2_t *pi_hash, gl2_t *out) {
+  switch (g->type) {
+    case OR_GATE_CONSTANT:
+      for (int i = 0; i < g->param; i++) out[i] = gl2_sub(consts[i], wires[i]);
+      break;
+    case OR_GATE_PUBLIC_INPUT:
+      for (int i = 0; i < 4; i++) out[i] = gl2_sub(wires[i], pi_hash[i]);
+      break;
+    case OR_GATE_ARITHMETIC:
+      for (int i = 0; i < g->param; i++) {
+        gl2_t m0 = wires[4 * i], m1 = wires[4 * i + 1], addend = wires[4 * i + 2], output = wires[4 * i + 3];
+        gl2_t computed = gl2_add(gl2_mul(gl2_mul(m0, m1), consts[0]), gl2_mul(addend, consts[1]));
+        out[i] = gl2_sub(output, computed);
+      }
+      break;
+    default: break;
+  }
+}
+
+/* filter of gate `row` inside its selector group: prod_{i in group, i != row} (i - s) [* (UNUSED - s)] */
+static gl2_t gate_filter(int row, const or_gate *g, gl2_t s, int many_selectors) {
+  gl2_t f = gl2_from_base(1);
+  for (int i = g->group_start; i < g->group_end; i++)
+    if (i != row) f = gl2_mul(f, gl2_sub(gl2_from_base((uint64_t)i), s));
+  if (many_selectors) f = gl2_mul(f, gl2_sub(gl2_from_base(UNUSED_SELECTOR), s));
+  return f;
+}
+
+/* vanishing(x) for every challenge, at one point. All inputs in F_p^2 (the prover embeds base values).
+ * consts: all num_constants "constants" openings (selectors first); l0 = L_0(x); x = the point itself. */
+static void eval_vanishing(const vctx_t *v, gl2_t x, gl2_t l0, const gl2_t *consts, const gl2_t *wires,
+                           const gl2_t *zs, const gl2_t *zs_next, const gl2_t *pps, const gl2_t *sigmas,
+                           const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas, gl2_t *out) {
+  const or_shape *sh = v->sh;
+  const or_gates *G = v->g;
+  const int nc = sh->num_challenges, R = sh->num_routed_wires, chunk = sh->quotient_degree_factor,
+            npp = sh->num_partial_products, ngc = or_gates_num_constraints(G);
+  int n_terms = nc + nc * (npp + 1) + ngc;
+  gl2_t *terms = (gl2_t *)calloc((size_t)n_terms, sizeof(gl2_t));
+  int t = 0;
+  /* L_0(x) (Z(x) - 1) */
+  for (int c = 0; c < nc; c++) terms[t++] = gl2_mul(l0, gl2_sub(zs[c], gl2_from_base(1)));
+  /* partial-product checks */
+  for (int c = 0; c < nc; c++) {
+    for (int k = 0; k <= npp; k++) {
+      gl2_t prev = k == 0 ? zs[c] : pps[c * npp + k - 1];
+      gl2_t next = k == npp ? zs_next[c] : pps[c * npp + k];
+      gl2_t pn = gl2_from_base(1), pd = gl2_from_base(1);
+      for (int j = k * chunk; j < R && j < (k + 1) * chunk; j++) {
+        gl2_t sid = gl2_scale(x, G->k_is[j]);
+        gl2_t num = gl2_add(gl2_add(wires[j], gl2_scale(sid, betas[c])), gl2_from_base(gammas[c]));
+        gl2_t den = gl2_add(gl2_add(wires[j], gl2_scale(sigmas[j], betas[c])), gl2_from_base(gammas[c]));
+        pn = gl2_mul(pn, num);
+        pd = gl2_mul(pd, den);
+      }
+      terms[t++] = gl2_sub(gl2_mul(prev, pn), gl2_mul(next, pd));
+    }
+  }
+  /* gate constraints: filtered, summed per constraint index */
+  gl2_t tmp[256];
+  for (int gi = 0; gi < G->n_gates; gi++) {
+    const or_gate *g = &G->gates[gi];
+    int c = gate_num_constraints(g);
+    if (c <= 0) continue;
+    gl2_t f = gate_filter(gi, g, consts[g->selector_index], G->num_selectors > 1);
+    gate_eval(g, consts + G->num_selectors, wires, v->pi_hash, tmp);
+    for (int i = 0; i < c; i++) terms[t + i] = gl2_add(terms[t + i], gl2_mul(tmp[i], f));
+  }
+  /* reduce_with_powers_multi: sum_i alpha^i term_i */
+  for (int c = 0; c < nc; c++) {
+    gl2_t acc = gl2_from_base(0);
+    for (int i = n_terms - 1; i >= 0; i--) acc = gl2_add(gl2_scale(acc, alphas[c]), terms[i]);
+    out[c] = acc;
+  }
+  free(terms);
+}
+
+static size_t bitrev_sz(size_t x, int bits) { size_t r = 0; for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i); return r; }
+
+/* Quotient chunk polynomials (coefficients), num_challenges*quotient_degree_factor x n.
+ * cs_lde / wires_lde / zs_lde: bit-reversed LDEs on 7*<omega_N>, poly-major (as or_commit_batch returns). */
+int or_quotient_polys(const or_shape *sh, const or_gates *G, const uint64_t pi_hash[4], const uint64_t *cs_lde,
+                      const uint64_t *wires_lde, const uint64_t *zs_lde, const uint64_t *betas,
+                      const uint64_t *gammas, const uint64_t *alphas, uint64_t *out_coeffs) {
+  const int db = sh->degree_bits, rb = sh->rate_bits, nc = sh->num_challenges;
+  if ((1 << rb) != sh->quotient_degree_factor) return -1; /* step = 1 only (the configuration in use) */
+  if (or_gates_num_constraints(G) < 0) return -2;
+  const size_t n = (size_t)1 << db, N = n << rb;
+  const int R = sh->num_routed_wires, ncst = sh->num_constants, W = sh->num_wires, npp = sh->num_partial_products;
+  vctx_t v = {sh, G, {{{pi_hash[0], 0}}, {{pi_hash[1], 0}}, {{pi_hash[2], 0}}, {{pi_hash[3], 0}}}};
+  /* Z_H on the coset takes 2^rb values: g^n * w^i - 1, w = omega_{2^rb} */
+  uint64_t gpn = gl_pow(GL_GENERATOR, n), w8 = gl_root_of_unity(rb), zh_inv[64], zh[64];
+  for (int i = 0; i < (1 << rb); i++) { zh[i] = gl_sub(gl_mul(gpn, gl_pow(w8, i)), 1); zh_inv[i] = gl_inv(zh[i]); }
+  uint64_t omegaN = gl_root_of_unity(db + rb);
+  uint64_t *vals = (uint64_t *)malloc((size_t)nc * N * 8); /* natural order */
+  gl2_t *consts = (gl2_t *)malloc((size_t)(ncst + W + R + 4 * nc + nc * npp) * sizeof(gl2_t));
+  gl2_t *wires = consts + ncst, *sig = wires + W, *zs = sig + R, *zsn = zs + nc, *pps = zsn + nc;
+  uint64_t x = GL_GENERATOR; /* coset point of natural index i */
+  for (size_t i = 0; i < N; i++) {
+    size_t s = bitrev_sz(i, db + rb), sn = bitrev_sz((i + ((size_t)1 << rb)) % N, db + rb);
+    for (int j = 0; j < ncst; j++) consts[j] = gl2_from_base(cs_lde[(size_t)j * N + s]);
+    for (int j = 0; j < R; j++) sig[j] = gl2_from_base(cs_lde[(size_t)(ncst + j) * N + s]);
+    for (int j = 0; j < W; j++) wires[j] = gl2_from_base(wires_lde[(size_t)j * N + s]);
+    for (int c = 0; c < nc; c++) { zs[c] = gl2_from_base(zs_lde[(size_t)c * N + s]); zsn[c] = gl2_from_base(zs_lde[(size_t)c * N + sn]); }
+    for (int j = 0; j < nc * npp; j++) pps[j] = gl2_from_base(zs_lde[(size_t)(nc + j) * N + s]);
+    /* L_0(x) = Z_H(x) / (n (x - 1)) */
+    uint64_t l0 = gl_mul(zh[i & ((1 << rb) - 1)], gl_inv(gl_mul((uint64_t)n, gl_sub(x, 1))));
+    gl2_t res[8];
+    eval_vanishing(&v, gl2_from_base(x), gl2_from_base(l0), consts, wires, zs, zsn, pps, sig, betas, gammas, alphas, res);
+    for (int c = 0; c < nc; c++) vals[(size_t)c * N + i] = gl_mul(res[c].c[0], zh_inv[i & ((1 << rb) - 1)]);
+    x = gl_mul(x, omegaN);
+  }
+  /* coset iFFT: values on 7*<omega_N> -> coefficients; chunk j of challenge c = coeffs[j*n .. (j+1)*n) */
+  uint64_t ginv = gl_inv(GL_GENERATOR);
+  for (int c = 0; c < nc; c++) {
+    uint64_t *p = vals + (size_t)c * N;
+    or_intt(p, db + rb);
+    uint64_t sp = 1;
+    for (size_t i = 0; i < N; i++) { p[i] = gl_mul(p[i], sp); sp = gl_mul(sp, ginv); }
+    memcpy(out_coeffs + (size_t)c * N, p, N * 8);
+  }
+  free(vals); free(consts);
+  return 0;
+}
+
+/* Verifier side: with the openings of a proof and the challenges, check
+ *   Z_H(zeta) * sum_i zeta^(n i) t_{c,i}(zeta) == vanishing_c(zeta)   for every challenge c.
+ * openings (ext, 2 u64 each): constants[num_constants], sigmas[R], wires[W], zs[nc], zs_next[nc],
+ * partial_products[nc*npp], quotient[nc*qdf]. Returns 0 when the identity holds. */
+int or_check_vanishing(const or_shape *sh, const or_gates *G, const uint64_t pi_hash[4], const uint64_t zeta[2],
+                       const uint64_t *op_constants, const uint64_t *op_sigmas, const uint64_t *op_wires,
+                       const uint64_t *op_zs, const uint64_t *op_zs_next, const uint64_t *op_pps,
+                       const uint64_t *op_quotient, const uint64_t *betas, const uint64_t *gammas,
+                       const uint64_t *alphas) {
+  const int nc = sh->num_challenges, qdf = sh->quotient_degree_factor;
+  const size_t n = (size_t)1 << sh->degree_bits;
+  vctx_t v = {sh, G, {{{pi_hash[0], 0}}, {{pi_hash[1], 0}}, {{pi_hash[2], 0}}, {{pi_hash[3], 0}}}};
+  gl2_t z = gl2_make(zeta[0], zeta[1]);
+  gl2_t zn = gl2_pow(z, n);
+  gl2_t zh = gl2_sub(zn, gl2_from_base(1));
+  gl2_t l0 = gl2_mul(zh, gl2_inv(gl2_scale(gl2_sub(z, gl2_from_base(1)), (uint64_t)n)));
+  gl2_t res[8];
+  eval_vanishing(&v, z, l0, (const gl2_t *)op_constants, (const gl2_t *)op_wires, (const gl2_t *)op_zs,
+                 (const gl2_t *)op_zs_next, (const gl2_t *)op_pps, (const gl2_t *)op_sigmas, betas, gammas, alphas, res);
+  for (int c = 0; c < nc; c++) {
+    gl2_t acc = gl2_from_base(0);
+    for (int i = qdf - 1; i >= 0; i--)
+      acc = gl2_add(gl2_mul(acc, zn), gl2_make(op_quotient[2 * (c * qdf + i)], op_quotient[2 * (c * qdf + i) + 1]));
+    if (!gl2_eq(gl2_mul(acc, zh), res[c])) return -(c + 1);
+  }
+  return 0;
+}

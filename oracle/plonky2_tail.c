@@ -147,10 +147,33 @@ typedef struct {
   size_t n_leaves[8];
 } fri_trees_t;
 
+static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circuit_digest[4], const uint64_t *public_inputs, size_t n_pi,
+                      const uint64_t *cs_values, const uint64_t *wires_values, const uint64_t *zs_pp_values,
+                      const uint64_t *quotient_coeffs, int use_pow_override, uint64_t pow_override,
+                      uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg);
+
 int or_prove_tail(const or_shape *sh, const uint64_t circuit_digest[4], const uint64_t *public_inputs, size_t n_pi,
                   const uint64_t *cs_values, const uint64_t *wires_values, const uint64_t *zs_pp_values,
                   const uint64_t *quotient_coeffs, int use_pow_override, uint64_t pow_override,
                   uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg) {
+  return prove_impl(sh, NULL, circuit_digest, public_inputs, n_pi, cs_values, wires_values, zs_pp_values, quotient_coeffs,
+                    use_pow_override, pow_override, proof_out, proof_len, dbg);
+}
+
+/* The whole of CircuitData::prove after witness generation: wires -> proof. Z / partial products (A7)
+ * and the quotient chunks (A8) are computed here from the transcript challenges and the gate set G. */
+int or_prove_full(const or_shape *sh, const or_gates *G, const uint64_t circuit_digest[4], const uint64_t *public_inputs,
+                  size_t n_pi, const uint64_t *cs_values, const uint64_t *wires_values, int use_pow_override,
+                  uint64_t pow_override, uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg) {
+  if (!G) return -100;
+  return prove_impl(sh, G, circuit_digest, public_inputs, n_pi, cs_values, wires_values, NULL, NULL, use_pow_override,
+                    pow_override, proof_out, proof_len, dbg);
+}
+
+static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circuit_digest[4], const uint64_t *public_inputs, size_t n_pi,
+                      const uint64_t *cs_values, const uint64_t *wires_values, const uint64_t *zs_pp_values,
+                      const uint64_t *quotient_coeffs, int use_pow_override, uint64_t pow_override,
+                      uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg) {
   const int db = sh->degree_bits, rb = sh->rate_bits, ch = sh->cap_height;
   const size_t n = (size_t)1 << db, N = n << rb;
   const size_t k_cs = sh->num_constants + sh->num_routed_wires, k_w = sh->num_wires;
@@ -172,10 +195,24 @@ int or_prove_tail(const or_shape *sh, const uint64_t circuit_digest[4], const ui
   uint64_t betas[8], gammas[8], alphas[8];
   for (int i = 0; i < sh->num_challenges; i++) betas[i] = or_ch_challenge(&c);
   for (int i = 0; i < sh->num_challenges; i++) gammas[i] = or_ch_challenge(&c);
+  uint64_t *own_zs = NULL, *own_q = NULL;
+  if (G) { /* A7 */
+    own_zs = (uint64_t *)malloc(k_z * n * 8);
+    or_zs_partial_products(sh, wires_values, cs_values + (size_t)sh->num_constants * n, G->k_is, betas, gammas, own_zs);
+    zs_pp_values = own_zs;
+  }
   batch_from_values(&B[2], zs_pp_values, k_z, db, rb, ch);
   or_ch_observe(&c, B[2].cap, cap_n * 4);
   for (int i = 0; i < sh->num_challenges; i++) alphas[i] = or_ch_challenge(&c);
+  if (G) { /* A8 */
+    own_q = (uint64_t *)malloc(k_q * n * 8);
+    int qrc = or_quotient_polys(sh, G, pi_hash, B[0].lde, B[1].lde, B[2].lde, betas, gammas, alphas, own_q);
+    if (qrc) return -200 + qrc;
+    quotient_coeffs = own_q;
+  }
   batch_from_coeffs(&B[3], quotient_coeffs, k_q, db, rb, ch);
+  free(own_zs);
+  free(own_q);
   or_ch_observe(&c, B[3].cap, cap_n * 4);
   gl2_t zeta = ch_ext(&c);
   uint64_t g = gl_root_of_unity(db);
@@ -424,9 +461,12 @@ int or_verify_tail(const or_shape *sh, const uint64_t circuit_digest[4], const u
   uint64_t pi_hash[4]; or_hash_no_pad(pi, n_pi, pi_hash);
   or_challenger c; or_ch_init(&c);
   or_ch_observe(&c, circuit_digest, 4); or_ch_observe(&c, pi_hash, 4); or_ch_observe(&c, caps[1], cap_n * 4);
-  for (int i = 0; i < 2 * sh->num_challenges; i++) (void)or_ch_challenge(&c);
+  uint64_t vb[8], vg[8], va[8];
+  for (int i = 0; i < sh->num_challenges; i++) vb[i] = or_ch_challenge(&c);
+  for (int i = 0; i < sh->num_challenges; i++) vg[i] = or_ch_challenge(&c);
   or_ch_observe(&c, caps[2], cap_n * 4);
-  for (int i = 0; i < sh->num_challenges; i++) (void)or_ch_challenge(&c);
+  for (int i = 0; i < sh->num_challenges; i++) va[i] = or_ch_challenge(&c);
+  if (dbg) { memcpy(dbg->betas, vb, sizeof vb); memcpy(dbg->gammas, vg, sizeof vg); memcpy(dbg->alphas, va, sizeof va); }
   or_ch_observe(&c, caps[3], cap_n * 4);
   gl2_t zeta = ch_ext(&c);
   gl2_t zeta_next = gl2_scale(zeta, gl_root_of_unity(db));

@@ -22,7 +22,7 @@ def lib():
     if _lib is not None:
         return _lib
     so = os.path.join(ORACLE_DIR, "libcityoracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("cityoracle.c", "plonky2_tail.c", "cityoracle.h", "goldilocks.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("cityoracle.c", "plonky2_tail.c", "plonky2_quotient.c", "cityoracle.h", "goldilocks.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         build()
     L = ctypes.CDLL(so)
@@ -265,3 +265,65 @@ def zs_partial_products(shape, wires_values, sigma_values, k_is, betas, gammas):
     out = np.zeros((shape.num_challenges * (1 + shape.num_partial_products), n), np.uint64)
     L.or_zs_partial_products(ctypes.byref(shape), ptr(w), ptr(s), ptr(k), ptr(b), ptr(g), ptr(out))
     return out
+
+
+# ---- gates / quotient / full prover ---------------------------------------------------------------
+GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC = 0, 1, 2, 3
+
+
+class Gate(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("type", "selector_index", "group_start", "group_end", "param")]
+
+
+class Gates(ctypes.Structure):
+    _fields_ = [("n_gates", ctypes.c_int), ("gates", Gate * 32), ("num_selectors", ctypes.c_int),
+                ("k_is", ctypes.c_uint64 * 256)]
+
+
+def make_gates(gate_list, num_selectors, k_is):
+    """gate_list: [(type, selector_index, group_start, group_end, param)] in gate-index order."""
+    g = Gates()
+    g.n_gates = len(gate_list)
+    for i, t in enumerate(gate_list):
+        g.gates[i] = Gate(*t)
+    g.num_selectors = num_selectors
+    for i, k in enumerate(k_is):
+        g.k_is[i] = k
+    return g
+
+
+def prove_full(shape, gates, circuit_digest, public_inputs, cs_values, wires_values, pow_override=None):
+    L = lib()
+    L.or_prove_full.restype = ctypes.c_int
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    ln = ctypes.c_size_t()
+    dbg = TailDebug()
+    cd, pi, a, b = arr(circuit_digest), arr(public_inputs), arr(cs_values), arr(wires_values)
+    rc = L.or_prove_full(ctypes.byref(shape), ctypes.byref(gates), ptr(cd), ptr(pi), ctypes.c_size_t(pi.size), ptr(a),
+                         ptr(b), ctypes.c_int(0 if pow_override is None else 1), ctypes.c_uint64(pow_override or 0),
+                         ctypes.byref(out), ctypes.byref(ln), ctypes.byref(dbg))
+    assert rc == 0, rc
+    data = ctypes.string_at(out, ln.value)
+    L.or_free(out)
+    return data, dbg
+
+
+def verify_full(shape, gates, circuit_digest, cs_cap, proof_bytes):
+    """FRI / transcript / Merkle checks (verify_tail) + the vanishing identity at zeta from the openings."""
+    from proof_format import parse_proof
+    rc, dbg = verify_tail(shape, circuit_digest, cs_cap, proof_bytes)
+    if rc != 0:
+        return rc
+    p = parse_proof(proof_bytes)
+    o = p["openings"]
+    flat = lambda k: arr([c for e in o[k] for c in e])
+    pi_hash = hash_no_pad(arr(p["public_inputs"]))
+    nc = shape.num_challenges
+    L = lib()
+    L.or_check_vanishing.restype = ctypes.c_int
+    rc = L.or_check_vanishing(ctypes.byref(shape), ctypes.byref(gates), ptr(pi_hash), ptr(arr(list(dbg.zeta))),
+                              ptr(flat("constants")), ptr(flat("plonk_sigmas")), ptr(flat("wires")),
+                              ptr(flat("plonk_zs")), ptr(flat("plonk_zs_next")), ptr(flat("partial_products")),
+                              ptr(flat("quotient_polys")), ptr(arr(list(dbg.betas)[:nc])),
+                              ptr(arr(list(dbg.gammas)[:nc])), ptr(arr(list(dbg.alphas)[:nc])))
+    return 0 if rc == 0 else -1000 + rc

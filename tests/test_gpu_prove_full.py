@@ -1,0 +1,67 @@
+"""GPU whole-proof parity (A7 + A8 + tail): wires -> ProofWithPublicInputs bytes must equal the oracle's,
+and the oracle's verifier (FRI + vanishing identity) must accept them."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from synth_circuit import build
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def prover():
+    import cityprover
+    p = cityprover.Prover(0)
+    yield p
+    p.close()
+
+
+def cp_shape_of(cp, s):
+    return cp.standard_recursion_shape(degree_bits=s.degree_bits, num_constants=s.num_constants,
+                                       num_routed_wires=s.num_routed_wires, num_wires=s.num_wires,
+                                       num_challenges=s.num_challenges, num_partial_products=s.num_partial_products,
+                                       quotient_degree_factor=s.quotient_degree_factor, rate_bits=s.rate_bits,
+                                       cap_height=s.cap_height, pow_bits=s.pow_bits,
+                                       num_query_rounds=s.num_query_rounds,
+                                       arity_bits=tuple(s.arity_bits[i] for i in range(s.n_arity)))
+
+
+@pytest.mark.parametrize("db,R,W,arity,B", [(5, 16, 20, (2,), 2), (8, 24, 30, (2, 2), 3), (12, 80, 135, (4, 4), 2)])
+def test_full_proofs_byte_identical(prover, db, R, W, arity, B):
+    import cityprover as cp
+    kw = dict(cap_height=4, pow_bits=16, num_query_rounds=28) if db == 12 else {}
+    cases = [build(db=db, num_routed=R, num_wires=W, chunk=8, rate_bits=3, arity_bits=arity, seed=100 + i, **kw)
+             for i in range(B)]
+    sh = cp_shape_of(cp, cases[0]["shape"])
+    circs = []
+    for i, c in enumerate(cases):
+        circ = cp.Circuit(prover, sh, [i, 2, 3, 4], c["cs_values"])
+        cp.set_gates(circ, c["gate_list"], 1)
+        circs.append(circ)
+    dw = prover.to_device(np.stack([c["wires"] for c in cases]))
+    got = cp.prove_batch_dev(prover, circs, [c["public_inputs"] for c in cases], dw.ptr)
+    O.lib().or_set_threads(8)
+    for i, c in enumerate(cases):
+        want, _ = O.prove_full(c["shape"], c["gates"], [i, 2, 3, 4], c["public_inputs"], c["cs_values"], c["wires"])
+        assert got[i] == want, f"proof {i}"
+        assert O.verify_full(c["shape"], c["gates"], [i, 2, 3, 4], circs[i].cs_cap(), got[i]) == 0
+    O.lib().or_set_threads(1)
+    dw.free()
+    for c in circs:
+        c.close()
+
+
+def test_prove_requires_gates_and_supported_types(prover):
+    import cityprover as cp
+    c = build(db=5, num_routed=16, num_wires=20, chunk=8, rate_bits=3, seed=1)
+    sh = cp_shape_of(cp, c["shape"])
+    circ = cp.Circuit(prover, sh, [0] * 4, c["cs_values"])
+    dw = prover.to_device(c["wires"][None])
+    with pytest.raises(cp.CityProverError):
+        cp.prove_batch_dev(prover, [circ], [c["public_inputs"]], dw.ptr)      # no gate set yet
+    with pytest.raises(cp.CityProverError):
+        cp.set_gates(circ, [(99, 0, 0, 1, 0)], 1)                              # unknown gate type
+    cp.set_gates(circ, c["gate_list"], 1)
+    assert len(cp.prove_batch_dev(prover, [circ], [c["public_inputs"]], dw.ptr)[0]) > 0
+    dw.free(); circ.close()
