@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-qbench", action="store_true", help="skip the proofs/s side measurement")
     args = ap.parse_args()
 
     import cityprover as cp
@@ -143,6 +144,26 @@ def main():
     prof = prover.profile_end()
     elapsed = D.max_over_ranks(dist, t1 - t0)
 
+    # Second half of BASELINE.json's metric ("block proofs/sec (qbench)"), reported beside the headline:
+    # whole-proof throughput of cp_prove_batch on synthetic qbench-shaped jobs (every rank proves its own
+    # jobs; 64 plonky2 proofs = one example block). Not part of the timed region above.
+    qb = None
+    if not args.no_qbench:
+        data.free()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import bench_prove
+        barrier()
+        r1 = bench_prove.run(prover, 32, 3)
+        rt = bench_prove.run_threads(3, 32, 3, device=local_rank)
+        pps = D.sum_over_ranks(dist, rt["proofs_per_s_steady"])
+        pps1 = D.sum_over_ranks(dist, r1["proofs_per_s"])
+        qb = {"proofs_per_s": pps, "blocks_per_s": pps / 64.0, "proofs_per_s_single_context": pps1,
+              "batch": 32, "contexts_per_gpu": 3, "proof_bytes": r1["proof_bytes"],
+              "workload": "synthetic standard_recursion_config jobs (n=2^12, 135 wires / 80 routed, 28 queries, 16-bit "
+                          "PoW; gates: Arithmetic/Constant/PublicInput/Noop), wires -> proof bytes, witness generation excluded"}
+        data = None
+
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
         ntts = k * world
@@ -190,9 +211,11 @@ def main():
             "poseidon_perms_per_s": (perms / (leaf_ms * 1e-3)) if leaf_ms else None,
             "merkle_levels_ms": lvl["total_ms"] / args.steps,
             "cpu_baseline": base,
+            "qbench_proofs": qb,
         }
         print(json.dumps(out))
-    data.free()
+    if data is not None:
+        data.free()
     cap.free()
     prover.close()
     if dist is not None:

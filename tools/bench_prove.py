@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""proofs/s of the whole GPU prover (cp_prove_batch: wires -> ProofWithPublicInputs) on synthetic
+qbench-shaped jobs: standard_recursion_config, n = 2^12, 135 wires / 80 routed, 28 queries, 16-bit PoW
+(gate mix: Arithmetic/Constant/PublicInput/Noop — PoseidonGate not built yet).
+One block of the example workload = 64 plonky2 proofs."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "city-rollup_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import cityprover as cp  # noqa: E402
+
+
+def run(prover, B, iters, n_circuits=4, profile=False):
+    from synth_circuit import build
+    cases = [build(db=12, num_routed=80, num_wires=135, chunk=8, rate_bits=3, arity_bits=(4, 4), seed=i, cap_height=4,
+                   pow_bits=16, num_query_rounds=28, n_copies=64) for i in range(n_circuits)]
+    sh = cp.standard_recursion_shape(num_constants=3)  # 1 selector + 2 gate constants in the synthetic circuits
+    circs = []
+    for i, c in enumerate(cases):
+        circ = cp.Circuit(prover, sh, [i, 1, 2, 3], c["cs_values"])
+        cp.set_gates(circ, c["gate_list"], 1)
+        circs.append(circ)
+    pick = [i % n_circuits for i in range(B)]
+    dw = prover.to_device(np.stack([cases[i]["wires"] for i in pick]))
+    pis = [cases[i]["public_inputs"] for i in pick]
+    cs = [circs[i] for i in pick]
+    proofs = cp.prove_batch_dev(prover, cs, pis, dw.ptr)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        proofs = cp.prove_batch_dev(prover, cs, pis, dw.ptr)
+    t1 = time.perf_counter()
+    out = {"B": B, "ms_per_batch": (t1 - t0) * 1e3 / iters, "proofs_per_s": B * iters / (t1 - t0),
+           "blocks_per_s": B * iters / (t1 - t0) / 64.0, "proof_bytes": len(proofs[0])}
+    if profile:
+        prover.profile_begin()
+        cp.prove_batch_dev(prover, cs, pis, dw.ptr)
+        prof = prover.profile_end()
+        out["kernel_ms_per_batch"] = sum(v["total_ms"] for v in prof.values())
+        out["kernels_ms"] = {k: round(v["total_ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+    dw.free()
+    for c in circs:
+        c.close()
+    return out
+
+
+def run_threads(T, B, iters, device=0):
+    """T host threads, each with its own context (stream): host transcript work of one batch overlaps the
+    kernels of the others."""
+    import threading
+    res = [None] * T
+    provers = [cp.Prover(device) for _ in range(T)]
+
+    def work(i):
+        res[i] = run(provers[i], B, iters)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for pr in provers:
+        pr.close()
+    return {"threads": T, "B": B, "proofs_per_s_steady": sum(r["proofs_per_s"] for r in res),
+            "blocks_per_s_steady": sum(r["blocks_per_s"] for r in res)}
+
+
+if __name__ == "__main__":
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    batches = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 16, 64]
+    threads = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else []
+    p = cp.Prover(0)
+    out = [run(p, B, iters, profile=True) for B in batches]
+    p.close()
+    for T in threads:
+        out.append(run_threads(T, 32, iters))
+    print(json.dumps(out))
