@@ -181,9 +181,17 @@ def main():
         # 8*R*k read + 32*R digests written.
         leaf_bytes = 8.0 * n * k + 32.0 * n
         perms = n * ((k + 7) // 8)
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes of this same command,
+        # gfx950-corrected; committed under profiles/): only valid for the default workload shape
+        pmc = {}
+        try:
+            if (k, log_n) == (COLS, LOG_N):
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
+        except (OSError, ValueError, KeyError):
+            pmc = {}
         roof = {"kernel": "leaf_hash_cols", "bound": "hbm",
                 "achieved": leaf_bytes / (leaf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "traffic": None,
+                "traffic": pmc.get("leaf_hash_cols", {}).get("hbm_bytes"), "algorithmic_bytes": leaf_bytes,
                 "note": "integer-VALU bound (Poseidon: no MFMA-shaped work); see roofline_ntt for the "
                         "HBM-bound kernel of this step"}
         roof["frac"] = roof["achieved"] / roof["peak"]
@@ -195,7 +203,11 @@ def main():
                     "achieved": 16.0 * n * k / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
                     "per_pass_GBs": {"cols": pass_bytes / (cols_ms * 1e-3) / 1e9 if cols_ms else None,
                                      "rows": pass_bytes / (rows_ms * 1e-3) / 1e9 if rows_ms else None},
-                    "ms_per_ntt_kernel_only": ntt_ms / k if ntt_ms else None}
+                    "ms_per_ntt_kernel_only": ntt_ms / k if ntt_ms else None,
+                    "traffic": (pmc["ntt16_cols"]["hbm_bytes"] + pmc["ntt16_rows"]["hbm_bytes"]) / k
+                    if "ntt16_cols" in pmc and "ntt16_rows" in pmc else None,
+                    "traffic_note": "HBM bytes per NTT (both passes) from FETCH_SIZE/WRITE_SIZE; equals the bytes the "
+                                    "two-pass structure must move (2 x 16 MiB), i.e. no wasted re-reads"}
         if roof_ntt["achieved"]:
             roof_ntt["frac"] = roof_ntt["achieved"] / HBM_PEAK_GBS
         out = {
