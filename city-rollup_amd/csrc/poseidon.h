@@ -60,28 +60,29 @@ GL_HD uint64_t add_const_lazy(uint64_t a, uint64_t c) {  // c canonical
 
 // ---- MDS layer on one 22-bit limb plane, arithmetic mod 2^32 (exact: true results < 2^31) ----
 // y[r] = sum_i C[i] * s[(i+r) % 12] + 8*s[0]*[r==0],  C = {17,15,41,16,2,28,13,13,39,18,34,20}
-GL_HD void mds_limb(const uint32_t (&s)[W], uint32_t (&y)[W]) {
-  uint32_t a[6], b[6];
+template <typename T>
+GL_HD void mds_limb(const T (&s)[W], T (&y)[W]) {
+  T a[6], b[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     a[i] = s[i] + s[i + 6];
     b[i] = s[i] - s[i + 6];
   }
   // cyclic-6 part: a (*) [15,24,18,17,40,14]  via  (x^3-1)(x^3+1)
-  uint32_t aa0 = a[0] + a[3], aa1 = a[1] + a[4], aa2 = a[2] + a[5];
-  uint32_t ab0 = a[0] - a[3], ab1 = a[1] - a[4], ab2 = a[2] - a[5];
-  uint32_t T16 = (aa0 + aa1 + aa2) << 4;
-  uint32_t E0 = T16 + (aa2 << 4), E1 = T16 + (aa0 << 4), E2 = T16 + (aa1 << 4);
-  uint32_t F0 = (ab2 << 3) - ab0 - (ab1 << 1);
-  uint32_t F1 = 0u - (ab0 << 3) - ab1 - (ab2 << 1);
-  uint32_t F2 = (ab0 << 1) - (ab1 << 3) - ab2;
-  uint32_t pc[6] = {E0 + F0, E1 + F1, E2 + F2, E0 - F0, E1 - F1, E2 - F2};
+  T aa0 = a[0] + a[3], aa1 = a[1] + a[4], aa2 = a[2] + a[5];
+  T ab0 = a[0] - a[3], ab1 = a[1] - a[4], ab2 = a[2] - a[5];
+  T T16 = (aa0 + aa1 + aa2) << 4;
+  T E0 = T16 + (aa2 << 4), E1 = T16 + (aa0 << 4), E2 = T16 + (aa1 << 4);
+  T F0 = (ab2 << 3) - ab0 - (ab1 << 1);
+  T F1 = (T)0 - (ab0 << 3) - ab1 - (ab2 << 1);
+  T F2 = (ab0 << 1) - (ab1 << 3) - ab2;
+  T pc[6] = {E0 + F0, E1 + F1, E2 + F2, E0 - F0, E1 - F1, E2 - F2};
   // negacyclic-6 part: b (*) [2,-4,16,1,-1,-1] mod (x^6+1)
   // V[k] = sum_{i+j=k} b[i]N[j] - sum_{i+j=k+6} b[i]N[j]
-  uint32_t nb[6];
+  T nb[6];
 #pragma unroll
-  for (int i = 0; i < 6; i++) nb[i] = 0u - b[i];
-  uint32_t v[6];
+  for (int i = 0; i < 6; i++) nb[i] = (T)0 - b[i];
+  T v[6];
   // N0=2 (<<1), N1=-4 (<<2, neg), N2=16 (<<4), N3=1, N4=-1, N5=-1
   // k=0: b0N0 - (b1N5 + b2N4 + b3N3 + b4N2 + b5N1)
   v[0] = (b[0] << 1) + b[1] + b[2] + nb[3] + (nb[4] << 4) + (b[5] << 2);
@@ -118,8 +119,38 @@ GL_HD uint64_t recombine(uint32_t y0, uint32_t y1, uint32_t y2, uint64_t c) {
   return r;
 }
 
+// Alternative: two 32-bit planes carried in 64-bit wrap-around arithmetic (true results < 2^41):
+// a third fewer plane evaluations and a cheaper recombination, paid for with 64-bit adds/subs.
+GL_HD void mds_layer_2planes(uint64_t (&s)[W], int next_rc_base) {
+  uint64_t lo[W], hi[W];
+#pragma unroll
+  for (int i = 0; i < W; i++) {
+    lo[i] = (uint32_t)s[i];
+    hi[i] = s[i] >> 32;
+  }
+  uint64_t yl[W], yh[W];
+  mds_limb(lo, yl);
+  mds_limb(hi, yh);
+#pragma unroll
+  for (int i = 0; i < W; i++) {
+    // value = yl + yh * 2^32 + rc  (< 2^74)
+    gl::u128 v = (gl::u128)yl[i] + ((gl::u128)yh[i] << 32) + (next_rc_base >= 0 ? rc(next_rc_base + i) : 0);
+    uint64_t l = (uint64_t)v, h = (uint64_t)(v >> 64);  // h < 2^10
+    gl::u128 r = (gl::u128)l + ((h << 32) - h);          // + h * (2^32 - 1)
+    s[i] = (uint64_t)r + ((0 - (uint64_t)(r >> 64)) & gl::EPS);
+  }
+}
+
+#ifndef POSEIDON_MDS_PLANES
+#define POSEIDON_MDS_PLANES 3
+#endif
+
 // s <- MDS * s + next_rc   (next_rc_base < 0: no constant)
 GL_HD void mds_layer(uint64_t (&s)[W], int next_rc_base) {
+#if POSEIDON_MDS_PLANES == 2
+  mds_layer_2planes(s, next_rc_base);
+  return;
+#endif
   uint32_t l0[W], l1[W], l2[W];
 #pragma unroll
   for (int i = 0; i < W; i++) {
