@@ -468,3 +468,12 @@ def prove_batch_dev(prover, circuits, public_inputs, wires_ptr, pow_overrides=No
         res.append(ctypes.string_at(outs[i], lens[i]))
         prover.lib.cp_free(outs[i])
     return res
+
+
+ABI["cp_verify"] = (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t])
+
+
+def verify(circuit, proof_bytes):
+    """CircuitData::verify. Returns None when the proof is accepted; raises CityProverError naming the
+    first failing check otherwise."""
+    circuit.prover._check(circuit.prover.lib.cp_verify(circuit.handle, proof_bytes, len(proof_bytes)))

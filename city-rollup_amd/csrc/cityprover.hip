@@ -786,3 +786,4 @@ int cp_commit_dev(cp_ctx *ctx, const uint64_t *values, size_t k, int log_n, int 
 #include "zs.h"
 #include "quotient.h"
 #include "prover_tail.inc"
+#include "verify.inc"

@@ -40,7 +40,8 @@ typedef enum cp_status {
   CP_ERR_HIP = -3,
   CP_ERR_OOM = -4,
   CP_ERR_UNSUPPORTED = -5,
-  CP_ERR_INTERNAL = -6
+  CP_ERR_INTERNAL = -6,
+  CP_ERR_VERIFY = -7 /* cp_verify: the proof is well-formed input but does not verify */
 } cp_status;
 
 typedef struct cp_ctx cp_ctx;
@@ -237,6 +238,11 @@ int cp_prove_batch(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circuits,
                    const uint64_t *const *public_inputs_host, const size_t *n_public_inputs,
                    const uint64_t *wires_values_dev, const int *use_pow_override,
                    const uint64_t *pow_override, uint8_t **proofs_out, size_t *proof_lens);
+/* plonky2 `CircuitData::verify` (reference call site: city_common_circuit/src/proof_minifier/
+ * pm_chain.rs:264-268): transcript, vanishing identity at zeta, proof of work, every query round's
+ * Merkle paths, fri_combine_initial, fold chain and final polynomial. Runs on the host (a few thousand
+ * permutations). 0 = accepted; CP_ERR_VERIFY with cp_last_error() naming the first failing check. */
+int cp_verify(cp_circuit *circuit, const uint8_t *proof, size_t proof_len);
 void cp_free(void *ptr);
 
 #ifdef __cplusplus
