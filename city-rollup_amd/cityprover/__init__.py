@@ -429,7 +429,7 @@ def zs_partial_products_dev(prover, circuits, wires_ptr, betas, gammas, out_ptr)
 
 
 # ---- gates and the whole proof ------------------------------------------------------------------------
-GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC = 0, 1, 2, 3
+GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON = 0, 1, 2, 3, 4
 
 
 class Gate(ctypes.Structure):

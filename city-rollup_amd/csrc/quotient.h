@@ -16,6 +16,7 @@
 // whose verifier side checks the vanishing identity at zeta.
 #pragma once
 #include "gl.h"
+#include "poseidon.h"
 
 namespace quot {
 
@@ -23,7 +24,7 @@ constexpr int MAXC = 4;        // num_challenges supported by the kernel
 constexpr int MAX_GATES = 32;
 constexpr uint64_t UNUSED_SELECTOR = 0xFFFFFFFFull;  // u32::MAX
 
-enum { GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3 };
+enum { GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3, GATE_POSEIDON = 4 };
 
 struct Gate { int type, selector_index, group_start, group_end, param; };
 
@@ -57,11 +58,12 @@ __device__ __forceinline__ uint64_t pow_tab(const uint64_t *T, uint64_t e) {
   return r;
 }
 
-__device__ __forceinline__ int gate_num_constraints(const Gate &g) {
+GL_HD int gate_num_constraints(const Gate &g) {
   switch (g.type) {
     case GATE_CONSTANT: return g.param;
     case GATE_PUBLIC_INPUT: return 4;
     case GATE_ARITHMETIC: return g.param;
+    case GATE_POSEIDON: return 123;
     default: return 0;
   }
 }
@@ -141,6 +143,63 @@ __global__ __launch_bounds__(256) void k_quotient(Args a) {
           uint64_t computed = gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1));
           add_term(gl::mul(f, gl::sub(o, computed)), t + k);
         }
+        break;
+      }
+      case GATE_POSEIDON: {
+        // plonky2 PoseidonGate: wires 0..11 in, 12..23 out, 24 swap, 25..28 delta, S-box inputs of full rounds
+        // 1..3 at 29.., of the 22 partial rounds at 65.., of the last 4 full rounds at 87.. (123 constraints).
+        // Textbook round structure with the lazy permutation primitives; anchors are canonicalised.
+        int c = t;
+        const uint64_t swap = w[(size_t)24 * N];
+        add_term(gl::mul(f, gl::mul(swap, gl::sub(swap, 1))), c++);
+        uint64_t st[poseidon::W];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          uint64_t l = w[(size_t)k * N], r = w[(size_t)(k + 4) * N], d = w[(size_t)(25 + k) * N];
+          add_term(gl::mul(f, gl::sub(gl::mul(swap, gl::sub(r, l)), d)), c++);
+          st[k] = gl::add(l, d);
+          st[k + 4] = gl::sub(r, d);
+        }
+#pragma unroll
+        for (int k = 8; k < 12; k++) st[k] = w[(size_t)k * N];
+#pragma unroll
+        for (int k = 0; k < 12; k++) st[k] = poseidon::add_const_lazy(st[k], poseidon::rc(k));
+        int rnd = 0;
+#pragma unroll 1
+        for (int r = 0; r < 4; r++, rnd++) {
+          if (r != 0) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+              uint64_t in = w[(size_t)(29 + 12 * (r - 1) + k) * N];
+              add_term(gl::mul(f, gl::sub(gl::canon(st[k]), in)), c++);
+              st[k] = in;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 12; k++) st[k] = poseidon::sbox_lazy(st[k]);
+          poseidon::mds_layer(st, (rnd + 1) * 12);
+        }
+#pragma unroll 1
+        for (int r = 0; r < 22; r++, rnd++) {
+          uint64_t in = w[(size_t)(65 + r) * N];
+          add_term(gl::mul(f, gl::sub(gl::canon(st[0]), in)), c++);
+          st[0] = poseidon::sbox_lazy(in);
+          poseidon::mds_layer(st, (rnd + 1) * 12);
+        }
+#pragma unroll 1
+        for (int r = 0; r < 4; r++, rnd++) {
+#pragma unroll
+          for (int k = 0; k < 12; k++) {
+            uint64_t in = w[(size_t)(87 + 12 * r + k) * N];
+            add_term(gl::mul(f, gl::sub(gl::canon(st[k]), in)), c++);
+            st[k] = in;
+          }
+#pragma unroll
+          for (int k = 0; k < 12; k++) st[k] = poseidon::sbox_lazy(st[k]);
+          poseidon::mds_layer(st, rnd + 1 < poseidon::ROUNDS ? (rnd + 1) * 12 : -1);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) add_term(gl::mul(f, gl::sub(gl::canon(st[k]), w[(size_t)(12 + k) * N])), c++);
         break;
       }
       default: break;

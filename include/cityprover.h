@@ -220,8 +220,8 @@ int cp_prove_tail_batch(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circuit
  * position) with its selector group (SelectorsInfo: selector_indices[gate], groups[selector]).
  * Supported gate types so far (upstream gates pinned by
  * city_common_circuit/src/builder/pad_circuit.rs:31-55): Noop, Constant{num_consts}, PublicInput,
- * Arithmetic{num_ops}. The first num_selectors "constants" columns are the selector polynomials. */
-enum { CP_GATE_NOOP = 0, CP_GATE_CONSTANT = 1, CP_GATE_PUBLIC_INPUT = 2, CP_GATE_ARITHMETIC = 3 };
+ * Arithmetic{num_ops}, Poseidon (123 constraints, needs 135 wires). The first num_selectors "constants" columns are the selector polynomials. */
+enum { CP_GATE_NOOP = 0, CP_GATE_CONSTANT = 1, CP_GATE_PUBLIC_INPUT = 2, CP_GATE_ARITHMETIC = 3, CP_GATE_POSEIDON = 4 };
 typedef struct cp_gate {
   int type;           /* CP_GATE_* */
   int selector_index; /* selector polynomial of this gate's group */

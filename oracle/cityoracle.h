@@ -132,7 +132,7 @@ uint64_t or_fri_query_point(size_t x_index, int log_n);
 void or_free(void *p);
 
 /* ---- gates / quotient (plonky2_quotient.c) ---- */
-enum { OR_GATE_NOOP = 0, OR_GATE_CONSTANT = 1, OR_GATE_PUBLIC_INPUT = 2, OR_GATE_ARITHMETIC = 3 };
+enum { OR_GATE_NOOP = 0, OR_GATE_CONSTANT = 1, OR_GATE_PUBLIC_INPUT = 2, OR_GATE_ARITHMETIC = 3, OR_GATE_POSEIDON = 4 };
 typedef struct {
   int type;           /* OR_GATE_* */
   int selector_index; /* which selector polynomial (constants column) carries this gate's group */

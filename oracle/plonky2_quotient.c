@@ -32,8 +32,67 @@ static int gate_num_constraints(const or_gate *g) {
     case OR_GATE_CONSTANT: return g->param;
     case OR_GATE_PUBLIC_INPUT: return 4;
     case OR_GATE_ARITHMETIC: return g->param;
+    case OR_GATE_POSEIDON: return 123;
     default: return -1;
   }
+}
+
+/* ---- PoseidonGate (plonky2 gates/poseidon.rs; named in city_common_circuit/src/builder/pad_circuit.rs:31-55).
+ * Wires: inputs 0..11, outputs 12..23, swap 24, delta 25..28, S-box inputs of full rounds 1..3 at 29..64,
+ * of the 22 partial rounds at 65..86, of the last 4 full rounds at 87..134. 123 constraints, in this order:
+ * swap boolean; 4 delta definitions; 36 + 22 + 48 S-box-input anchors; 12 outputs.
+ * The gate is evaluated in the textbook round structure (full constant vector + full MDS every round);
+ * upstream uses its sparse partial-round factorisation, which is the same polynomial map between anchors. */
+static uint64_t PG_RC[360], PG_CIRC[12], PG_DIAG[12];
+static int pg_ready = 0;
+static void pg_init(void) {
+  if (pg_ready) return;
+  or_poseidon_round_constants(PG_RC);
+  or_poseidon_mds(PG_CIRC, PG_DIAG);
+  pg_ready = 1;
+}
+static gl2_t ext_pow7(gl2_t x) { gl2_t x2 = gl2_mul(x, x), x4 = gl2_mul(x2, x2), x3 = gl2_mul(x, x2); return gl2_mul(x3, x4); }
+static void ext_mds(gl2_t s[12]) {
+  gl2_t o[12];
+  for (int r = 0; r < 12; r++) {
+    gl2_t acc = gl2_from_base(0);
+    for (int i = 0; i < 12; i++) acc = gl2_add(acc, gl2_scale(s[(i + r) % 12], PG_CIRC[i]));
+    acc = gl2_add(acc, gl2_scale(s[r], PG_DIAG[r]));
+    o[r] = acc;
+  }
+  memcpy(s, o, sizeof o);
+}
+static void poseidon_gate_eval(const gl2_t *w, gl2_t *out) {
+  pg_init();
+  int c = 0;
+  gl2_t swap = w[24];
+  out[c++] = gl2_mul(swap, gl2_sub(swap, gl2_from_base(1)));
+  for (int i = 0; i < 4; i++) out[c++] = gl2_sub(gl2_mul(swap, gl2_sub(w[i + 4], w[i])), w[25 + i]);
+  gl2_t st[12];
+  for (int i = 0; i < 4; i++) { st[i] = gl2_add(w[i], w[25 + i]); st[i + 4] = gl2_sub(w[i + 4], w[25 + i]); }
+  for (int i = 8; i < 12; i++) st[i] = w[i];
+  int rnd = 0;
+  for (int r = 0; r < 4; r++, rnd++) {
+    for (int i = 0; i < 12; i++) st[i] = gl2_add(st[i], gl2_from_base(PG_RC[rnd * 12 + i]));
+    if (r != 0)
+      for (int i = 0; i < 12; i++) { gl2_t in = w[29 + 12 * (r - 1) + i]; out[c++] = gl2_sub(st[i], in); st[i] = in; }
+    for (int i = 0; i < 12; i++) st[i] = ext_pow7(st[i]);
+    ext_mds(st);
+  }
+  for (int r = 0; r < 22; r++, rnd++) {
+    for (int i = 0; i < 12; i++) st[i] = gl2_add(st[i], gl2_from_base(PG_RC[rnd * 12 + i]));
+    gl2_t in = w[65 + r];
+    out[c++] = gl2_sub(st[0], in);
+    st[0] = ext_pow7(in);
+    ext_mds(st);
+  }
+  for (int r = 0; r < 4; r++, rnd++) {
+    for (int i = 0; i < 12; i++) st[i] = gl2_add(st[i], gl2_from_base(PG_RC[rnd * 12 + i]));
+    for (int i = 0; i < 12; i++) { gl2_t in = w[87 + 12 * r + i]; out[c++] = gl2_sub(st[i], in); st[i] = in; }
+    for (int i = 0; i < 12; i++) st[i] = ext_pow7(st[i]);
+    ext_mds(st);
+  }
+  for (int i = 0; i < 12; i++) out[c++] = gl2_sub(st[i], w[12 + i]);
 }
 
 int or_gates_num_constraints(const or_gates *g) {
@@ -61,6 +120,9 @@ static void gate_eval(const or_gate *g, const gl2_t *consts, const gl2_t *wires,
         gl2_t computed = gl2_add(gl2_mul(gl2_mul(m0, m1), consts[0]), gl2_mul(addend, consts[1]));
         out[i] = gl2_sub(output, computed);
       }
+      break;
+    case OR_GATE_POSEIDON:
+      poseidon_gate_eval(wires, out);
       break;
     default: break;
   }

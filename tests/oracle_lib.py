@@ -327,3 +327,4 @@ def verify_full(shape, gates, circuit_digest, cs_cap, proof_bytes):
                               ptr(flat("quotient_polys")), ptr(arr(list(dbg.betas)[:nc])),
                               ptr(arr(list(dbg.gammas)[:nc])), ptr(arr(list(dbg.alphas)[:nc])))
     return 0 if rc == 0 else -1000 + rc
+GATE_POSEIDON = 4

@@ -65,3 +65,33 @@ def test_prove_requires_gates_and_supported_types(prover):
     cp.set_gates(circ, c["gate_list"], 1)
     assert len(cp.prove_batch_dev(prover, [circ], [c["public_inputs"]], dw.ptr)[0]) > 0
     dw.free(); circ.close()
+
+
+@pytest.mark.parametrize("db,frac", [(5, 0.5), (8, 0.6)])
+def test_poseidon_gate_circuits(prover, db, frac):
+    """Circuits with PoseidonGate rows (two selector groups, 135 wires): GPU proof == oracle proof; cp_verify
+    and the oracle verifier accept; a corrupted Poseidon intermediate wire is caught by both."""
+    import cityprover as cp
+    c = build(db=db, num_routed=80, num_wires=135, chunk=8, rate_bits=3, arity_bits=(2, 2), seed=70 + db,
+              poseidon_fraction=frac)
+    assert 4 in c["gate_of_row"]
+    sh = cp_shape_of(cp, c["shape"])
+    digest = [7, 7, 7, db]
+    circ = cp.Circuit(prover, sh, digest, c["cs_values"])
+    cp.set_gates(circ, c["gate_list"], c["num_selectors"])
+    dw = prover.to_device(c["wires"][None])
+    got = cp.prove_batch_dev(prover, [circ], [c["public_inputs"]], dw.ptr)[0]
+    O.lib().or_set_threads(8)
+    want, _ = O.prove_full(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], c["wires"])
+    O.lib().or_set_threads(1)
+    assert got == want
+    cp.verify(circ, got)
+    assert O.verify_full(c["shape"], c["gates"], digest, circ.cs_cap(), got) == 0
+    row = c["gate_of_row"].index(4)
+    w = c["wires"].copy()
+    w[77, row] = (int(w[77, row]) + 1) % O.P
+    dw2 = prover.to_device(w[None])
+    bad = cp.prove_batch_dev(prover, [circ], [c["public_inputs"]], dw2.ptr)[0]
+    with pytest.raises(cp.CityProverError, match="vanishing identity"):
+        cp.verify(circ, bad)
+    dw.free(); dw2.free(); circ.close()

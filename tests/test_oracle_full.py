@@ -65,3 +65,30 @@ def test_copy_constraint_violation_is_rejected():
     w[4 * op + 3, i] = (m0 * m1 % P * int(c["cs_values"][1, i]) + ad * int(c["cs_values"][2, i])) % P
     bad, _ = O.prove_full(c["shape"], c["gates"], [2, 2, 2, 2], c["public_inputs"], c["cs_values"], w)
     assert O.verify_full(c["shape"], c["gates"], [2, 2, 2, 2], cs_cap(c), bad) <= -1000
+
+
+def test_poseidon_gate_rows_verify():
+    """Circuit with PoseidonGate rows (two selector groups): valid witness verifies; corrupting one
+    intermediate S-box wire or one output of a Poseidon row is rejected by the vanishing identity."""
+    c = build(db=5, num_routed=80, num_wires=135, chunk=8, rate_bits=3, arity_bits=(2,), seed=21,
+              poseidon_fraction=0.5)
+    assert 4 in c["gate_of_row"]
+    digest = [3, 1, 4, 1]
+    proof, _ = O.prove_full(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], c["wires"])
+    cap = cs_cap(c)
+    assert O.verify_full(c["shape"], c["gates"], digest, cap, proof) == 0
+    row = c["gate_of_row"].index(4)
+    for wire in (70, 15, 24, 100):   # partial-round S-box input, an output, the swap flag, a late full-round input
+        w = c["wires"].copy()
+        w[wire, row] = (int(w[wire, row]) + 1) % P
+        bad, _ = O.prove_full(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], w)
+        assert O.verify_full(c["shape"], c["gates"], digest, cap, bad) <= -1000, wire
+
+
+def test_poseidon_gate_outputs_are_the_permutation():
+    from synth_circuit import poseidon_gate_row
+    x = [int(v) for v in O.splitmix64_felts(5, 12)]
+    row = poseidon_gate_row(x, 0)
+    assert row[12:24] == [int(v) for v in O.permute(x)]
+    swapped = x[4:8] + x[0:4] + x[8:]
+    assert poseidon_gate_row(x, 1)[12:24] == [int(v) for v in O.permute(swapped)]
