@@ -12,17 +12,32 @@ everything else is the identity permutation. The witness satisfies every gate. T
 any particular city-rollup circuit."""
 import numpy as np
 
-import oracle_lib as O
-
-P = O.P
+P = 0xFFFFFFFF00000001
 UNUSED = 0xFFFFFFFF
+GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON = 0, 1, 2, 3, 4
 _RC = None
 CIRC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
+
+
+class OracleBackend:
+    """Default (tests): hashing / round constants from the CPU oracle, Poseidon rows in pure Python."""
+
+    def __init__(self):
+        import oracle_lib as O
+        self.O = O
+
+    def hash_no_pad(self, xs):
+        return [int(v) for v in self.O.hash_no_pad(self.O.arr(xs))]
+
+    def poseidon_rows(self, inputs, swaps):
+        return np.array([poseidon_gate_row([int(v) for v in inputs[i]], int(swaps[i])) for i in range(len(swaps))],
+                        dtype=np.uint64).reshape(len(swaps), 135)
 
 
 def _rc():
     global _RC
     if _RC is None:
+        import oracle_lib as O
         rc = np.zeros(360, np.uint64)
         O.lib().or_poseidon_round_constants(O.ptr(rc))
         _RC = [int(x) for x in rc]
@@ -68,7 +83,12 @@ def poseidon_gate_row(inputs, swap):
 
 
 def build(db=5, num_routed=8, num_wires=12, chunk=4, nc=2, seed=0, rate_bits=3, cap_height=2, pow_bits=5,
-          num_query_rounds=4, arity_bits=(2,), n_copies=6, poseidon_fraction=0.0):
+          num_query_rounds=4, arity_bits=(2,), n_copies=6, poseidon_fraction=0.0, backend=None):
+    """backend: object with hash_no_pad(list) and poseidon_rows(inputs, swaps); None = the oracle (tests).
+    With a non-oracle backend the returned dict has no oracle `shape` / `gates` objects."""
+    use_oracle = backend is None
+    if use_oracle:
+        backend = OracleBackend()
     rng = np.random.default_rng(seed)
     n = 1 << db
     num_ops = num_routed // 4
@@ -79,18 +99,21 @@ def build(db=5, num_routed=8, num_wires=12, chunk=4, nc=2, seed=0, rate_bits=3, 
     nsel = 2 if with_poseidon else 1
     ncst = nsel + 2
     npp = (num_routed + chunk - 1) // chunk - 1
-    shape = O.standard_shape(degree_bits=db, num_wires=num_wires, num_routed=num_routed, num_constants=ncst,
-                             num_challenges=nc, num_partial_products=npp, quotient_degree_factor=chunk,
-                             rate_bits=rate_bits, cap_height=cap_height, pow_bits=pow_bits,
-                             num_query_rounds=num_query_rounds, arity_bits=arity_bits)
     k_is = [pow(7, j, P) for j in range(num_routed)]
-    gate_list = [(O.GATE_NOOP, 0, 0, 4, 0), (O.GATE_CONSTANT, 0, 0, 4, 2), (O.GATE_PUBLIC_INPUT, 0, 0, 4, 0),
-                 (O.GATE_ARITHMETIC, 0, 0, 4, num_ops)]
+    gate_list = [(GATE_NOOP, 0, 0, 4, 0), (GATE_CONSTANT, 0, 0, 4, 2), (GATE_PUBLIC_INPUT, 0, 0, 4, 0),
+                 (GATE_ARITHMETIC, 0, 0, 4, num_ops)]
     if with_poseidon:
-        gate_list.append((O.GATE_POSEIDON, 1, 4, 5, 0))
-    gates = O.make_gates(gate_list, nsel, k_is)
+        gate_list.append((GATE_POSEIDON, 1, 4, 5, 0))
+    shape = gates = None
+    if use_oracle:
+        O = backend.O
+        shape = O.standard_shape(degree_bits=db, num_wires=num_wires, num_routed=num_routed, num_constants=ncst,
+                                 num_challenges=nc, num_partial_products=npp, quotient_degree_factor=chunk,
+                                 rate_bits=rate_bits, cap_height=cap_height, pow_bits=pow_bits,
+                                 num_query_rounds=num_query_rounds, arity_bits=arity_bits)
+        gates = O.make_gates(gate_list, nsel, k_is)
     public_inputs = [int(x) for x in rng.integers(0, P, 5, dtype=np.uint64)]
-    pi_hash = [int(x) for x in O.hash_no_pad(O.arr(public_inputs))]
+    pi_hash = backend.hash_no_pad(public_inputs)
 
     def pick():
         u = rng.random()
@@ -135,11 +158,12 @@ def build(db=5, num_routed=8, num_wires=12, chunk=4, nc=2, seed=0, rate_bits=3, 
             for op in range(num_ops):
                 m0, m1, ad = (int(wires[4 * op + t, i]) for t in range(3))
                 wires[4 * op + 3, i] = (m0 * m1 % P * int(c0[i]) + ad * int(c1[i])) % P
-        elif g == 4:
-            row = poseidon_gate_row([int(wires[j, i]) for j in range(12)], int(rng.integers(0, 2)))
-            for j in range(135):
-                wires[j, i] = row[j]
+    prow = [i for i in range(n) if gate_of_row[i] == 4]
+    if prow:
+        rows = backend.poseidon_rows(np.ascontiguousarray(wires[:12, prow].T), rng.integers(0, 2, len(prow), dtype=np.uint64))
+        wires[:135, prow] = rows.T
     cs_values = np.vstack([sels, c0[None, :], c1[None, :], sigma]).astype(np.uint64)
     return dict(shape=shape, gates=gates, k_is=k_is, public_inputs=public_inputs,
                 cs_values=np.ascontiguousarray(cs_values), wires=np.ascontiguousarray(wires), gate_of_row=gate_of_row,
-                num_ops=num_ops, gate_list=[tuple(int(v) for v in g) for g in gate_list], num_selectors=nsel)
+                num_ops=num_ops, gate_list=[tuple(int(v) for v in g) for g in gate_list], num_selectors=nsel,
+                num_constants=ncst, num_partial_products=npp)

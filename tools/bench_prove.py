@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """proofs/s of the whole GPU prover (cp_prove_batch: wires -> ProofWithPublicInputs) on synthetic
 qbench-shaped jobs: standard_recursion_config, n = 2^12, 135 wires / 80 routed, 28 queries, 16-bit PoW
-(gate mix: Arithmetic/Constant/PublicInput/Noop — PoseidonGate not built yet).
+(gate mix: ~60 % PoseidonGate rows, Arithmetic, Constant, PublicInput, Noop).
 One block of the example workload = 64 plonky2 proofs."""
 import json
 import os
@@ -11,19 +11,50 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "city-rollup_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np  # noqa: E402
 import cityprover as cp  # noqa: E402
 
 
-def run(prover, B, iters, n_circuits=4, profile=False):
-    from synth_circuit import build
-    cases = [build(db=12, num_routed=80, num_wires=135, chunk=8, rate_bits=3, arity_bits=(4, 4), seed=i, cap_height=4,
-                   pow_bits=16, num_query_rounds=28, n_copies=64) for i in range(n_circuits)]
-    sh = cp.standard_recursion_shape(num_constants=3)  # 1 selector + 2 gate constants in the synthetic circuits
+class ProductBackend:
+    """Witness-side helpers for the synthetic circuits WITHOUT the oracle: public-input hash through the
+    product ABI, PoseidonGate rows through tools/witgen (product headers compiled for the host)."""
+
+    def __init__(self, prover):
+        self.prover = prover
+
+    def hash_no_pad(self, xs):
+        return [int(v) for v in self.prover.hash_no_pad(np.array(xs, dtype=np.uint64))]
+
+    def poseidon_rows(self, inputs, swaps):
+        import witgen
+        return witgen.poseidon_gate_rows(inputs, swaps)
+
+
+_CASES = {}
+
+
+def cases_for(prover, n_circuits, poseidon_fraction):
+    key = (n_circuits, poseidon_fraction)
+    if key not in _CASES:
+        from synth_circuit import build
+        be = ProductBackend(prover)
+        _CASES[key] = [build(db=12, num_routed=80, num_wires=135, chunk=8, rate_bits=3, arity_bits=(4, 4), seed=i,
+                             cap_height=4, pow_bits=16, num_query_rounds=28, n_copies=64,
+                             poseidon_fraction=poseidon_fraction, backend=be) for i in range(n_circuits)]
+    return _CASES[key]
+
+
+POSEIDON_FRACTION = 0.6  # recursion-circuit gate mix (SURVEY.md §8(d) M1: Poseidon ~60 % of the rows)
+
+
+def run(prover, B, iters, n_circuits=4, profile=False, poseidon_fraction=POSEIDON_FRACTION):
+    cases = cases_for(prover, n_circuits, poseidon_fraction)
+    sh = cp.standard_recursion_shape(num_constants=cases[0]["num_constants"])  # selectors + 2 gate constants
     circs = []
     for i, c in enumerate(cases):
         circ = cp.Circuit(prover, sh, [i, 1, 2, 3], c["cs_values"])
-        cp.set_gates(circ, c["gate_list"], 1)
+        cp.set_gates(circ, c["gate_list"], c["num_selectors"])
         circs.append(circ)
     pick = [i % n_circuits for i in range(B)]
     dw = prover.to_device(np.stack([cases[i]["wires"] for i in pick]))
