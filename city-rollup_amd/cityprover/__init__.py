@@ -430,11 +430,12 @@ def zs_partial_products_dev(prover, circuits, wires_ptr, betas, gammas, out_ptr)
 
 # ---- gates and the whole proof ------------------------------------------------------------------------
 GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON = 0, 1, 2, 3, 4
+GATE_COMPARISON, GATE_U32_ARITHMETIC, GATE_U32_RANGE_CHECK = 5, 6, 7
 
 
 class Gate(ctypes.Structure):
     """cp_gate"""
-    _fields_ = [(n, ctypes.c_int) for n in ("type", "selector_index", "group_start", "group_end", "param")]
+    _fields_ = [(n, ctypes.c_int) for n in ("type", "selector_index", "group_start", "group_end", "param", "param2")]
 
 
 ABI["cp_circuit_set_gates"] = (ctypes.c_int, [_vp, ctypes.POINTER(Gate), ctypes.c_size_t, ctypes.c_int])
@@ -445,8 +446,8 @@ ABI["cp_prove_batch"] = (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp
 
 
 def set_gates(circuit, gate_list, num_selectors):
-    """gate_list: [(type, selector_index, group_start, group_end, param)] in gate-index order."""
-    arr = (Gate * len(gate_list))(*[Gate(*g) for g in gate_list])
+    """gate_list: [(type, selector_index, group_start, group_end, param[, param2])] in gate-index order."""
+    arr = (Gate * len(gate_list))(*[Gate(*(tuple(g) + (0,) * (6 - len(g)))) for g in gate_list])
     circuit.prover._check(circuit.prover.lib.cp_circuit_set_gates(circuit.handle, arr, len(gate_list), num_selectors))
 
 

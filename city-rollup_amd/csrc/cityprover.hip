@@ -555,8 +555,8 @@ int cp_ntt_dev(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stri
   }
   if (flags & CP_NTT_BITREV_IN) {  // un-permute the input first (v1: explicit pass)
     CP_TRY(bitrev_copy(ctx, data, tmp, stride, n, log_n, batch, nullptr));
-    for (size_t b = 0; b < batch; b++)
-      HIP_TRY(ctx, hipMemcpyAsync(data + b * stride, tmp + b * n, n * sizeof(uint64_t),
+    // one strided device-to-device copy for the whole batch (a single contiguous copy when stride == n)
+    HIP_TRY(ctx, hipMemcpy2DAsync(data, stride * sizeof(uint64_t), tmp, n * sizeof(uint64_t), n * sizeof(uint64_t), batch,
                                   hipMemcpyDeviceToDevice, ctx->stream));
   }
   uint64_t scale = 0;
@@ -570,8 +570,8 @@ int cp_ntt_dev(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stri
   CP_TRY(run_dif(ctx, data, log_n, batch, stride, inverse, scale, (coset && !inverse) ? stab : nullptr));
   if (!(flags & CP_NTT_BITREV_OUT)) {
     CP_TRY(bitrev_copy(ctx, data, tmp, stride, n, log_n, batch, (coset && inverse) ? stab : nullptr));
-    for (size_t b = 0; b < batch; b++)
-      HIP_TRY(ctx, hipMemcpyAsync(data + b * stride, tmp + b * n, n * sizeof(uint64_t),
+    // one strided device-to-device copy for the whole batch (a single contiguous copy when stride == n)
+    HIP_TRY(ctx, hipMemcpy2DAsync(data, stride * sizeof(uint64_t), tmp, n * sizeof(uint64_t), n * sizeof(uint64_t), batch,
                                   hipMemcpyDeviceToDevice, ctx->stream));
   } else if (coset && inverse) {
     return set_error(ctx, CP_ERR_UNSUPPORTED, "inverse coset NTT with bit-reversed output is not supported");

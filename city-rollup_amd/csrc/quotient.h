@@ -15,6 +15,7 @@
 // Parity: unpinned by reference data (see oracle/plonky2_quotient.c); bit-exact against that oracle,
 // whose verifier side checks the vanishing identity at zeta.
 #pragma once
+#include "gates.h"
 #include "gl.h"
 #include "poseidon.h"
 
@@ -24,9 +25,10 @@ constexpr int MAXC = 4;        // num_challenges supported by the kernel
 constexpr int MAX_GATES = 32;
 constexpr uint64_t UNUSED_SELECTOR = 0xFFFFFFFFull;  // u32::MAX
 
-enum { GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3, GATE_POSEIDON = 4 };
+enum { GATE_NOOP = gates::NOOP, GATE_CONSTANT = gates::CONSTANT, GATE_PUBLIC_INPUT = gates::PUBLIC_INPUT,
+       GATE_ARITHMETIC = gates::ARITHMETIC, GATE_POSEIDON = gates::POSEIDON };
 
-struct Gate { int type, selector_index, group_start, group_end, param; };
+using Gate = gates::Gate;
 
 struct Args {
   const uint64_t *const *cs_lde;  // per proof: (num_constants + R) x N, bit-reversed
@@ -58,15 +60,7 @@ __device__ __forceinline__ uint64_t pow_tab(const uint64_t *T, uint64_t e) {
   return r;
 }
 
-GL_HD int gate_num_constraints(const Gate &g) {
-  switch (g.type) {
-    case GATE_CONSTANT: return g.param;
-    case GATE_PUBLIC_INPUT: return 4;
-    case GATE_ARITHMETIC: return g.param;
-    case GATE_POSEIDON: return 123;
-    default: return 0;
-  }
-}
+GL_HD int gate_num_constraints(const Gate &g) { return gates::num_constraints(g); }
 
 // grid = (N/256, B)
 __global__ __launch_bounds__(256) void k_quotient(Args a) {
@@ -129,22 +123,6 @@ __global__ __launch_bounds__(256) void k_quotient(Args a) {
     if (a.num_selectors > 1) f = gl::mul(f, gl::sub(UNUSED_SELECTOR, sv));
     const uint64_t *consts = cs + (size_t)a.num_selectors * N;
     switch (g.type) {
-      case GATE_CONSTANT:
-        for (int k = 0; k < g.param; k++) add_term(gl::mul(f, gl::sub(consts[(size_t)k * N], w[(size_t)k * N])), t + k);
-        break;
-      case GATE_PUBLIC_INPUT:
-        for (int k = 0; k < 4; k++) add_term(gl::mul(f, gl::sub(w[(size_t)k * N], pih[k])), t + k);
-        break;
-      case GATE_ARITHMETIC: {
-        const uint64_t c0 = consts[0], c1 = consts[N];
-        for (int k = 0; k < g.param; k++) {
-          uint64_t m0 = w[(size_t)(4 * k) * N], m1 = w[(size_t)(4 * k + 1) * N], ad = w[(size_t)(4 * k + 2) * N],
-                   o = w[(size_t)(4 * k + 3) * N];
-          uint64_t computed = gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1));
-          add_term(gl::mul(f, gl::sub(o, computed)), t + k);
-        }
-        break;
-      }
       case GATE_POSEIDON: {
         // plonky2 PoseidonGate: wires 0..11 in, 12..23 out, 24 swap, 25..28 delta, S-box inputs of full rounds
         // 1..3 at 29.., of the 22 partial rounds at 65.., of the last 4 full rounds at 87.. (123 constraints).
@@ -202,7 +180,11 @@ __global__ __launch_bounds__(256) void k_quotient(Args a) {
         for (int k = 0; k < 12; k++) add_term(gl::mul(f, gl::sub(gl::canon(st[k]), w[(size_t)(12 + k) * N])), c++);
         break;
       }
-      default: break;
+      default:  // every other gate: the generic constraint code shared with the host verifier (gates.h)
+        gates::eval<uint64_t>(
+            g, [&](int j) { return w[(size_t)j * N]; }, [&](int j) { return consts[(size_t)j * N]; },
+            [&](int j) { return pih[j]; }, [&](int k, uint64_t v) { add_term(gl::mul(f, v), t + k); });
+        break;
     }
   }
   uint64_t *out = a.out + proof * a.out_stride + i;

@@ -221,12 +221,19 @@ int cp_prove_tail_batch(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circuit
  * Supported gate types so far (upstream gates pinned by
  * city_common_circuit/src/builder/pad_circuit.rs:31-55): Noop, Constant{num_consts}, PublicInput,
  * Arithmetic{num_ops}, Poseidon (123 constraints, needs 135 wires). The first num_selectors "constants" columns are the selector polynomials. */
-enum { CP_GATE_NOOP = 0, CP_GATE_CONSTANT = 1, CP_GATE_PUBLIC_INPUT = 2, CP_GATE_ARITHMETIC = 3, CP_GATE_POSEIDON = 4 };
+enum {
+  CP_GATE_NOOP = 0, CP_GATE_CONSTANT = 1, CP_GATE_PUBLIC_INPUT = 2, CP_GATE_ARITHMETIC = 3, CP_GATE_POSEIDON = 4,
+  /* in-tree city-rollup gates (city_common_circuit/src/u32/gates/): */
+  CP_GATE_COMPARISON = 5,      /* comparison.rs:96-200      param = num_bits, param2 = num_chunks */
+  CP_GATE_U32_ARITHMETIC = 6,  /* arithmetic_u32.rs:90-150  param = num_ops */
+  CP_GATE_U32_RANGE_CHECK = 7  /* range_check_u32.rs:57-80  param = num_input_limbs */
+};
 typedef struct cp_gate {
   int type;           /* CP_GATE_* */
   int selector_index; /* selector polynomial of this gate's group */
   int group_start, group_end; /* gate indices [start, end) sharing that selector */
-  int param;          /* Constant: num_consts, Arithmetic: num_ops */
+  int param;          /* Constant: num_consts, Arithmetic / U32Arithmetic: num_ops, Comparison: num_bits, ... */
+  int param2;         /* Comparison: num_chunks; otherwise 0 */
 } cp_gate;
 int cp_circuit_set_gates(cp_circuit *circuit, const cp_gate *gates, size_t n_gates, int num_selectors);
 

@@ -132,12 +132,14 @@ uint64_t or_fri_query_point(size_t x_index, int log_n);
 void or_free(void *p);
 
 /* ---- gates / quotient (plonky2_quotient.c) ---- */
-enum { OR_GATE_NOOP = 0, OR_GATE_CONSTANT = 1, OR_GATE_PUBLIC_INPUT = 2, OR_GATE_ARITHMETIC = 3, OR_GATE_POSEIDON = 4 };
+enum { OR_GATE_NOOP = 0, OR_GATE_CONSTANT = 1, OR_GATE_PUBLIC_INPUT = 2, OR_GATE_ARITHMETIC = 3, OR_GATE_POSEIDON = 4,
+       OR_GATE_COMPARISON = 5, OR_GATE_U32_ARITHMETIC = 6, OR_GATE_U32_RANGE_CHECK = 7 };
 typedef struct {
   int type;           /* OR_GATE_* */
   int selector_index; /* which selector polynomial (constants column) carries this gate's group */
   int group_start, group_end; /* the gate indices sharing that selector */
-  int param;          /* Constant: num_consts; Arithmetic: num_ops */
+  int param;          /* Constant: num_consts; Arithmetic / U32Arithmetic: num_ops; Comparison: num_bits; RangeCheck: limbs */
+  int param2;         /* Comparison: num_chunks */
 } or_gate;
 typedef struct {
   int n_gates;

@@ -33,7 +33,80 @@ static int gate_num_constraints(const or_gate *g) {
     case OR_GATE_PUBLIC_INPUT: return 4;
     case OR_GATE_ARITHMETIC: return g->param;
     case OR_GATE_POSEIDON: return 123;
+    case OR_GATE_COMPARISON: return 6 + 5 * g->param2 + (g->param + g->param2 - 1) / g->param2; /* comparison.rs:310-312 */
+    case OR_GATE_U32_ARITHMETIC: return g->param * 36;  /* arithmetic_u32.rs:269-271 */
+    case OR_GATE_U32_RANGE_CHECK: return g->param * 17; /* range_check_u32.rs:158-160 */
     default: return -1;
+  }
+}
+
+static gl2_t range_prod(gl2_t v, int count) { /* prod_{x<count} (v - x) */
+  gl2_t p = v;
+  for (int x = 1; x < count; x++) p = gl2_mul(p, gl2_sub(v, gl2_from_base((uint64_t)x)));
+  return p;
+}
+
+/* ComparisonGate — city_common_circuit/src/u32/gates/comparison.rs:96-200 */
+static void comparison_gate_eval(const or_gate *g, const gl2_t *w, gl2_t *out) {
+  const int nch = g->param2, cb = (g->param + nch - 1) / nch, csz = 1 << cb;
+  const gl2_t one = gl2_from_base(1), base = gl2_from_base((uint64_t)csz);
+  int c = 0;
+  gl2_t fc = gl2_from_base(0), sc = gl2_from_base(0);
+  for (int i = nch - 1; i >= 0; i--) { fc = gl2_add(gl2_mul(fc, base), w[4 + i]); sc = gl2_add(gl2_mul(sc, base), w[4 + nch + i]); }
+  out[c++] = gl2_sub(fc, w[0]);
+  out[c++] = gl2_sub(sc, w[1]);
+  gl2_t msd = gl2_from_base(0);
+  for (int i = 0; i < nch; i++) {
+    gl2_t f = w[4 + i], s = w[4 + nch + i];
+    out[c++] = range_prod(f, csz);
+    out[c++] = range_prod(s, csz);
+    gl2_t diff = gl2_sub(s, f), dummy = w[4 + 2 * nch + i], eq = w[4 + 3 * nch + i];
+    out[c++] = gl2_sub(gl2_mul(diff, dummy), gl2_sub(one, eq));
+    out[c++] = gl2_mul(eq, diff);
+    gl2_t inter = w[4 + 4 * nch + i];
+    out[c++] = gl2_sub(inter, gl2_mul(eq, msd));
+    msd = gl2_add(inter, gl2_mul(gl2_sub(one, eq), diff));
+  }
+  out[c++] = gl2_sub(w[3], msd);
+  gl2_t bits = gl2_from_base(0);
+  for (int i = cb; i >= 0; i--) bits = gl2_add(gl2_add(bits, bits), w[4 + 5 * nch + i]);
+  for (int i = 0; i <= cb; i++) out[c++] = gl2_mul(w[4 + 5 * nch + i], gl2_sub(one, w[4 + 5 * nch + i]));
+  out[c++] = gl2_sub(gl2_add(base, w[3]), bits);
+  out[c++] = gl2_sub(w[2], w[4 + 5 * nch + cb]);
+}
+
+/* U32ArithmeticGate — city_common_circuit/src/u32/gates/arithmetic_u32.rs:90-150 */
+static void u32_arithmetic_gate_eval(const or_gate *g, const gl2_t *w, gl2_t *out) {
+  const int nops = g->param;
+  const gl2_t one = gl2_from_base(1), four = gl2_from_base(4);
+  int c = 0;
+  for (int i = 0; i < nops; i++) {
+    gl2_t m0 = w[6 * i], m1 = w[6 * i + 1], addend = w[6 * i + 2], lo = w[6 * i + 3], hi = w[6 * i + 4], inv = w[6 * i + 5];
+    gl2_t computed = gl2_add(gl2_mul(m0, m1), addend);
+    gl2_t diff = gl2_sub(gl2_from_base(0xFFFFFFFFULL), hi);
+    out[c++] = gl2_mul(gl2_sub(gl2_mul(inv, diff), one), lo);
+    out[c++] = gl2_sub(gl2_add(gl2_scale(hi, 1ULL << 32), lo), computed);
+    gl2_t cl = gl2_from_base(0), chh = gl2_from_base(0);
+    for (int j = 31; j >= 0; j--) {
+      gl2_t limb = w[6 * nops + 32 * i + j];
+      out[c++] = range_prod(limb, 4);
+      if (j < 16) cl = gl2_add(gl2_mul(four, cl), limb); else chh = gl2_add(gl2_mul(four, chh), limb);
+    }
+    out[c++] = gl2_sub(cl, lo);
+    out[c++] = gl2_sub(chh, hi);
+  }
+}
+
+/* U32RangeCheckGate — city_common_circuit/src/u32/gates/range_check_u32.rs:57-80 */
+static void u32_range_check_gate_eval(const or_gate *g, const gl2_t *w, gl2_t *out) {
+  const int n = g->param;
+  const gl2_t four = gl2_from_base(4);
+  int c = 0;
+  for (int i = 0; i < n; i++) {
+    gl2_t sum = gl2_from_base(0);
+    for (int j = 15; j >= 0; j--) sum = gl2_add(gl2_mul(sum, four), w[n + 16 * i + j]);
+    out[c++] = gl2_sub(sum, w[i]);
+    for (int j = 0; j < 16; j++) out[c++] = range_prod(w[n + 16 * i + j], 4);
   }
 }
 
@@ -123,6 +196,15 @@ static void gate_eval(const or_gate *g, const gl2_t *consts, const gl2_t *wires,
       break;
     case OR_GATE_POSEIDON:
       poseidon_gate_eval(wires, out);
+      break;
+    case OR_GATE_COMPARISON:
+      comparison_gate_eval(g, wires, out);
+      break;
+    case OR_GATE_U32_ARITHMETIC:
+      u32_arithmetic_gate_eval(g, wires, out);
+      break;
+    case OR_GATE_U32_RANGE_CHECK:
+      u32_range_check_gate_eval(g, wires, out);
       break;
     default: break;
   }

@@ -15,6 +15,7 @@ import numpy as np
 P = 0xFFFFFFFF00000001
 UNUSED = 0xFFFFFFFF
 GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON = 0, 1, 2, 3, 4
+GATE_COMPARISON, GATE_U32_ARITHMETIC, GATE_U32_RANGE_CHECK = 5, 6, 7
 _RC = None
 CIRC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
 
@@ -82,8 +83,47 @@ def poseidon_gate_row(inputs, swap):
     return w
 
 
+def comparison_row(a, b, num_bits=32, num_chunks=16):
+    """Wires of a ComparisonGate row — witness logic of city_common_circuit/src/u32/gates/comparison.rs:440-520."""
+    cb = -(-num_bits // num_chunks)
+    cs = 1 << cb
+    fch = [(a >> (cb * i)) % cs for i in range(num_chunks)]
+    sch = [(b >> (cb * i)) % cs for i in range(num_chunks)]
+    eq = [int(f == s) for f, s in zip(fch, sch)]
+    dummy = [1 if f == s else pow((s - f) % P, P - 2, P) for f, s in zip(fch, sch)]
+    msd, inter = 0, []
+    for i in range(num_chunks):
+        if fch[i] != sch[i]:
+            msd = (sch[i] - fch[i]) % P
+            inter.append(0)
+        else:
+            inter.append(msd)
+    two_n_plus = (cs + msd) % P
+    bits = [(two_n_plus >> i) & 1 for i in range(cb + 1)]
+    return [a, b, int(a <= b), msd] + fch + sch + dummy + eq + inter + bits
+
+
+def u32_arithmetic_row(ops):
+    """ops: list of (m0, m1, addend), all < 2^32 — arithmetic_u32.rs:375-425."""
+    n = len(ops)
+    routed, limbs = [], []
+    for m0, m1, ad in ops:
+        out = m0 * m1 + ad
+        hi, lo = out >> 32, out & 0xFFFFFFFF
+        diff = 0xFFFFFFFF - hi
+        inv = 0 if diff == 0 else pow(diff, P - 2, P)
+        routed += [m0, m1, ad, lo, hi, inv]
+        limbs += [(out >> (2 * j)) & 3 for j in range(32)]
+    return routed + limbs
+
+
+def u32_range_check_row(vals):
+    """vals: list of u32 — range_check_u32.rs (aux limbs = base-4 digits, little endian)."""
+    return list(vals) + [(v >> (2 * j)) & 3 for v in vals for j in range(16)]
+
+
 def build(db=5, num_routed=8, num_wires=12, chunk=4, nc=2, seed=0, rate_bits=3, cap_height=2, pow_bits=5,
-          num_query_rounds=4, arity_bits=(2,), n_copies=6, poseidon_fraction=0.0, backend=None):
+          num_query_rounds=4, arity_bits=(2,), n_copies=6, poseidon_fraction=0.0, backend=None, u32_gates=False):
     """backend: object with hash_no_pad(list) and poseidon_rows(inputs, swaps); None = the oracle (tests).
     With a non-oracle backend the returned dict has no oracle `shape` / `gates` objects."""
     use_oracle = backend is None
@@ -96,14 +136,24 @@ def build(db=5, num_routed=8, num_wires=12, chunk=4, nc=2, seed=0, rate_bits=3, 
     with_poseidon = poseidon_fraction > 0
     if with_poseidon:
         assert num_wires >= 135
-    nsel = 2 if with_poseidon else 1
+    if u32_gates:
+        assert num_wires >= 119
+    nsel = 1 + int(u32_gates) + int(with_poseidon)
     ncst = nsel + 2
     npp = (num_routed + chunk - 1) // chunk - 1
     k_is = [pow(7, j, P) for j in range(num_routed)]
-    gate_list = [(GATE_NOOP, 0, 0, 4, 0), (GATE_CONSTANT, 0, 0, 4, 2), (GATE_PUBLIC_INPUT, 0, 0, 4, 0),
-                 (GATE_ARITHMETIC, 0, 0, 4, num_ops)]
+    gate_list = [(GATE_NOOP, 0, 0, 4, 0, 0), (GATE_CONSTANT, 0, 0, 4, 2, 0), (GATE_PUBLIC_INPUT, 0, 0, 4, 0, 0),
+                 (GATE_ARITHMETIC, 0, 0, 4, num_ops, 0)]
+    u32_ids = {}
+    if u32_gates:   # second selector group: the in-tree u32 gates (degree 4 each)
+        base = len(gate_list)
+        gate_list += [(GATE_COMPARISON, 1, base, base + 3, 32, 16), (GATE_U32_ARITHMETIC, 1, base, base + 3, 3, 0),
+                      (GATE_U32_RANGE_CHECK, 1, base, base + 3, 7, 0)]
+        u32_ids = {"cmp": base, "arith": base + 1, "range": base + 2}
+    pos_id = None
     if with_poseidon:
-        gate_list.append((GATE_POSEIDON, 1, 4, 5, 0))
+        pos_id = len(gate_list)
+        gate_list.append((GATE_POSEIDON, nsel - 1, pos_id, pos_id + 1, 0, 0))
     shape = gates = None
     if use_oracle:
         O = backend.O
@@ -118,12 +168,14 @@ def build(db=5, num_routed=8, num_wires=12, chunk=4, nc=2, seed=0, rate_bits=3, 
     def pick():
         u = rng.random()
         if with_poseidon and u < poseidon_fraction:
-            return 4
+            return pos_id
+        if u32_gates and rng.random() < 0.4:
+            return int(rng.choice(list(u32_ids.values())))
         return 3 if rng.random() < 0.8 else 0
     gate_of_row = [2, 1] + [pick() for _ in range(n - 2)]
     sels = np.full((nsel, n), UNUSED, dtype=np.uint64)
     for i, g in enumerate(gate_of_row):
-        sels[1 if g == 4 else 0, i] = g
+        sels[gate_list[g][1], i] = g
     c0 = rng.integers(0, P, n, dtype=np.uint64)
     c1 = rng.integers(0, P, n, dtype=np.uint64)
     wires = rng.integers(0, P, (num_wires, n), dtype=np.uint64)
@@ -158,7 +210,21 @@ def build(db=5, num_routed=8, num_wires=12, chunk=4, nc=2, seed=0, rate_bits=3, 
             for op in range(num_ops):
                 m0, m1, ad = (int(wires[4 * op + t, i]) for t in range(3))
                 wires[4 * op + 3, i] = (m0 * m1 % P * int(c0[i]) + ad * int(c1[i])) % P
-    prow = [i for i in range(n) if gate_of_row[i] == 4]
+    for i in range(n):
+        g = gate_of_row[i]
+        if u32_gates and g == u32_ids["cmp"]:
+            a, b = int(rng.integers(0, 2**32)), int(rng.integers(0, 2**32))
+            if rng.random() < 0.2:
+                b = a
+            row = comparison_row(a, b)
+        elif u32_gates and g == u32_ids["arith"]:
+            row = u32_arithmetic_row([tuple(int(v) for v in rng.integers(0, 2**32, 3)) for _ in range(3)])
+        elif u32_gates and g == u32_ids["range"]:
+            row = u32_range_check_row([int(v) for v in rng.integers(0, 2**32, 7)])
+        else:
+            continue
+        wires[:len(row), i] = np.array(row, dtype=np.uint64)
+    prow = [i for i in range(n) if pos_id is not None and gate_of_row[i] == pos_id]
     if prow:
         rows = backend.poseidon_rows(np.ascontiguousarray(wires[:12, prow].T), rng.integers(0, 2, len(prow), dtype=np.uint64))
         wires[:135, prow] = rows.T
@@ -166,4 +232,4 @@ def build(db=5, num_routed=8, num_wires=12, chunk=4, nc=2, seed=0, rate_bits=3, 
     return dict(shape=shape, gates=gates, k_is=k_is, public_inputs=public_inputs,
                 cs_values=np.ascontiguousarray(cs_values), wires=np.ascontiguousarray(wires), gate_of_row=gate_of_row,
                 num_ops=num_ops, gate_list=[tuple(int(v) for v in g) for g in gate_list], num_selectors=nsel,
-                num_constants=ncst, num_partial_products=npp)
+                num_constants=ncst, num_partial_products=npp, poseidon_gate_index=pos_id, u32_gate_ids=u32_ids)

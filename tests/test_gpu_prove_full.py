@@ -74,7 +74,7 @@ def test_poseidon_gate_circuits(prover, db, frac):
     import cityprover as cp
     c = build(db=db, num_routed=80, num_wires=135, chunk=8, rate_bits=3, arity_bits=(2, 2), seed=70 + db,
               poseidon_fraction=frac)
-    assert 4 in c["gate_of_row"]
+    assert c["poseidon_gate_index"] in c["gate_of_row"]
     sh = cp_shape_of(cp, c["shape"])
     digest = [7, 7, 7, db]
     circ = cp.Circuit(prover, sh, digest, c["cs_values"])
@@ -87,7 +87,7 @@ def test_poseidon_gate_circuits(prover, db, frac):
     assert got == want
     cp.verify(circ, got)
     assert O.verify_full(c["shape"], c["gates"], digest, circ.cs_cap(), got) == 0
-    row = c["gate_of_row"].index(4)
+    row = c["gate_of_row"].index(c["poseidon_gate_index"])
     w = c["wires"].copy()
     w[77, row] = (int(w[77, row]) + 1) % O.P
     dw2 = prover.to_device(w[None])
@@ -95,3 +95,51 @@ def test_poseidon_gate_circuits(prover, db, frac):
     with pytest.raises(cp.CityProverError, match="vanishing identity"):
         cp.verify(circ, bad)
     dw.free(); dw2.free(); circ.close()
+
+
+@pytest.mark.parametrize("db,frac", [(6, 0.0), (8, 0.3)])
+def test_u32_gate_circuits(prover, db, frac):
+    """In-tree city-rollup gates (ComparisonGate(32,16), U32ArithmeticGate(3), U32RangeCheckGate(7)) in their own
+    selector group, optionally beside PoseidonGate rows: GPU proof bytes == oracle proof bytes, both verifiers accept,
+    and a corrupted witness of each gate is rejected by cp_verify's vanishing identity."""
+    import cityprover as cp
+    c = build(db=db, num_routed=80, num_wires=135, chunk=8, rate_bits=3, arity_bits=(2, 2), seed=90 + db,
+              poseidon_fraction=frac, u32_gates=True)
+    ids = c["u32_gate_ids"]
+    for gid in ids.values():
+        assert gid in c["gate_of_row"]
+    sh = cp_shape_of(cp, c["shape"])
+    digest = [8, 8, 8, db]
+    circ = cp.Circuit(prover, sh, digest, c["cs_values"])
+    cp.set_gates(circ, c["gate_list"], c["num_selectors"])
+    dw = prover.to_device(c["wires"][None])
+    got = cp.prove_batch_dev(prover, [circ], [c["public_inputs"]], dw.ptr)[0]
+    O.lib().or_set_threads(8)
+    want, _ = O.prove_full(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], c["wires"])
+    O.lib().or_set_threads(1)
+    assert got == want
+    cp.verify(circ, got)
+    assert O.verify_full(c["shape"], c["gates"], digest, circ.cs_cap(), got) == 0
+    for name, wire in (("cmp", 2), ("arith", 4), ("range", 7 + 20)):
+        row = c["gate_of_row"].index(ids[name])
+        w = c["wires"].copy()
+        w[wire, row] = (int(w[wire, row]) + 1) % O.P
+        dw2 = prover.to_device(w[None])
+        bad = cp.prove_batch_dev(prover, [circ], [c["public_inputs"]], dw2.ptr)[0]
+        with pytest.raises(cp.CityProverError, match="vanishing identity"):
+            cp.verify(circ, bad)
+        dw2.free()
+    dw.free(); circ.close()
+
+
+def test_set_gates_rejects_oversized_gate(prover):
+    """A gate whose wires do not fit the circuit's wire count must be refused at load time, not read out of bounds."""
+    import cityprover as cp
+    c = build(db=5, num_routed=16, num_wires=24, chunk=8, rate_bits=3, arity_bits=(2,), seed=3)
+    sh = cp_shape_of(cp, c["shape"])
+    circ = cp.Circuit(prover, sh, [1, 1, 1, 1], c["cs_values"])
+    for bad in [(cp.GATE_U32_RANGE_CHECK, 0, 0, 1, 8, 0), (cp.GATE_COMPARISON, 0, 0, 1, 32, 16),
+                (cp.GATE_POSEIDON, 0, 0, 1, 0, 0), (cp.GATE_COMPARISON, 0, 0, 1, 32, 0)]:
+        with pytest.raises(cp.CityProverError):
+            cp.set_gates(circ, [bad], 1)
+    circ.close()

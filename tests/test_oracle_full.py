@@ -1,6 +1,7 @@
 """Oracle end-to-end: wires -> proof (A7 + A8 + tail) on a synthetic satisfiable circuit; the verifier side
 (FRI + the vanishing identity at zeta) accepts it, and rejects a witness that breaks a gate or a copy
 constraint. This is the self-consistency gate for the quotient restatement (parity unpinned by reference data)."""
+import ctypes
 import numpy as np
 import pytest
 
@@ -72,12 +73,12 @@ def test_poseidon_gate_rows_verify():
     intermediate S-box wire or one output of a Poseidon row is rejected by the vanishing identity."""
     c = build(db=5, num_routed=80, num_wires=135, chunk=8, rate_bits=3, arity_bits=(2,), seed=21,
               poseidon_fraction=0.5)
-    assert 4 in c["gate_of_row"]
+    assert c["poseidon_gate_index"] in c["gate_of_row"]
     digest = [3, 1, 4, 1]
     proof, _ = O.prove_full(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], c["wires"])
     cap = cs_cap(c)
     assert O.verify_full(c["shape"], c["gates"], digest, cap, proof) == 0
-    row = c["gate_of_row"].index(4)
+    row = c["gate_of_row"].index(c["poseidon_gate_index"])
     for wire in (70, 15, 24, 100):   # partial-round S-box input, an output, the swap flag, a late full-round input
         w = c["wires"].copy()
         w[wire, row] = (int(w[wire, row]) + 1) % P
@@ -92,3 +93,53 @@ def test_poseidon_gate_outputs_are_the_permutation():
     assert row[12:24] == [int(v) for v in O.permute(x)]
     swapped = x[4:8] + x[0:4] + x[8:]
     assert poseidon_gate_row(x, 1)[12:24] == [int(v) for v in O.permute(swapped)]
+
+
+# wire -> what it is, for the three in-tree u32 gates at the synthetic circuit's parameters
+U32_CORRUPTIONS = {
+    "cmp": [(0, "first input"), (2, "result bool"), (3, "most significant diff"), (5, "a chunk"), (4 + 32 + 3, "equality dummy"),
+            (4 + 48 + 1, "chunk-equal flag"), (4 + 64 + 7, "intermediate value"), (4 + 80 + 1, "msd bit")],
+    "arith": [(1, "multiplicand"), (3, "low half"), (4, "high half"), (18 + 40, "a 2-bit limb"), (6 + 5, "inverse")],
+    "range": [(2, "input limb"), (7 + 20, "aux limb")],
+}
+
+
+def test_u32_gates_verify_and_reject():
+    """In-tree gates (ComparisonGate(32,16), U32ArithmeticGate(3 ops), U32RangeCheckGate(7)) in their own selector
+    group: the witness built by the reference's generator logic verifies; every class of wire they constrain is
+    caught by the vanishing identity when corrupted."""
+    c = build(db=6, num_routed=80, num_wires=135, chunk=8, rate_bits=3, arity_bits=(2,), seed=33, u32_gates=True)
+    ids = c["u32_gate_ids"]
+    for name, gid in ids.items():
+        assert gid in c["gate_of_row"], name
+    digest = [9, 9, 9, 1]
+    proof, _ = O.prove_full(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], c["wires"])
+    cap = cs_cap(c)
+    assert O.verify_full(c["shape"], c["gates"], digest, cap, proof) == 0
+    for name, gid in ids.items():
+        row = c["gate_of_row"].index(gid)
+        for wire, what in U32_CORRUPTIONS[name]:
+            w = c["wires"].copy()
+            if what == "equality dummy":   # only constrained where the two chunks differ
+                wire = next(4 + 32 + i for i in range(16) if w[4 + i, row] != w[4 + 16 + i, row])
+            w[wire, row] = (int(w[wire, row]) + 1) % P
+            bad, _ = O.prove_full(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], w)
+            assert O.verify_full(c["shape"], c["gates"], digest, cap, bad) <= -1000, (name, what)
+
+
+def test_u32_gate_constraint_counts():
+    """num_constraints of the in-tree gates (comparison.rs:310, arithmetic_u32.rs:269, range_check_u32.rs:158)."""
+    g = O.make_gates([(O.GATE_COMPARISON, 0, 0, 1, 32, 16)], 1, [1])
+    assert O.lib().or_gates_num_constraints(ctypes.byref(g)) == 6 + 5 * 16 + 2
+    g = O.make_gates([(O.GATE_U32_ARITHMETIC, 0, 0, 1, 3, 0)], 1, [1])
+    assert O.lib().or_gates_num_constraints(ctypes.byref(g)) == 108
+    g = O.make_gates([(O.GATE_U32_RANGE_CHECK, 0, 0, 1, 8, 0)], 1, [1])
+    assert O.lib().or_gates_num_constraints(ctypes.byref(g)) == 136
+
+
+def test_comparison_witness_semantics():
+    from synth_circuit import comparison_row
+    for a, b in [(5, 9), (9, 5), (7, 7), (0, 2**32 - 1), (2**32 - 1, 0), (0x12345678, 0x12355678)]:
+        r = comparison_row(a, b)
+        assert r[2] == int(a <= b)
+        assert len(r) == 4 + 5 * 16 + 3
