@@ -431,11 +431,14 @@ def zs_partial_products_dev(prover, circuits, wires_ptr, betas, gammas, out_ptr)
 # ---- gates and the whole proof ------------------------------------------------------------------------
 GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON = 0, 1, 2, 3, 4
 GATE_COMPARISON, GATE_U32_ARITHMETIC, GATE_U32_RANGE_CHECK = 5, 6, 7
+GATE_U32_ADD_MANY, GATE_U32_SUBTRACTION, GATE_U32_INTERLEAVE, GATE_UNINTERLEAVE_TO_U32, GATE_UNINTERLEAVE_TO_B32 = 8, 9, 10, 11, 12
+(GATE_ARITHMETIC_EXT, GATE_MUL_EXT, GATE_BASE_SUM, GATE_RANDOM_ACCESS, GATE_REDUCING, GATE_REDUCING_EXT, GATE_POSEIDON_MDS,
+ GATE_COSET_INTERPOLATION) = 13, 14, 15, 16, 17, 18, 19, 20
 
 
 class Gate(ctypes.Structure):
     """cp_gate"""
-    _fields_ = [(n, ctypes.c_int) for n in ("type", "selector_index", "group_start", "group_end", "param", "param2")]
+    _fields_ = [(n, ctypes.c_int) for n in ("type", "selector_index", "group_start", "group_end", "param", "param2", "param3")]
 
 
 ABI["cp_circuit_set_gates"] = (ctypes.c_int, [_vp, ctypes.POINTER(Gate), ctypes.c_size_t, ctypes.c_int])
@@ -446,8 +449,8 @@ ABI["cp_prove_batch"] = (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp
 
 
 def set_gates(circuit, gate_list, num_selectors):
-    """gate_list: [(type, selector_index, group_start, group_end, param[, param2])] in gate-index order."""
-    arr = (Gate * len(gate_list))(*[Gate(*(tuple(g) + (0,) * (6 - len(g)))) for g in gate_list])
+    """gate_list: [(type, selector_index, group_start, group_end, param[, param2[, param3]])] in gate-index order."""
+    arr = (Gate * len(gate_list))(*[Gate(*(tuple(g) + (0,) * (7 - len(g)))) for g in gate_list])
     circuit.prover._check(circuit.prover.lib.cp_circuit_set_gates(circuit.handle, arr, len(gate_list), num_selectors))
 
 

@@ -7,6 +7,15 @@
 //   Comparison        city_common_circuit/src/u32/gates/comparison.rs:96-200      (88 constraints @ (32,16), deg 4)
 //   U32Arithmetic     city_common_circuit/src/u32/gates/arithmetic_u32.rs:90-150  (36 per op, deg 4)
 //   U32RangeCheck     city_common_circuit/src/u32/gates/range_check_u32.rs:57-80  (17 per limb, deg 4)
+//   U32AddMany        city_common_circuit/src/u32/gates/add_many_u32.rs:93-140    (21 per op, deg 4)
+//   U32Subtraction    city_common_circuit/src/u32/gates/subtraction_u32.rs:89-125 (19 per op, deg 4)
+//   U32Interleave     city_common_circuit/src/u32/gates/interleave_u32.rs:90-128  (34 per op, deg 2)
+//   UninterleaveToU32 city_common_circuit/src/u32/gates/uninterleave_to_u32.rs:82-130 (67 per op, deg 2)
+//   UninterleaveToB32 city_common_circuit/src/u32/gates/uninterleave_to_b32.rs:82-131 (67 per op, deg 2)
+// Remaining upstream gates of the city-common gate set (pad_circuit.rs:31-55), restated from plonky2 0.2.2:
+// ArithmeticExtension, MulExtension, BaseSum<B>, RandomAccess, Reducing, ReducingExtension, PoseidonMds,
+// CosetInterpolation. Extension-valued wires are pairs of wires forming an element of the extension ALGEBRA
+// (F[X]/(X^2-7) over F = base field for the prover, F = F_p^2 for the verifier): `Alg<F>` below.
 // Each `eval` calls emit(k, value) for constraint k in the order the reference pushes them.
 #pragma once
 #include "gl.h"
@@ -19,10 +28,26 @@ enum {
   COMPARISON = 5,       // param = num_bits, param2 = num_chunks
   U32_ARITHMETIC = 6,   // param = num_ops
   U32_RANGE_CHECK = 7,  // param = num_input_limbs
-  N_TYPES = 8
+  U32_ADD_MANY = 8,     // param = num_ops, param2 = num_addends
+  U32_SUBTRACTION = 9,  // param = num_ops
+  U32_INTERLEAVE = 10,  // param = num_ops
+  UNINTERLEAVE_TO_U32 = 11,  // param = num_ops
+  UNINTERLEAVE_TO_B32 = 12,  // param = num_ops
+  ARITHMETIC_EXT = 13,  // param = num_ops
+  MUL_EXT = 14,         // param = num_ops
+  BASE_SUM = 15,        // param = num_limbs, param2 = base B
+  RANDOM_ACCESS = 16,   // param = bits, param2 = num_copies, param3 = num_extra_constants
+  REDUCING = 17,        // param = num_coeffs
+  REDUCING_EXT = 18,    // param = num_coeffs
+  POSEIDON_MDS = 19,
+  COSET_INTERPOLATION = 20,  // param = subgroup_bits, param2 = degree
+  N_TYPES = 21
 };
 
-struct Gate { int type, selector_index, group_start, group_end, param, param2; };
+constexpr int MAX_RANDOM_ACCESS_BITS = 4;
+constexpr int MAX_COSET_BITS = 5;
+
+struct Gate { int type, selector_index, group_start, group_end, param, param2, param3; };
 
 template <class F> struct Ops;
 template <> struct Ops<uint64_t> {
@@ -49,6 +74,26 @@ GL_HD int num_constraints(const Gate &g) {
     case COMPARISON: return 6 + 5 * g.param2 + ceil_div(g.param, g.param2);  // comparison.rs:310-312
     case U32_ARITHMETIC: return g.param * 36;                               // arithmetic_u32.rs:269-271
     case U32_RANGE_CHECK: return g.param * 17;                              // range_check_u32.rs:158-160
+    case U32_ADD_MANY: return g.param * 21;                                 // add_many_u32.rs:266-268
+    case U32_SUBTRACTION: return g.param * 19;                              // subtraction_u32.rs:215-217
+    case U32_INTERLEAVE: return g.param * 34;                               // interleave_u32.rs:214-216
+    case UNINTERLEAVE_TO_U32: case UNINTERLEAVE_TO_B32: return g.param * 67;  // uninterleave_to_u32.rs:246-248
+    case ARITHMETIC_EXT: case MUL_EXT: return 2 * g.param;
+    case BASE_SUM: return 1 + g.param;
+    case RANDOM_ACCESS: return g.param2 * (g.param + 2) + g.param3;
+    case REDUCING: case REDUCING_EXT: return 2 * g.param;
+    case POSEIDON_MDS: return 24;
+    case COSET_INTERPOLATION: return 2 * (2 + 2 * (((1 << g.param) - 2) / (g.param2 - 1)));
+    default: return 0;
+  }
+}
+// constants columns (after the selectors) a gate reads
+GL_HD int num_constants(const Gate &g) {
+  switch (g.type) {
+    case CONSTANT: return g.param;
+    case ARITHMETIC: case ARITHMETIC_EXT: return 2;
+    case MUL_EXT: return 1;
+    case RANDOM_ACCESS: return g.param3;
     default: return 0;
   }
 }
@@ -62,9 +107,32 @@ GL_HD int num_wires(const Gate &g) {
     case COMPARISON: return 4 + 5 * g.param2 + ceil_div(g.param, g.param2) + 1;
     case U32_ARITHMETIC: return g.param * 38;
     case U32_RANGE_CHECK: return g.param * 17;
+    case U32_ADD_MANY: return g.param * (g.param2 + 3 + 18);
+    case U32_SUBTRACTION: return g.param * 21;
+    case U32_INTERLEAVE: return g.param * 34;
+    case UNINTERLEAVE_TO_U32: case UNINTERLEAVE_TO_B32: return g.param * 67;
+    case ARITHMETIC_EXT: return 8 * g.param;
+    case MUL_EXT: return 6 * g.param;
+    case BASE_SUM: return 1 + g.param;
+    case RANDOM_ACCESS: return g.param2 * (2 + (1 << g.param)) + g.param3 + g.param2 * g.param;
+    case REDUCING: return 6 + g.param + 2 * (g.param - 1);
+    case REDUCING_EXT: return 6 + 2 * g.param + 2 * (g.param - 1);
+    case POSEIDON_MDS: return 48;
+    case COSET_INTERPOLATION: return 1 + 2 * (1 << g.param) + 4 + 4 * (((1 << g.param) - 2) / (g.param2 - 1)) + 2;
     default: return 0;
   }
 }
+
+// plonky2's ExtensionAlgebra<F, 2>: a + b*X with X^2 = 7, components in F (F = base field: this is F_p^2 itself)
+template <class F> struct Alg { F a, b; };
+template <class F> GL_HD Alg<F> alg_add(Alg<F> x, Alg<F> y) { using O = Ops<F>; return {O::add(x.a, y.a), O::add(x.b, y.b)}; }
+template <class F> GL_HD Alg<F> alg_sub(Alg<F> x, Alg<F> y) { using O = Ops<F>; return {O::sub(x.a, y.a), O::sub(x.b, y.b)}; }
+template <class F> GL_HD Alg<F> alg_mul(Alg<F> x, Alg<F> y) {
+  using O = Ops<F>;
+  return {O::add(O::mul(x.a, y.a), O::mul(O::from(7), O::mul(x.b, y.b))), O::add(O::mul(x.a, y.b), O::mul(x.b, y.a))};
+}
+template <class F> GL_HD Alg<F> alg_scale(Alg<F> x, F s) { using O = Ops<F>; return {O::mul(x.a, s), O::mul(x.b, s)}; }
+template <class F, class WF> GL_HD Alg<F> alg_at(WF W, int start) { return {W(start), W(start + 1)}; }
 
 // prod_{x < count} (v - x)
 template <class F>
@@ -220,6 +288,199 @@ GL_HD void eval(const Gate &g, WF W, CF C, PF PI, EF emit) {
         emit(c++, O::sub(sum, W(i)));
         for (int j = 0; j < 16; j++) emit(c++, range_product(W(n + 16 * i + j), 4));
       }
+      break;
+    }
+    case U32_ADD_MANY: {  // add_many_u32.rs:93-140
+      const int num_ops = g.param, na = g.param2, stride = na + 3;
+      int c = 0;
+      const F four = O::from(4);
+      for (int i = 0; i < num_ops; i++) {
+        F computed = W(stride * i + na);  // input carry
+        for (int j = 0; j < na; j++) computed = O::add(computed, W(stride * i + j));
+        const F out_result = W(stride * i + na + 1), out_carry = W(stride * i + na + 2);
+        emit(c++, O::sub(O::add(O::mul(out_carry, O::from(1ull << 32)), out_result), computed));
+        F cr = O::from(0), cc = O::from(0);
+        for (int j = 17; j >= 0; j--) {
+          const F limb = W(stride * num_ops + 18 * i + j);
+          emit(c++, range_product(limb, 4));
+          if (j < 16) cr = O::add(O::mul(four, cr), limb);
+          else cc = O::add(O::mul(four, cc), limb);
+        }
+        emit(c++, O::sub(cr, out_result));
+        emit(c++, O::sub(cc, out_carry));
+      }
+      break;
+    }
+    case U32_SUBTRACTION: {  // subtraction_u32.rs:89-125
+      const int num_ops = g.param;
+      int c = 0;
+      const F four = O::from(4);
+      for (int i = 0; i < num_ops; i++) {
+        const F x = W(5 * i), y = W(5 * i + 1), borrow = W(5 * i + 2), out_result = W(5 * i + 3), out_borrow = W(5 * i + 4);
+        const F initial = O::sub(O::sub(x, y), borrow);
+        emit(c++, O::sub(out_result, O::add(initial, O::mul(O::from(1ull << 32), out_borrow))));
+        F comb = O::from(0);
+        for (int j = 15; j >= 0; j--) {
+          const F limb = W(5 * num_ops + 16 * i + j);
+          emit(c++, range_product(limb, 4));
+          comb = O::add(O::mul(four, comb), limb);
+        }
+        emit(c++, O::sub(comb, out_result));
+        emit(c++, O::mul(out_borrow, O::sub(O::from(1), out_borrow)));
+      }
+      break;
+    }
+    case U32_INTERLEAVE: {  // interleave_u32.rs:90-128 — bit wires are big-endian
+      const int num_ops = g.param;
+      int c = 0;
+      for (int i = 0; i < num_ops; i++) {
+        const int b0 = 2 * num_ops + 32 * i;
+        F cx = O::from(0), ci = O::from(0);
+        for (int k = 0; k < 32; k++) {
+          const F bit = W(b0 + k);
+          cx = O::add(O::add(cx, cx), bit);
+          ci = O::add(O::mul(ci, O::from(4)), bit);
+        }
+        emit(c++, O::sub(cx, W(2 * i)));
+        emit(c++, O::sub(ci, W(2 * i + 1)));
+        for (int k = 0; k < 32; k++) emit(c++, range_product(W(b0 + k), 2));
+      }
+      break;
+    }
+    case UNINTERLEAVE_TO_U32:    // uninterleave_to_u32.rs:82-130
+    case UNINTERLEAVE_TO_B32: {  // uninterleave_to_b32.rs:82-131 (even/odd bits weighted by 4^k instead of 2^k)
+      const int num_ops = g.param;
+      const F base = O::from(g.type == UNINTERLEAVE_TO_U32 ? 2 : 4);
+      int c = 0;
+      for (int i = 0; i < num_ops; i++) {
+        const int b0 = 3 * num_ops + 64 * i;
+        F ci = O::from(0), ev = O::from(0), od = O::from(0);
+        for (int k = 0; k < 64; k++) {
+          const F bit = W(b0 + k);
+          ci = O::add(O::add(ci, ci), bit);
+          if (k & 1) od = O::add(O::mul(od, base), bit);
+          else ev = O::add(O::mul(ev, base), bit);
+        }
+        emit(c++, O::sub(ci, W(3 * i)));
+        emit(c++, O::sub(ev, W(3 * i + 1)));
+        emit(c++, O::sub(od, W(3 * i + 2)));
+        for (int k = 0; k < 64; k++) emit(c++, range_product(W(b0 + k), 2));
+      }
+      break;
+    }
+    case ARITHMETIC_EXT: {  // plonky2 ArithmeticExtensionGate: out = c0*m0*m1 + c1*addend in the extension algebra
+      const F c0 = C(0), c1 = C(1);
+      for (int i = 0; i < g.param; i++) {
+        const Alg<F> m0 = alg_at<F>(W, 8 * i), m1 = alg_at<F>(W, 8 * i + 2), ad = alg_at<F>(W, 8 * i + 4),
+                     out = alg_at<F>(W, 8 * i + 6);
+        const Alg<F> d = alg_sub(out, alg_add(alg_scale(alg_mul(m0, m1), c0), alg_scale(ad, c1)));
+        emit(2 * i, d.a);
+        emit(2 * i + 1, d.b);
+      }
+      break;
+    }
+    case MUL_EXT: {  // plonky2 MulExtensionGate: out = c0*m0*m1
+      const F c0 = C(0);
+      for (int i = 0; i < g.param; i++) {
+        const Alg<F> m0 = alg_at<F>(W, 6 * i), m1 = alg_at<F>(W, 6 * i + 2), out = alg_at<F>(W, 6 * i + 4);
+        const Alg<F> d = alg_sub(out, alg_scale(alg_mul(m0, m1), c0));
+        emit(2 * i, d.a);
+        emit(2 * i + 1, d.b);
+      }
+      break;
+    }
+    case BASE_SUM: {  // plonky2 BaseSumGate<B>: wire 0 = sum, wires 1.. = little-endian limbs
+      const int limbs = g.param, B = g.param2;
+      F s = O::from(0);
+      for (int i = limbs - 1; i >= 0; i--) s = O::add(O::mul(s, O::from((uint64_t)B)), W(1 + i));
+      emit(0, O::sub(s, W(0)));
+      for (int i = 0; i < limbs; i++) emit(1 + i, range_product(W(1 + i), B));
+      break;
+    }
+    case RANDOM_ACCESS: {  // plonky2 RandomAccessGate
+      const int bits = g.param, copies = g.param2, extra = g.param3, vec = 1 << bits;
+      const int routed = (2 + vec) * copies + extra;
+      int c = 0;
+      for (int cp = 0; cp < copies; cp++) {
+        const int base = (2 + vec) * cp, wb = routed + cp * bits;
+        for (int b = 0; b < bits; b++) { const F bit = W(wb + b); emit(c++, O::mul(bit, O::sub(bit, O::from(1)))); }
+        F idx = O::from(0);
+        for (int b = bits - 1; b >= 0; b--) idx = O::add(O::add(idx, idx), W(wb + b));
+        emit(c++, O::sub(idx, W(base)));
+        F list[1 << MAX_RANDOM_ACCESS_BITS];
+#pragma unroll
+        for (int k = 0; k < (1 << MAX_RANDOM_ACCESS_BITS); k++) list[k] = k < vec ? W(base + 2 + k) : O::from(0);
+#pragma unroll
+        for (int b = 0; b < MAX_RANDOM_ACCESS_BITS; b++) {
+          if (b < bits) {
+            const F bit = W(wb + b);
+#pragma unroll
+            for (int k = 0; k < ((1 << MAX_RANDOM_ACCESS_BITS) >> (b + 1)); k++)
+              list[k] = O::add(list[2 * k], O::mul(bit, O::sub(list[2 * k + 1], list[2 * k])));
+          }
+        }
+        emit(c++, O::sub(list[0], W(base + 1)));
+      }
+      for (int i = 0; i < extra; i++) emit(c++, O::sub(C(i), W((2 + vec) * copies + i)));
+      break;
+    }
+    case REDUCING:        // plonky2 ReducingGate: acc_{i} = acc_{i-1}*alpha + coeff_i (coeffs in the base field)
+    case REDUCING_EXT: {  // plonky2 ReducingExtensionGate: same with extension coefficients
+      const int n = g.param;
+      const bool ext = g.type == REDUCING_EXT;
+      const int start_accs = 6 + (ext ? 2 * n : n);
+      const Alg<F> alpha = alg_at<F>(W, 2);
+      Alg<F> acc = alg_at<F>(W, 4);
+      for (int i = 0; i < n; i++) {
+        const Alg<F> coeff = ext ? alg_at<F>(W, 6 + 2 * i) : Alg<F>{W(6 + i), O::from(0)};
+        const Alg<F> next = i == n - 1 ? alg_at<F>(W, 0) : alg_at<F>(W, start_accs + 2 * i);
+        const Alg<F> d = alg_sub(alg_add(alg_mul(acc, alpha), coeff), next);
+        emit(2 * i, d.a);
+        emit(2 * i + 1, d.b);
+        acc = next;
+      }
+      break;
+    }
+    case POSEIDON_MDS: {  // plonky2 PoseidonMdsGate: 12 extension inputs (wires 0..23) -> 12 outputs (wires 24..47)
+      for (int r = 0; r < 12; r++)
+        for (int h = 0; h < 2; h++) {
+          F acc = O::from(0);
+          for (int i = 0; i < 12; i++) acc = O::add(acc, O::mul(W(((i + r) % 12) * 2 + h), O::from((uint64_t)POSEIDON_MDS_CIRC[i])));
+          if (r == 0) acc = O::add(acc, O::mul(W(h), O::from(8)));
+          emit(2 * r + h, O::sub(W(24 + 2 * r + h), acc));
+        }
+      break;
+    }
+    case COSET_INTERPOLATION: {  // plonky2 CosetInterpolationGate (barycentric, chunked by `degree`)
+      const int bits = g.param, deg = g.param2, n = 1 << bits, n_inter = (n - 2) / (deg - 1);
+      const int w_point = 1 + 2 * n, w_value = w_point + 2, w_inter = w_value + 2, w_shifted = w_inter + 4 * n_inter;
+      int c = 0;
+      const Alg<F> sp = alg_at<F>(W, w_shifted);
+      Alg<F> d = alg_sub(alg_at<F>(W, w_point), alg_scale(sp, W(0)));
+      emit(c++, d.a);
+      emit(c++, d.b);
+      // domain = <omega_n> in natural order; the barycentric weight of point x_i of a full subgroup is x_i / n
+      const uint64_t omega = gl::pow(7, (gl::P - 1) >> bits), n_inv = gl::inv((uint64_t)n);
+      uint64_t x = 1;
+      Alg<F> ev{O::from(0), O::from(0)}, pr{O::from(1), O::from(0)};
+      int boundary = deg, k = 0;
+      for (int i = 0; i < n; i++) {
+        if (i == boundary) {  // the k-th pair of intermediate wires takes over
+          const Alg<F> ie = alg_at<F>(W, w_inter + 2 * k), ip = alg_at<F>(W, w_inter + 2 * (n_inter + k));
+          d = alg_sub(ie, ev); emit(c++, d.a); emit(c++, d.b);
+          d = alg_sub(ip, pr); emit(c++, d.a); emit(c++, d.b);
+          ev = ie; pr = ip; k++; boundary += deg - 1;
+        }
+        const Alg<F> term{O::sub(sp.a, O::from(x)), sp.b};
+        const Alg<F> val = alg_at<F>(W, 1 + 2 * i);
+        const Alg<F> nev = alg_add(alg_mul(ev, term), alg_mul(val, alg_scale(pr, O::from(gl::mul(x, n_inv)))));
+        pr = alg_mul(pr, term);
+        ev = nev;
+        x = gl::mul(x, omega);
+      }
+      d = alg_sub(alg_at<F>(W, w_value), ev);
+      emit(c++, d.a);
+      emit(c++, d.b);
       break;
     }
     default: break;

@@ -218,22 +218,36 @@ int cp_prove_tail_batch(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circuit
 /* ---- gates and the whole proof ---------------------------------------------------------------
  * A8 needs the circuit's gate set: CommonCircuitData::gates (in order: a gate's index is its
  * position) with its selector group (SelectorsInfo: selector_indices[gate], groups[selector]).
- * Supported gate types so far (upstream gates pinned by
- * city_common_circuit/src/builder/pad_circuit.rs:31-55): Noop, Constant{num_consts}, PublicInput,
- * Arithmetic{num_ops}, Poseidon (123 constraints, needs 135 wires). The first num_selectors "constants" columns are the selector polynomials. */
+ * Supported: the whole city-common gate set (city_common_circuit/src/builder/pad_circuit.rs:31-55)
+ * and all eight in-tree u32 gates (city_common_circuit/src/u32/gates/). The first num_selectors
+ * "constants" columns are the selector polynomials; a gate's own constants follow them. */
 enum {
   CP_GATE_NOOP = 0, CP_GATE_CONSTANT = 1, CP_GATE_PUBLIC_INPUT = 2, CP_GATE_ARITHMETIC = 3, CP_GATE_POSEIDON = 4,
   /* in-tree city-rollup gates (city_common_circuit/src/u32/gates/): */
   CP_GATE_COMPARISON = 5,      /* comparison.rs:96-200      param = num_bits, param2 = num_chunks */
   CP_GATE_U32_ARITHMETIC = 6,  /* arithmetic_u32.rs:90-150  param = num_ops */
-  CP_GATE_U32_RANGE_CHECK = 7  /* range_check_u32.rs:57-80  param = num_input_limbs */
+  CP_GATE_U32_RANGE_CHECK = 7, /* range_check_u32.rs:57-80  param = num_input_limbs */
+  CP_GATE_U32_ADD_MANY = 8,    /* add_many_u32.rs:93-140    param = num_ops, param2 = num_addends */
+  CP_GATE_U32_SUBTRACTION = 9, /* subtraction_u32.rs:89-125 param = num_ops */
+  CP_GATE_U32_INTERLEAVE = 10, /* interleave_u32.rs:90-128  param = num_ops */
+  CP_GATE_UNINTERLEAVE_TO_U32 = 11, /* uninterleave_to_u32.rs:82-130 param = num_ops */
+  CP_GATE_UNINTERLEAVE_TO_B32 = 12, /* uninterleave_to_b32.rs:82-131 param = num_ops */
+  /* remaining upstream plonky2 0.2.2 gates of the city-common set: */
+  CP_GATE_ARITHMETIC_EXT = 13, /* ArithmeticExtensionGate   param = num_ops */
+  CP_GATE_MUL_EXT = 14,        /* MulExtensionGate          param = num_ops */
+  CP_GATE_BASE_SUM = 15,       /* BaseSumGate<B>            param = num_limbs, param2 = B */
+  CP_GATE_RANDOM_ACCESS = 16,  /* RandomAccessGate          param = bits (<= 4), param2 = num_copies, param3 = num_extra_constants */
+  CP_GATE_REDUCING = 17,       /* ReducingGate              param = num_coeffs */
+  CP_GATE_REDUCING_EXT = 18,   /* ReducingExtensionGate     param = num_coeffs */
+  CP_GATE_POSEIDON_MDS = 19,   /* PoseidonMdsGate */
+  CP_GATE_COSET_INTERPOLATION = 20 /* CosetInterpolationGate param = subgroup_bits (<= 5), param2 = degree */
 };
 typedef struct cp_gate {
   int type;           /* CP_GATE_* */
   int selector_index; /* selector polynomial of this gate's group */
   int group_start, group_end; /* gate indices [start, end) sharing that selector */
   int param;          /* Constant: num_consts, Arithmetic / U32Arithmetic: num_ops, Comparison: num_bits, ... */
-  int param2;         /* Comparison: num_chunks; otherwise 0 */
+  int param2, param3; /* second / third constructor parameter where the gate has one, else 0 */
 } cp_gate;
 int cp_circuit_set_gates(cp_circuit *circuit, const cp_gate *gates, size_t n_gates, int num_selectors);
 

@@ -133,13 +133,19 @@ void or_free(void *p);
 
 /* ---- gates / quotient (plonky2_quotient.c) ---- */
 enum { OR_GATE_NOOP = 0, OR_GATE_CONSTANT = 1, OR_GATE_PUBLIC_INPUT = 2, OR_GATE_ARITHMETIC = 3, OR_GATE_POSEIDON = 4,
-       OR_GATE_COMPARISON = 5, OR_GATE_U32_ARITHMETIC = 6, OR_GATE_U32_RANGE_CHECK = 7 };
+       OR_GATE_COMPARISON = 5, OR_GATE_U32_ARITHMETIC = 6, OR_GATE_U32_RANGE_CHECK = 7,
+       /* plonky2_gates.c: */
+       OR_GATE_U32_ADD_MANY = 8, OR_GATE_U32_SUBTRACTION = 9, OR_GATE_U32_INTERLEAVE = 10, OR_GATE_UNINTERLEAVE_TO_U32 = 11,
+       OR_GATE_UNINTERLEAVE_TO_B32 = 12, OR_GATE_ARITHMETIC_EXT = 13, OR_GATE_MUL_EXT = 14, OR_GATE_BASE_SUM = 15,
+       OR_GATE_RANDOM_ACCESS = 16, OR_GATE_REDUCING = 17, OR_GATE_REDUCING_EXT = 18, OR_GATE_POSEIDON_MDS = 19,
+       OR_GATE_COSET_INTERPOLATION = 20 };
 typedef struct {
   int type;           /* OR_GATE_* */
   int selector_index; /* which selector polynomial (constants column) carries this gate's group */
   int group_start, group_end; /* the gate indices sharing that selector */
   int param;          /* Constant: num_consts; Arithmetic / U32Arithmetic: num_ops; Comparison: num_bits; RangeCheck: limbs */
-  int param2;         /* Comparison: num_chunks */
+  int param2;         /* Comparison: num_chunks; AddMany: num_addends; BaseSum: B; RandomAccess: num_copies; CosetInterpolation: degree */
+  int param3;         /* RandomAccess: num_extra_constants */
 } or_gate;
 typedef struct {
   int n_gates;

@@ -10,9 +10,11 @@
  * which is an independent formula path, and the GPU path is compared bit for bit with this file.
  *
  * Gate set restated here (constraint formulas of the upstream gates named in
- * city_common_circuit/src/builder/pad_circuit.rs:31-55): Noop, Constant, PublicInput, Arithmetic.
+ * city_common_circuit/src/builder/pad_circuit.rs:31-55): Noop, Constant, PublicInput, Arithmetic, Poseidon, and the in-tree
+ * Comparison / U32Arithmetic / U32RangeCheck gates here; every other gate of the set in plonky2_gates.c.
  */
 #include "cityoracle.h"
+#include "gates_internal.h"
 #include "goldilocks.h"
 
 #include <stdlib.h>
@@ -36,7 +38,7 @@ static int gate_num_constraints(const or_gate *g) {
     case OR_GATE_COMPARISON: return 6 + 5 * g->param2 + (g->param + g->param2 - 1) / g->param2; /* comparison.rs:310-312 */
     case OR_GATE_U32_ARITHMETIC: return g->param * 36;  /* arithmetic_u32.rs:269-271 */
     case OR_GATE_U32_RANGE_CHECK: return g->param * 17; /* range_check_u32.rs:158-160 */
-    default: return -1;
+    default: return or_extra_gate_num_constraints(g); /* plonky2_gates.c */
   }
 }
 
@@ -172,7 +174,7 @@ int or_gates_num_constraints(const or_gates *g) {
   int m = 0;
   for (int i = 0; i < g->n_gates; i++) {
     int c = gate_num_constraints(&g->gates[i]);
-    if (c < 0) return -1;
+    if (c < 0 || c > 512) return -1;
     if (c > m) m = c;
   }
   return m;
@@ -206,7 +208,9 @@ static void gate_eval(const or_gate *g, const gl2_t *consts, const gl2_t *wires,
     case OR_GATE_U32_RANGE_CHECK:
       u32_range_check_gate_eval(g, wires, out);
       break;
-    default: break;
+    default:
+      or_extra_gate_eval(g, consts, wires, out); /* plonky2_gates.c */
+      break;
   }
 }
 
@@ -250,7 +254,7 @@ static void eval_vanishing(const vctx_t *v, gl2_t x, gl2_t l0, const gl2_t *cons
     }
   }
   /* gate constraints: filtered, summed per constraint index */
-  gl2_t tmp[256];
+  gl2_t tmp[512];
   for (int gi = 0; gi < G->n_gates; gi++) {
     const or_gate *g = &G->gates[gi];
     int c = gate_num_constraints(g);

@@ -272,7 +272,7 @@ GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC = 0, 1, 2, 3
 
 
 class Gate(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int) for n in ("type", "selector_index", "group_start", "group_end", "param", "param2")]
+    _fields_ = [(n, ctypes.c_int) for n in ("type", "selector_index", "group_start", "group_end", "param", "param2", "param3")]
 
 
 class Gates(ctypes.Structure):
@@ -285,7 +285,7 @@ def make_gates(gate_list, num_selectors, k_is):
     g = Gates()
     g.n_gates = len(gate_list)
     for i, t in enumerate(gate_list):
-        g.gates[i] = Gate(*(tuple(t) + (0,) * (6 - len(t))))
+        g.gates[i] = Gate(*(tuple(t) + (0,) * (7 - len(t))))
     g.num_selectors = num_selectors
     for i, k in enumerate(k_is):
         g.k_is[i] = k
@@ -329,3 +329,6 @@ def verify_full(shape, gates, circuit_digest, cs_cap, proof_bytes):
     return 0 if rc == 0 else -1000 + rc
 GATE_POSEIDON = 4
 GATE_COMPARISON, GATE_U32_ARITHMETIC, GATE_U32_RANGE_CHECK = 5, 6, 7
+GATE_U32_ADD_MANY, GATE_U32_SUBTRACTION, GATE_U32_INTERLEAVE, GATE_UNINTERLEAVE_TO_U32, GATE_UNINTERLEAVE_TO_B32 = 8, 9, 10, 11, 12
+(GATE_ARITHMETIC_EXT, GATE_MUL_EXT, GATE_BASE_SUM, GATE_RANDOM_ACCESS, GATE_REDUCING, GATE_REDUCING_EXT, GATE_POSEIDON_MDS,
+ GATE_COSET_INTERPOLATION) = 13, 14, 15, 16, 17, 18, 19, 20
