@@ -161,7 +161,9 @@ def main():
         qb = {"proofs_per_s": pps, "blocks_per_s": pps / 64.0, "proofs_per_s_single_context": pps1,
               "batch": 32, "contexts_per_gpu": 3, "proof_bytes": r1["proof_bytes"],
               "workload": "synthetic standard_recursion_config jobs (n=2^12, 135 wires / 80 routed, 28 queries, 16-bit "
-                          "PoW; ~60 % PoseidonGate rows + Arithmetic/Constant/PublicInput/Noop), wires -> proof bytes, witness generation excluded"}
+                          "PoW; the 14-gate city-common gate set of pad_circuit.rs:31-55 in 4 selector groups; rows ~60 % Poseidon, ~25 % "
+                          "Arithmetic/ArithmeticExtension/MulExtension, ~10 % Reducing/RandomAccess/BaseSum/CosetInterpolation, Noop pad), "
+                          "wires -> proof bytes, witness generation excluded"}
         data = None
 
     if rank == 0:

@@ -474,6 +474,57 @@ def prove_batch_dev(prover, circuits, public_inputs, wires_ptr, pow_overrides=No
     return res
 
 
+ABI["cp_prove_batch_host"] = (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp), ctypes.POINTER(_u64p),
+                                             ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(_u64p),
+                                             ctypes.POINTER(ctypes.c_int), _u64p,
+                                             ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)),
+                                             ctypes.POINTER(ctypes.c_size_t)])
+ABI["cp_prove"] = (ctypes.c_int, [_vp, _u64p, _u64p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64,
+                                  ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)), ctypes.POINTER(ctypes.c_size_t)])
+
+
+def prove_batch(prover, circuits, public_inputs, wires, pow_overrides=None):
+    """Host-memory variant (cp_prove_batch_host): wires = list of [num_wires][n] uint64 arrays (the witness generator's
+    output); the library copies them to the device."""
+    B = len(circuits)
+    cs = (_vp * B)(*[c.handle for c in circuits])
+    pis = [_as_u64(p) for p in public_inputs]
+    pi_ptrs = (_u64p * B)(*[_ptr(p) if p.size else None for p in pis])
+    n_pis = (ctypes.c_size_t * B)(*[p.size for p in pis])
+    ws = [_as_u64(w) for w in wires]
+    for c, w in zip(circuits, ws):   # the C ABI takes bare pointers: sizes are checked here
+        if w.size != c.shape.num_wires << c.shape.degree_bits:
+            raise ValueError("wires must be [num_wires][n] = %d x %d values" % (c.shape.num_wires, 1 << c.shape.degree_bits))
+    w_ptrs = (_u64p * B)(*[_ptr(w) for w in ws])
+    use = (ctypes.c_int * B)(*[0 if (pow_overrides is None or pow_overrides[i] is None) else 1 for i in range(B)])
+    ov = np.array([0 if (pow_overrides is None or pow_overrides[i] is None) else pow_overrides[i] for i in range(B)],
+                  dtype=np.uint64)
+    outs = (ctypes.POINTER(ctypes.c_uint8) * B)()
+    lens = (ctypes.c_size_t * B)()
+    prover._check(prover.lib.cp_prove_batch_host(prover.ctx, B, cs, pi_ptrs, n_pis, w_ptrs, use, _ptr(ov), outs, lens))
+    res = []
+    for i in range(B):
+        res.append(ctypes.string_at(outs[i], lens[i]))
+        prover.lib.cp_free(outs[i])
+    return res
+
+
+def prove(circuit, wires, public_inputs, pow_override=None):
+    """cp_prove: CircuitData::prove after witness generation for ONE proof, wires in host memory."""
+    pr = circuit.prover
+    w, pi = _as_u64(wires), _as_u64(public_inputs)
+    if w.size != circuit.shape.num_wires << circuit.shape.degree_bits:
+        raise ValueError("wires must be [num_wires][n]")
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    n = ctypes.c_size_t()
+    pr._check(pr.lib.cp_prove(circuit.handle, _ptr(w), _ptr(pi) if pi.size else None, pi.size,
+                              0 if pow_override is None else 1, 0 if pow_override is None else pow_override,
+                              ctypes.byref(out), ctypes.byref(n)))
+    res = ctypes.string_at(out, n.value)
+    pr.lib.cp_free(out)
+    return res
+
+
 ABI["cp_verify"] = (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t])
 
 

@@ -41,6 +41,9 @@ struct cp_ctx {
   // scratch buffer reused by natural-order NTT epilogues / merkle host paths
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
+  // device staging buffer for wire matrices that arrive in host memory (cp_prove / cp_prove_batch_host)
+  uint64_t *wires_stage = nullptr;
+  size_t wires_stage_bytes = 0;
   // per-proof workspace arena (prover_tail.inc): chunks survive between proofs
   struct Arena {
     std::vector<std::pair<char *, size_t>> chunks;
@@ -423,6 +426,7 @@ void cp_ctx_destroy(cp_ctx *ctx) {
   for (auto &kv : ctx->prescale_tables) hipFree(kv.second);
   for (auto &ch : ctx->arena.chunks) hipFree(ch.first);
   if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->wires_stage) hipFree(ctx->wires_stage);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -259,6 +259,17 @@ int cp_prove_batch(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circuits,
                    const uint64_t *const *public_inputs_host, const size_t *n_public_inputs,
                    const uint64_t *wires_values_dev, const int *use_pow_override,
                    const uint64_t *pow_override, uint8_t **proofs_out, size_t *proof_lens);
+/* The same with the wire matrices in HOST memory — what the Rust shim calls right after plonky2's witness generation
+ * (`generate_partial_witness(...).full_witness().wire_values`, the matrix `CircuitData::prove` builds before
+ * `PolynomialBatch::from_values`; call sites: SURVEY.md §8(a) A1). wires_values_host[p]: [num_wires][n]. The library
+ * stages them through a device buffer owned by the context. cp_prove = one proof (SURVEY.md §8(b) `cp_prove`). */
+int cp_prove_batch_host(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circuits,
+                        const uint64_t *const *public_inputs_host, const size_t *n_public_inputs,
+                        const uint64_t *const *wires_values_host, const int *use_pow_override,
+                        const uint64_t *pow_override, uint8_t **proofs_out, size_t *proof_lens);
+int cp_prove(cp_circuit *circuit, const uint64_t *wires_values_host, const uint64_t *public_inputs_host,
+             size_t n_public_inputs, int use_pow_override, uint64_t pow_override, uint8_t **proof_out,
+             size_t *proof_len);
 /* plonky2 `CircuitData::verify` (reference call site: city_common_circuit/src/proof_minifier/
  * pm_chain.rs:264-268): transcript, vanishing identity at zeta, proof of work, every query round's
  * Merkle paths, fri_combine_initial, fold chain and final polynomial. Runs on the host (a few thousand

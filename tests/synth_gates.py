@@ -283,7 +283,10 @@ def build_gate_set(gate_set=CITY_COMMON, db=7, num_routed=80, num_wires=135, chu
     if weights is None:
         weights = {t: 1.0 for t in active}
     wl = np.array([weights.get(t, 0.0) for t in active], dtype=np.float64)
-    wl = wl / wl.sum()
+    if active:
+        wl = wl / wl.sum()
+    else:
+        noop_fraction = 1.0
     types = [PUBLIC_INPUT, CONSTANT] + active
     assert len(types) <= n
     while len(types) < n:

@@ -143,3 +143,26 @@ def test_set_gates_rejects_oversized_gate(prover):
         with pytest.raises(cp.CityProverError):
             cp.set_gates(circ, [bad], 1)
     circ.close()
+
+
+def test_host_memory_entry_points(prover):
+    """cp_prove / cp_prove_batch_host (wires in host memory, the Rust shim's call) == the device-pointer path."""
+    import cityprover as cp
+    cases = [build(db=8, num_routed=24, num_wires=30, chunk=8, rate_bits=3, arity_bits=(2, 2), seed=300 + i) for i in range(3)]
+    sh = cp_shape_of(cp, cases[0]["shape"])
+    circs = []
+    for i, c in enumerate(cases):
+        circ = cp.Circuit(prover, sh, [i, 5, 5, 5], c["cs_values"])
+        cp.set_gates(circ, c["gate_list"], 1)
+        circs.append(circ)
+    dw = prover.to_device(np.stack([c["wires"] for c in cases]))
+    pis = [c["public_inputs"] for c in cases]
+    want = cp.prove_batch_dev(prover, circs, pis, dw.ptr)
+    assert cp.prove_batch(prover, circs, pis, [c["wires"] for c in cases]) == want
+    assert cp.prove(circs[1], cases[1]["wires"], pis[1]) == want[1]
+    assert cp.prove_batch(prover, circs[:1], pis[:1], [cases[0]["wires"]]) == want[:1]   # smaller batch after a larger one
+    with pytest.raises(ValueError):
+        cp.prove_batch(prover, circs, pis, [cases[0]["wires"], cases[1]["wires"], np.zeros(7, np.uint64)])
+    dw.free()
+    for c in circs:
+        c.close()

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """proofs/s of the whole GPU prover (cp_prove_batch: wires -> ProofWithPublicInputs) on synthetic
 qbench-shaped jobs: standard_recursion_config, n = 2^12, 135 wires / 80 routed, 28 queries, 16-bit PoW
-(gate mix: ~60 % PoseidonGate rows, Arithmetic, Constant, PublicInput, Noop).
+(SURVEY.md §8(d) M1). Circuits carry the whole city-common gate set (pad_circuit.rs:31-55: 14 gate types in 4 selector
+groups, 6 constants columns) with the recursion-circuit row mix: Poseidon ~60 %, Arithmetic / ArithmeticExtension /
+MulExtension ~25 %, Reducing / ReducingExtension / RandomAccess / BaseSum / CosetInterpolation ~10 %, Noop padding.
 One block of the example workload = 64 plonky2 proofs."""
 import json
 import os
@@ -34,22 +36,37 @@ class ProductBackend:
 _CASES = {}
 
 
-def cases_for(prover, n_circuits, poseidon_fraction):
-    key = (n_circuits, poseidon_fraction)
+def recursion_mix(poseidon_fraction):
+    import synth_gates as SG
+    rest = 1.0 - poseidon_fraction
+    return {SG.POSEIDON: poseidon_fraction, SG.ARITHMETIC: 0.25 * rest, SG.ARITHMETIC_EXT: 0.25 * rest, SG.MUL_EXT: 0.125 * rest,
+            SG.REDUCING: 0.05 * rest, SG.REDUCING_EXT: 0.05 * rest, SG.RANDOM_ACCESS: 0.075 * rest, SG.BASE_SUM: 0.05 * rest,
+            SG.COSET_INTERPOLATION: 0.025 * rest, SG.POSEIDON_MDS: 0.025 * rest, SG.COMPARISON: 0.025 * rest}
+
+
+def cases_for(prover, n_circuits, poseidon_fraction, gate_set="city_common"):
+    key = (n_circuits, poseidon_fraction, gate_set)
     if key not in _CASES:
-        from synth_circuit import build
         be = ProductBackend(prover)
-        _CASES[key] = [build(db=12, num_routed=80, num_wires=135, chunk=8, rate_bits=3, arity_bits=(4, 4), seed=i,
-                             cap_height=4, pow_bits=16, num_query_rounds=28, n_copies=64,
-                             poseidon_fraction=poseidon_fraction, backend=be) for i in range(n_circuits)]
+        kw = dict(db=12, num_routed=80, num_wires=135, chunk=8, rate_bits=3, arity_bits=(4, 4), cap_height=4, pow_bits=16,
+                  num_query_rounds=28, n_copies=64, backend=be)
+        if gate_set == "basic":   # Noop / Constant / PublicInput / Arithmetic (+ Poseidon): the first-milestone circuits
+            from synth_circuit import build
+            _CASES[key] = [build(seed=i, poseidon_fraction=poseidon_fraction, **kw) for i in range(n_circuits)]
+        else:
+            import synth_gates as SG
+            _CASES[key] = [SG.build_gate_set(SG.CITY_COMMON if gate_set == "city_common" else SG.ALL_GATES, seed=i,
+                                             weights=recursion_mix(poseidon_fraction), noop_fraction=0.03, **kw)
+                           for i in range(n_circuits)]
     return _CASES[key]
 
 
 POSEIDON_FRACTION = 0.6  # recursion-circuit gate mix (Poseidon ~60 % of the rows)
 
 
-def run(prover, B, iters, n_circuits=4, profile=False, poseidon_fraction=POSEIDON_FRACTION):
-    cases = cases_for(prover, n_circuits, poseidon_fraction)
+def run(prover, B, iters, n_circuits=4, profile=False, poseidon_fraction=POSEIDON_FRACTION, gate_set="city_common",
+        host_wires=False):
+    cases = cases_for(prover, n_circuits, poseidon_fraction, gate_set)
     sh = cp.standard_recursion_shape(num_constants=cases[0]["num_constants"])  # selectors + 2 gate constants
     circs = []
     for i, c in enumerate(cases):
@@ -66,7 +83,17 @@ def run(prover, B, iters, n_circuits=4, profile=False, poseidon_fraction=POSEIDO
         proofs = cp.prove_batch_dev(prover, cs, pis, dw.ptr)
     t1 = time.perf_counter()
     out = {"B": B, "ms_per_batch": (t1 - t0) * 1e3 / iters, "proofs_per_s": B * iters / (t1 - t0),
-           "blocks_per_s": B * iters / (t1 - t0) / 64.0, "proof_bytes": len(proofs[0])}
+           "blocks_per_s": B * iters / (t1 - t0) / 64.0, "proof_bytes": len(proofs[0]), "gate_set": gate_set,
+           "n_gate_types": len(cases[0]["gate_list"]), "num_selectors": cases[0]["num_selectors"]}
+    if host_wires:   # PCIe-inclusive: wires start in host memory (what the Rust shim hands over), proofs end there
+        hw = [cases[i]["wires"] for i in pick]
+        cp.prove_batch(prover, cs, pis, hw)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            cp.prove_batch(prover, cs, pis, hw)
+        t1 = time.perf_counter()
+        out["proofs_per_s_host_wires"] = B * iters / (t1 - t0)
+        out["h2d_bytes_per_proof"] = int(hw[0].nbytes)
     if profile:
         prover.profile_begin()
         cp.prove_batch_dev(prover, cs, pis, dw.ptr)
@@ -79,7 +106,7 @@ def run(prover, B, iters, n_circuits=4, profile=False, poseidon_fraction=POSEIDO
     return out
 
 
-def run_threads(T, B, iters, device=0):
+def run_threads(T, B, iters, device=0, gate_set="city_common"):
     """T host threads, each with its own context (stream): host transcript work of one batch overlaps the
     kernels of the others."""
     import threading
@@ -87,7 +114,7 @@ def run_threads(T, B, iters, device=0):
     provers = [cp.Prover(device) for _ in range(T)]
 
     def work(i):
-        res[i] = run(provers[i], B, iters)
+        res[i] = run(provers[i], B, iters, gate_set=gate_set)
 
     ths = [threading.Thread(target=work, args=(i,)) for i in range(T)]
     t0 = time.perf_counter()
@@ -105,9 +132,13 @@ if __name__ == "__main__":
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     batches = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 16, 64]
     threads = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else []
+    gate_set = sys.argv[4] if len(sys.argv) > 4 else "city_common"
     p = cp.Prover(0)
-    out = [run(p, B, iters, profile=True) for B in batches]
+    t0 = time.perf_counter()
+    cases_for(p, 4, POSEIDON_FRACTION, gate_set)
+    print("witness generation for 4 circuits: %.1f s" % (time.perf_counter() - t0), file=sys.stderr)
+    out = [run(p, B, iters, profile=True, gate_set=gate_set, host_wires=True) for B in batches]
     p.close()
     for T in threads:
-        out.append(run_threads(T, 32, iters))
+        out.append(run_threads(T, 32, iters, gate_set=gate_set))
     print(json.dumps(out))
