@@ -155,11 +155,21 @@ def main():
         import bench_prove
         barrier()
         r1 = bench_prove.run(prover, 32, 3)
-        rt = bench_prove.run_threads(3, 32, 3, device=local_rank)
+        rt = bench_prove.run_threads(3, 32, 8, device=local_rank, host_wires=True)
+        import qbench_replay
+        rp = qbench_replay.run(32, threads=3, max_batch=32, device=local_rank)
         pps = D.sum_over_ranks(dist, rt["proofs_per_s_steady"])
         pps1 = D.sum_over_ranks(dist, r1["proofs_per_s"])
+        bps = D.sum_over_ranks(dist, rp["blocks_per_s"])
         qb = {"proofs_per_s": pps, "blocks_per_s": pps / 64.0, "proofs_per_s_single_context": pps1,
               "batch": 32, "contexts_per_gpu": 3, "proof_bytes": r1["proof_bytes"],
+              "timing": "wall clock from a common start until the last of 3 contexts has finished 8 batches of 32; wire "
+                        "matrices start in page-locked HOST memory (PCIe-inclusive), proofs end in host memory",
+              "dag_replay": {"blocks_per_s": bps, "blocks_in_flight_per_gpu": rp["blocks"], "proofs_per_block": 64,
+                             "critical_path_proofs": rp["critical_path_proofs"], "mean_batch": rp["mean_batch"],
+                             "note": "tools/qbench_replay.py: the example block's job DAG (job_planner.rs:5-154) at proof "
+                                     "level, ready-queue scheduler over 3 contexts; order constraints only (a parent does "
+                                     "not consume its children's bytes: witness generation is outside the build)"},
               "workload": "synthetic standard_recursion_config jobs (n=2^12, 135 wires / 80 routed, 28 queries, 16-bit "
                           "PoW; the 14-gate city-common gate set of pad_circuit.rs:31-55 in 4 selector groups; rows ~60 % Poseidon, ~25 % "
                           "Arithmetic/ArithmeticExtension/MulExtension, ~10 % Reducing/RandomAccess/BaseSum/CosetInterpolation, Noop pad), "

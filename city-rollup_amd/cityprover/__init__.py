@@ -29,6 +29,8 @@ ABI = {
     "cp_last_error": (ctypes.c_char_p, [_vp]),
     "cp_dev_alloc": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "cp_dev_free": (ctypes.c_int, [_vp, _vp]),
+    "cp_host_alloc": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "cp_host_free": (ctypes.c_int, [_vp, _vp]),
     "cp_h2d": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
     "cp_d2h": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
     "cp_d2d": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
@@ -139,6 +141,7 @@ class Prover:
 
     def close(self):
         if getattr(self, "ctx", None):
+            self.free_pinned()
             self.lib.cp_ctx_destroy(self.ctx)
             self.ctx = None
 
@@ -159,6 +162,22 @@ class Prover:
     def to_device(self, arr):
         arr = _as_u64(arr)
         return DeviceBuffer(self, arr.size).upload(arr)
+
+    def pinned(self, arr):
+        """Copy of `arr` (uint64) in page-locked host memory (cp_host_alloc); freed with the Prover or free_pinned()."""
+        arr = _as_u64(arr)
+        p = _vp()
+        self._check(self.lib.cp_host_alloc(self.ctx, arr.size * 8, ctypes.byref(p)))
+        out = np.ctypeslib.as_array(ctypes.cast(p, _u64p), shape=(arr.size,)).reshape(arr.shape)
+        out[...] = arr
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p.value)
+        return out
+
+    def free_pinned(self):
+        for p in getattr(self, "_pinned", []):
+            self.lib.cp_host_free(self.ctx, p)
+        self._pinned = []
 
     def sync(self):
         self._check(self.lib.cp_sync(self.ctx))

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <new>
@@ -41,6 +42,10 @@ struct cp_ctx {
   // scratch buffer reused by natural-order NTT epilogues / merkle host paths
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
+  // page-locked host staging for the small transfers of a proving call (caps, challenges, openings, query words):
+  // pageable copies block inside the runtime and serialise the contexts of a process
+  char *pin = nullptr;
+  size_t pin_bytes = 0, pin_off = 0;
   // device staging buffer for wire matrices that arrive in host memory (cp_prove / cp_prove_batch_host)
   uint64_t *wires_stage = nullptr;
   size_t wires_stage_bytes = 0;
@@ -55,6 +60,10 @@ struct cp_ctx {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> prof_pool;
   std::map<std::string, std::pair<uint64_t, double>> prof_acc;  // name -> (launches, total ms)
+  // host-side phase clock (profiling only): wall time per phase of a proving call and the part of it spent
+  // blocked on the stream, reported as "host:<phase>" / "wait:<phase>"
+  const char *phase_name = nullptr;
+  double phase_t0 = 0, phase_wait = 0;
 };
 
 namespace {
@@ -129,6 +138,34 @@ void prof_flush(cp_ctx *ctx) {
     ctx->prof_pool.push_back(r.e1);
   }
   ctx->prof_recs.clear();
+}
+
+double host_now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// closes the running host phase (if any) and opens `name` (nullptr: none)
+void host_phase(cp_ctx *ctx, const char *name) {
+  if (!ctx->profiling) { ctx->phase_name = nullptr; return; }
+  const double t = host_now_ms();
+  if (ctx->phase_name) {
+    auto &a = ctx->prof_acc[std::string("host:") + ctx->phase_name];
+    a.first += 1;
+    a.second += t - ctx->phase_t0;
+    auto &w = ctx->prof_acc[std::string("wait:") + ctx->phase_name];
+    w.first += 1;
+    w.second += ctx->phase_wait;
+  }
+  ctx->phase_name = name;
+  ctx->phase_t0 = t;
+  ctx->phase_wait = 0;
+}
+// hipStreamSynchronize on the context stream, accounted to the running host phase
+hipError_t sync_stream(cp_ctx *ctx) {
+  if (!ctx->profiling) return hipStreamSynchronize(ctx->stream);
+  const double t = host_now_ms();
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  ctx->phase_wait += host_now_ms() - t;
+  return e;
 }
 
 // Launch `kernel` on the context stream; when profiling is on, bracket it with HIP events.
@@ -427,6 +464,7 @@ void cp_ctx_destroy(cp_ctx *ctx) {
   for (auto &ch : ctx->arena.chunks) hipFree(ch.first);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->wires_stage) hipFree(ctx->wires_stage);
+  if (ctx->pin) hipHostFree(ctx->pin);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -444,6 +482,21 @@ int cp_dev_free(cp_ctx *ctx, void *ptr) {
   if (!ptr) return CP_OK;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipFree(ptr));
+  return CP_OK;
+}
+int cp_host_alloc(cp_ctx *ctx, size_t bytes, void **out) {
+  CHECK_CTX(ctx);
+  if (!out) return set_error(ctx, CP_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (bytes == 0) return CP_OK;
+  if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) { *out = nullptr; return set_error(ctx, CP_ERR_OOM, "hipHostMalloc of %zu bytes failed", bytes); }
+  return CP_OK;
+}
+int cp_host_free(cp_ctx *ctx, void *ptr) {
+  CHECK_CTX(ctx);
+  if (!ptr) return CP_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipHostFree(ptr));
   return CP_OK;
 }
 int cp_h2d(cp_ctx *ctx, void *dst, const void *src, size_t bytes) {

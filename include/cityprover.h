@@ -60,6 +60,11 @@ const char *cp_last_error(cp_ctx *ctx);
 /* ---- device memory & stream ---------------------------------------------------------- */
 int cp_dev_alloc(cp_ctx *ctx, size_t bytes, void **out);
 int cp_dev_free(cp_ctx *ctx, void *ptr);
+/* Page-locked host memory for buffers the caller hands to cp_prove / cp_prove_batch_host (the witness
+ * generator's wire matrices): copies from it are DMA transfers that overlap other contexts' work; copies
+ * from ordinary pageable memory are staged by the runtime and serialise across contexts. */
+int cp_host_alloc(cp_ctx *ctx, size_t bytes, void **out);
+int cp_host_free(cp_ctx *ctx, void *ptr);
 int cp_h2d(cp_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int cp_d2h(cp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int cp_d2d(cp_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);

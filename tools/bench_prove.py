@@ -86,7 +86,8 @@ def run(prover, B, iters, n_circuits=4, profile=False, poseidon_fraction=POSEIDO
            "blocks_per_s": B * iters / (t1 - t0) / 64.0, "proof_bytes": len(proofs[0]), "gate_set": gate_set,
            "n_gate_types": len(cases[0]["gate_list"]), "num_selectors": cases[0]["num_selectors"]}
     if host_wires:   # PCIe-inclusive: wires start in host memory (what the Rust shim hands over), proofs end there
-        hw = [cases[i]["wires"] for i in pick]
+        pin = [prover.pinned(c["wires"]) for c in cases]   # page-locked, as the shim would allocate them (cp_host_alloc)
+        hw = [pin[i] for i in pick]
         cp.prove_batch(prover, cs, pis, hw)
         t0 = time.perf_counter()
         for _ in range(iters):
@@ -94,38 +95,80 @@ def run(prover, B, iters, n_circuits=4, profile=False, poseidon_fraction=POSEIDO
         t1 = time.perf_counter()
         out["proofs_per_s_host_wires"] = B * iters / (t1 - t0)
         out["h2d_bytes_per_proof"] = int(hw[0].nbytes)
+        pg = [cases[i]["wires"] for i in pick]
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            cp.prove_batch(prover, cs, pis, pg)
+        t1 = time.perf_counter()
+        out["proofs_per_s_pageable_host_wires"] = B * iters / (t1 - t0)
+        prover.free_pinned()
     if profile:
         prover.profile_begin()
         cp.prove_batch_dev(prover, cs, pis, dw.ptr)
         prof = prover.profile_end()
-        out["kernel_ms_per_batch"] = sum(v["total_ms"] for v in prof.values())
-        out["kernels_ms"] = {k: round(v["total_ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+        kern = {k: v for k, v in prof.items() if not k.startswith(("host:", "wait:"))}
+        out["kernel_ms_per_batch"] = sum(v["total_ms"] for v in kern.values())
+        out["kernels_ms"] = {k: round(v["total_ms"], 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["total_ms"])}
+        # host phases of the call: wall ms, and the part NOT spent blocked on the stream (= host work the GPU waits for
+        # unless another context fills the gap)
+        out["host_phases_ms"] = {k[5:]: [round(v["total_ms"], 3), round(v["total_ms"] - prof["wait:" + k[5:]]["total_ms"], 3)]
+                                 for k, v in prof.items() if k.startswith("host:")}
     dw.free()
     for c in circs:
         c.close()
     return out
 
 
-def run_threads(T, B, iters, device=0, gate_set="city_common"):
+def run_threads(T, B, iters, device=0, gate_set="city_common", host_wires=False):
     """T host threads, each with its own context (stream): host transcript work of one batch overlaps the
-    kernels of the others."""
+    kernels of the others. Wall clock from a common start (after every thread has loaded its circuits and run a
+    warm-up batch) until the last thread finishes its `iters` batches."""
     import threading
-    res = [None] * T
     provers = [cp.Prover(device) for _ in range(T)]
+    cases = cases_for(provers[0], 4, POSEIDON_FRACTION, gate_set)
+    sh = cp.standard_recursion_shape(num_constants=cases[0]["num_constants"])
+    start = threading.Barrier(T + 1)
+    done = [None] * T
+    pick = [i % len(cases) for i in range(B)]
+    pis = [cases[i]["public_inputs"] for i in pick]
 
-    def work(i):
-        res[i] = run(provers[i], B, iters, gate_set=gate_set)
+    def work(t):
+        p = provers[t]
+        circs = []
+        for i, c in enumerate(cases):
+            circ = cp.Circuit(p, sh, [i, 1, 2, 3], c["cs_values"])
+            cp.set_gates(circ, c["gate_list"], c["num_selectors"])
+            circs.append(circ)
+        cs = [circs[i] for i in pick]
+        if host_wires:
+            pin = [p.pinned(c["wires"]) for c in cases]
+            hw = [pin[i] for i in pick]
+            go = lambda: cp.prove_batch(p, cs, pis, hw)
+        else:
+            dw = p.to_device(np.stack([cases[i]["wires"] for i in pick]))
+            go = lambda: cp.prove_batch_dev(p, cs, pis, dw.ptr)
+        go()
+        start.wait()
+        for _ in range(iters):
+            go()
+        done[t] = time.perf_counter()
+        if not host_wires:
+            dw.free()
+        for c in circs:
+            c.close()
 
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(T)]
-    t0 = time.perf_counter()
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(T)]
     for t in ths:
         t.start()
+    start.wait()
+    t0 = time.perf_counter()
     for t in ths:
         t.join()
     for pr in provers:
         pr.close()
-    return {"threads": T, "B": B, "proofs_per_s_steady": sum(r["proofs_per_s"] for r in res),
-            "blocks_per_s_steady": sum(r["blocks_per_s"] for r in res)}
+    wall = max(done) - t0
+    return {"threads": T, "B": B, "iters_per_thread": iters, "wall_s": wall, "host_wires": host_wires,
+            "proofs_per_s_steady": T * B * iters / wall, "blocks_per_s_steady": T * B * iters / wall / 64.0}
 
 
 if __name__ == "__main__":
@@ -137,8 +180,11 @@ if __name__ == "__main__":
     t0 = time.perf_counter()
     cases_for(p, 4, POSEIDON_FRACTION, gate_set)
     print("witness generation for 4 circuits: %.1f s" % (time.perf_counter() - t0), file=sys.stderr)
-    out = [run(p, B, iters, profile=True, gate_set=gate_set, host_wires=True) for B in batches]
+    threads_only = len(sys.argv) > 5 and sys.argv[5] == "threads_only"
+    out = [] if threads_only else [run(p, B, iters, profile=True, gate_set=gate_set, host_wires=True) for B in batches]
     p.close()
     for T in threads:
-        out.append(run_threads(T, 32, iters, gate_set=gate_set))
+        out.append(run_threads(T, 32, max(iters, 8), gate_set=gate_set))
+        if not threads_only:
+            out.append(run_threads(T, 32, max(iters, 8), gate_set=gate_set, host_wires=True))
     print(json.dumps(out))

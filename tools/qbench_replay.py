@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""qbench-shaped DAG replay: block proofs/sec with the example block's dependency
+structure instead of independent proofs.
+
+One example block (`qbench_data/example.bin`: job_config register 4 / claim 2 / transfer 4 / add-withdrawal 4 /
+process-withdrawal 4 / add-deposit 2, 3 sighash inputs) = 64 plonky2 proofs. The job DAG is the one
+`plan_jobs` writes (city_rollup_core_orchestrator/src/debug/scenario/actors/job_planner.rs:5-154), expanded to proof
+level with the proof chains each job runs internally (root-agg + minifier, state transition +
+minifier, sighash inner + 3 minifiers + wrapper, final + minifier, wrap).
+
+What is replayed: the ORDER constraints and the batching opportunities. Every proof is a synthetic
+standard_recursion_config job (tools/bench_prove.py: city-common gate set, n = 2^12); a parent does not consume its
+children's bytes, because witness generation (A2) is outside the build. Wires are handed over in host memory
+(cp_prove_batch_host), so the rate is PCIe-inclusive.
+
+Scheduler: a ready queue shared by T host threads, one cp_ctx each; a thread takes up to B ready proofs of any block,
+proves them as one batch, then releases their dependents. K blocks are in flight at once (configs[3]: 64 independent
+blocks)."""
+import json
+import os
+import sys
+import threading
+import time
+import zlib
+from collections import deque
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for d in ("city-rollup_amd", "tests", "tools"):
+    sys.path.insert(0, os.path.join(ROOT, d))
+import cityprover as cp  # noqa: E402
+import bench_prove  # noqa: E402
+
+JOB_CONFIG = {"register_user": 4, "claim_deposit": 2, "token_transfer": 4, "add_withdrawal": 4, "process_withdrawal": 4,
+              "add_deposit": 2}
+PART_1 = ("register_user", "claim_deposit", "token_transfer")       # job_planner.rs:84-99
+PART_2 = ("add_withdrawal", "process_withdrawal", "add_deposit")    # job_planner.rs:101-116
+NUM_SIGHASH_INPUTS = 3
+
+
+def block_dag():
+    """[(name, [dependency names])] for the 64 proofs of one example block, in a topological order."""
+    tasks = []
+
+    def add(name, deps=()):
+        tasks.append((name, list(deps)))
+        return name
+
+    roots = {}
+    for op, count in JOB_CONFIG.items():   # op leaves + binary aggregation tree (write_multidimensional_jobs)
+        level = [add(f"{op}/leaf{i}") for i in range(count)]
+        depth = 0
+        while len(level) > 1:
+            depth += 1
+            level = [add(f"{op}/agg{depth}_{i}", level[2 * i:2 * i + 2]) for i in range(len(level) // 2)]
+        roots[op] = level[0]
+    p1 = add("state_part_1/min", [add("state_part_1", [roots[o] for o in PART_1])])
+    p2 = add("state_part_2/min", [add("state_part_2", [roots[o] for o in PART_2])])
+    st = add("state_transition/min", [add("state_transition", [p1, p2])])
+    wrappers = []
+    for i in range(NUM_SIGHASH_INPUTS):    # sighash introspection: inner STARK-carrying proof, 3 minifiers, wrapper
+        prev = add(f"sighash{i}/inner")
+        for m in range(3):
+            prev = add(f"sighash{i}/min{m}", [prev])
+        wrappers.append(add(f"sighash{i}/wrapper", [prev]))
+    for i in range(NUM_SIGHASH_INPUTS):    # final needs the state root AND the all-introspections barrier (job_planner.rs:47-54)
+        f = add(f"sighash_final{i}/min", [add(f"sighash_final{i}", [st] + wrappers)])
+        add(f"wrap_bls12381_{i}", [f])
+    return tasks
+
+
+def critical_path(tasks):
+    depth = {}
+    for name, deps in tasks:
+        depth[name] = 1 + max((depth[d] for d in deps), default=0)
+    return max(depth.values())
+
+
+class Replay:
+    def __init__(self, n_blocks):
+        dag = block_dag()
+        self.per_block = len(dag)
+        self.children, self.missing = {}, {}
+        for b in range(n_blocks):
+            for name, deps in dag:
+                self.missing[(b, name)] = len(deps)
+                for d in deps:
+                    self.children.setdefault((b, d), []).append((b, name))
+        self.ready = deque(k for k, v in self.missing.items() if v == 0)
+        self.left = len(self.missing)
+        self.block_left = [self.per_block] * n_blocks
+        self.block_done_at = [None] * n_blocks
+        self.cv = threading.Condition()
+        self.batches = []
+
+    def take(self, max_batch):
+        with self.cv:
+            while not self.ready and self.left:
+                self.cv.wait()
+            if not self.left:
+                return []
+            n = min(max_batch, len(self.ready))
+            return [self.ready.popleft() for _ in range(n)]
+
+    def done(self, batch, now):
+        with self.cv:
+            self.batches.append(len(batch))
+            for t in batch:
+                self.left -= 1
+                self.block_left[t[0]] -= 1
+                if self.block_left[t[0]] == 0:
+                    self.block_done_at[t[0]] = now
+                for ch in self.children.get(t, []):
+                    self.missing[ch] -= 1
+                    if self.missing[ch] == 0:
+                        self.ready.append(ch)
+            self.cv.notify_all()
+
+
+def run(n_blocks, threads=3, max_batch=32, device=0, gate_set="city_common", n_circuits=4, pinned=True):
+    provers = [cp.Prover(device) for _ in range(threads)]
+    cases = bench_prove.cases_for(provers[0], n_circuits, bench_prove.POSEIDON_FRACTION, gate_set)
+    sh = cp.standard_recursion_shape(num_constants=cases[0]["num_constants"])
+    circs = []
+    for p in provers:   # every context keeps its own resident copy of the circuits
+        cs = []
+        for i, c in enumerate(cases):
+            circ = cp.Circuit(p, sh, [i, 1, 2, 3], c["cs_values"])
+            cp.set_gates(circ, c["gate_list"], c["num_selectors"])
+            cs.append(circ)
+        circs.append(cs)
+    # the witness generator's output buffers: page-locked (cp_host_alloc) unless pinned=False
+    hw = [provers[0].pinned(c["wires"]) if pinned else c["wires"] for c in cases]
+    for ti, p in enumerate(provers):   # warm-up: arena, staging buffer, tables
+        cp.prove_batch(p, [circs[ti][0]] * max_batch, [cases[0]["public_inputs"]] * max_batch, [hw[0]] * max_batch)
+    rp = Replay(n_blocks)
+    t0 = time.perf_counter()
+
+    def worker(ti):
+        p = provers[ti]
+        while True:
+            batch = rp.take(max_batch)
+            if not batch:
+                return
+            pick = [(t[0] + zlib.crc32(t[1].encode())) % n_circuits for t in batch]
+            cp.prove_batch(p, [circs[ti][k] for k in pick], [cases[k]["public_inputs"] for k in pick],
+                           [hw[k] for k in pick])
+            rp.done(batch, time.perf_counter() - t0)
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(threads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    elapsed = time.perf_counter() - t0
+    for cs in circs:
+        for c in cs:
+            c.close()
+    for p in provers:
+        p.close()
+    lat = sorted(rp.block_done_at)
+    return {"blocks": n_blocks, "proofs": n_blocks * rp.per_block, "threads": threads, "max_batch": max_batch,
+            "seconds": elapsed, "blocks_per_s": n_blocks / elapsed, "proofs_per_s": n_blocks * rp.per_block / elapsed,
+            "first_block_done_s": lat[0], "median_block_done_s": lat[len(lat) // 2], "batches": len(rp.batches),
+            "mean_batch": sum(rp.batches) / len(rp.batches), "critical_path_proofs": critical_path(block_dag()),
+            "gate_set": gate_set, "pinned_host_wires": pinned}
+
+
+if __name__ == "__main__":
+    ks = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 8, 64]
+    threads = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    pinned = (sys.argv[3] != "pageable") if len(sys.argv) > 3 else True
+    print(json.dumps([run(k, threads=threads, pinned=pinned) for k in ks]))
