@@ -70,3 +70,25 @@ def test_set_gates_parameter_validation(prover):
         with pytest.raises(cp.CityProverError):
             cp.set_gates(circ, [bad], 1)
     circ.close()
+
+
+@pytest.mark.parametrize("db,arity", [(13, (4, 4)), (14, (4, 4, 1))])
+def test_larger_circuits(prover, db, arity):
+    """Degrees above the 4096-point single-pass NTT tile (op circuits before minification are 2^13..2^15 rows): the
+    multi-pass iNTT / LDE paths, deeper trees and a third FRI layer must give the oracle's bytes too."""
+    import cityprover as cp
+    c = SG.build_gate_set(SG.CITY_COMMON, db=db, seed=40 + db, arity_bits=arity, cap_height=4, num_query_rounds=8,
+                          pow_bits=8, noop_fraction=0.3)
+    sh = cp_shape_of(cp, c["shape"])
+    digest = [9, 9, db, 1]
+    circ = cp.Circuit(prover, sh, digest, c["cs_values"])
+    cp.set_gates(circ, c["gate_list"], c["num_selectors"])
+    got = cp.prove(circ, c["wires"], c["public_inputs"])
+    O.lib().or_set_threads(16)
+    try:
+        want, _ = O.prove_full(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], c["wires"])
+    finally:
+        O.lib().or_set_threads(1)
+    assert got == want
+    cp.verify(circ, got)
+    circ.close()
