@@ -198,10 +198,12 @@ GL_HD void poseidon_gate(WF W, EF emit) {
 
 // Unfiltered constraints of every gate type except Poseidon-on-device.
 // W(j): local wire j; C(j): gate constant j (after the selector columns); PI(j): public-inputs hash element j.
-template <class F, class WF, class CF, class PF, class EF>
-GL_HD void eval(const Gate &g, WF W, CF C, PF PI, EF emit) {
+// TYPE is a compile-time constant so that a caller instantiating one gate type carries only that gate's code
+// (the quotient kernels are one instantiation per gate type); `eval` below dispatches at run time.
+template <int TYPE, class F, class WF, class CF, class PF, class EF>
+GL_HD void eval_t(const Gate &g, WF W, CF C, PF PI, EF emit) {
   using O = Ops<F>;
-  switch (g.type) {
+  switch (TYPE) {
     case CONSTANT:
       for (int k = 0; k < g.param; k++) emit(k, O::sub(C(k), W(k)));
       break;
@@ -350,7 +352,7 @@ GL_HD void eval(const Gate &g, WF W, CF C, PF PI, EF emit) {
     case UNINTERLEAVE_TO_U32:    // uninterleave_to_u32.rs:82-130
     case UNINTERLEAVE_TO_B32: {  // uninterleave_to_b32.rs:82-131 (even/odd bits weighted by 4^k instead of 2^k)
       const int num_ops = g.param;
-      const F base = O::from(g.type == UNINTERLEAVE_TO_U32 ? 2 : 4);
+      const F base = O::from(TYPE == UNINTERLEAVE_TO_U32 ? 2 : 4);
       int c = 0;
       for (int i = 0; i < num_ops; i++) {
         const int b0 = 3 * num_ops + 64 * i;
@@ -427,7 +429,7 @@ GL_HD void eval(const Gate &g, WF W, CF C, PF PI, EF emit) {
     case REDUCING:        // plonky2 ReducingGate: acc_{i} = acc_{i-1}*alpha + coeff_i (coeffs in the base field)
     case REDUCING_EXT: {  // plonky2 ReducingExtensionGate: same with extension coefficients
       const int n = g.param;
-      const bool ext = g.type == REDUCING_EXT;
+      const bool ext = TYPE == REDUCING_EXT;
       const int start_accs = 6 + (ext ? 2 * n : n);
       const Alg<F> alpha = alg_at<F>(W, 2);
       Alg<F> acc = alg_at<F>(W, 4);
@@ -460,7 +462,15 @@ GL_HD void eval(const Gate &g, WF W, CF C, PF PI, EF emit) {
       emit(c++, d.a);
       emit(c++, d.b);
       // domain = <omega_n> in natural order; the barycentric weight of point x_i of a full subgroup is x_i / n
-      const uint64_t omega = gl::pow(7, (gl::P - 1) >> bits), n_inv = gl::inv((uint64_t)n);
+      // omega_n = 7^((p-1)/n) and 1/n for n = 2^bits <= 32 (literals: a per-point pow/inv would cost more than the gate)
+      constexpr uint64_t OMEGA[6] = {1ull, 0xffffffff00000000ull, 0x1000000000000ull, 0xfffffffeff000001ull,
+                                     0xefffffff00000001ull, 0x3fffffffc000ull};
+      constexpr uint64_t N_INV[6] = {1ull, 0x7fffffff80000001ull, 0xbfffffff40000001ull, 0xdfffffff20000001ull,
+                                     0xefffffff10000001ull, 0xf7ffffff08000001ull};
+      uint64_t omega = OMEGA[1], n_inv = N_INV[1];
+#pragma unroll
+      for (int b = 2; b <= MAX_COSET_BITS; b++)
+        if (bits == b) { omega = OMEGA[b]; n_inv = N_INV[b]; }
       uint64_t x = 1;
       Alg<F> ev{O::from(0), O::from(0)}, pr{O::from(1), O::from(0)};
       int boundary = deg, k = 0;
@@ -483,6 +493,21 @@ GL_HD void eval(const Gate &g, WF W, CF C, PF PI, EF emit) {
       emit(c++, d.b);
       break;
     }
+    default: break;
+  }
+}
+
+template <class F, class WF, class CF, class PF, class EF>
+GL_HD void eval(const Gate &g, WF W, CF C, PF PI, EF emit) {
+  switch (g.type) {
+#define CITY_GATE_CASE(T) case T: eval_t<T, F>(g, W, C, PI, emit); break;
+    CITY_GATE_CASE(CONSTANT) CITY_GATE_CASE(PUBLIC_INPUT) CITY_GATE_CASE(ARITHMETIC) CITY_GATE_CASE(POSEIDON)
+    CITY_GATE_CASE(COMPARISON) CITY_GATE_CASE(U32_ARITHMETIC) CITY_GATE_CASE(U32_RANGE_CHECK) CITY_GATE_CASE(U32_ADD_MANY)
+    CITY_GATE_CASE(U32_SUBTRACTION) CITY_GATE_CASE(U32_INTERLEAVE) CITY_GATE_CASE(UNINTERLEAVE_TO_U32)
+    CITY_GATE_CASE(UNINTERLEAVE_TO_B32) CITY_GATE_CASE(ARITHMETIC_EXT) CITY_GATE_CASE(MUL_EXT) CITY_GATE_CASE(BASE_SUM)
+    CITY_GATE_CASE(RANDOM_ACCESS) CITY_GATE_CASE(REDUCING) CITY_GATE_CASE(REDUCING_EXT) CITY_GATE_CASE(POSEIDON_MDS)
+    CITY_GATE_CASE(COSET_INTERPOLATION)
+#undef CITY_GATE_CASE
     default: break;
   }
 }

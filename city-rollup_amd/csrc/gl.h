@@ -77,6 +77,14 @@ GL_HD uint64_t mul(uint64_t a, uint64_t b) {
   return reduce128(lo, hi);
 }
 GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
+// a*b + c as a lazy u64 (any representative < 2^64 of the class); a, b, c may be lazy themselves
+GL_HD uint64_t mul_add_lazy(uint64_t a, uint64_t b, uint64_t c) {
+  uint64_t lo, hi;
+  mul_wide(a, b, lo, hi);
+  lo += c;
+  hi += lo < c;  // a*b <= (2^64-1)^2 keeps hi <= 2^64-2: no overflow
+  return reduce128_lazy(lo, hi);
+}
 
 GL_HD uint64_t pow7(uint64_t x) {
   uint64_t x2 = sqr(x), x4 = sqr(x2), x3 = mul(x, x2);

@@ -6,11 +6,13 @@
 // checks of every challenge, then the gate constraints (filtered by the selector polynomials and summed
 // per constraint index over all gates).
 //
-// One lane per LDE point, in STORAGE order (bit-reversed), so that all ~240 column reads per point are
-// coalesced across the wave; the two results per point are written to their natural position (the
-// inverse transform wants natural order) — a scattered 8-byte store per challenge into an L2-resident
-// 256 KB column. The kernel is HBM/L2-streaming bound by design: ~1.9 KB read per point, ~1.2 K modular
-// multiplications (permutation argument) + the gate set.
+// One lane per LDE point, in STORAGE order (bit-reversed), so that all column reads of a point are coalesced
+// across the wave. The work is split into one launch per piece — the permutation argument (k_quot_perm), one
+// launch per gate of the circuit (k_quot_gate<TYPE>: an instantiation carries only that gate's code, so the
+// light gates run at 5-8 waves per SIMD instead of the 2 a single fused kernel gets from PoseidonGate's
+// register footprint) and k_quot_finish (divide by Z_H, scatter to the natural order the inverse transform
+// wants). The pieces add into a [proof][challenge][N] accumulator in storage order; field addition is exact, so
+// the split does not change a bit of the result.
 //
 // Parity: unpinned by reference data (see oracle/plonky2_quotient.c); bit-exact against that oracle,
 // whose verifier side checks the vanishing identity at zeta.
@@ -45,6 +47,7 @@ struct Args {
   const uint64_t *omega_tab;      // power table of omega_N
   uint64_t *out;                  // [proof][nc][N], NATURAL index order
   size_t out_stride;
+  uint64_t *acc;                  // [proof][nc][N], storage order: sum_t alpha^t term_t before the division by Z_H
   uint64_t n_field;               // n as a field element
   size_t N;
   int log_N, rb;
@@ -62,8 +65,8 @@ __device__ __forceinline__ uint64_t pow_tab(const uint64_t *T, uint64_t e) {
 
 GL_HD int gate_num_constraints(const Gate &g) { return gates::num_constraints(g); }
 
-// grid = (N/256, B)
-__global__ __launch_bounds__(256) void k_quotient(Args a) {
+// grid = (N/256, B). L_0(x)(Z(x)-1) for every challenge, then the partial-product checks: terms 0 .. nc*(npp+2)
+__global__ __launch_bounds__(256) void k_quot_perm(Args a) {
   const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;  // storage (bit-reversed) position
   if (s >= a.N) return;
   const size_t proof = blockIdx.y;
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void k_quotient(Args a) {
   const int nc = a.nc;
 
   const uint64_t x = gl::mul(7, pow_tab(a.omega_tab, i));
-  const uint64_t zh = a.zh[i & ((1u << a.rb) - 1)], zh_inv = a.zh_inv[i & ((1u << a.rb) - 1)];
+  const uint64_t zh = a.zh[i & ((1u << a.rb) - 1)];
   const uint64_t l0 = gl::mul(zh, gl::inv(gl::mul(a.n_field, gl::sub(x, 1))));
 
   uint64_t acc[MAXC];
@@ -89,9 +92,8 @@ __global__ __launch_bounds__(256) void k_quotient(Args a) {
   auto add_term = [&](uint64_t term, int idx) {
 #pragma unroll
     for (int c = 0; c < MAXC; c++)
-      if (c < nc) acc[c] = gl::add(acc[c], gl::mul(term, apow[(size_t)c * a.n_terms + idx]));
+      if (c < nc) acc[c] = gl::mul_add_lazy(term, apow[(size_t)c * a.n_terms + idx], acc[c]);  // lazy u64
   };
-  // L_0(x) (Z(x) - 1)
   for (int c = 0; c < nc; c++) add_term(gl::mul(l0, gl::sub(zsb[(size_t)c * N + s], 1)), t++);
   // partial-product checks: prev * prod(num chunk) - next * prod(den chunk)
   for (int c = 0; c < nc; c++) {
@@ -110,87 +112,133 @@ __global__ __launch_bounds__(256) void k_quotient(Args a) {
       prev = next;
     }
   }
-  // gate constraints: filter * unfiltered, summed per constraint index over the gates
-  const uint64_t *pih = a.pi_hash + proof * 4;
-  for (int gi = 0; gi < a.n_gates; gi++) {
-    const Gate g = a.gates[gi];
-    const int ncon = gate_num_constraints(g);
-    if (ncon == 0) continue;
-    const uint64_t sv = cs[(size_t)g.selector_index * N];
-    uint64_t f = 1;
-    for (int r = g.group_start; r < g.group_end; r++)
-      if (r != gi) f = gl::mul(f, gl::sub((uint64_t)r, sv));
-    if (a.num_selectors > 1) f = gl::mul(f, gl::sub(UNUSED_SELECTOR, sv));
-    const uint64_t *consts = cs + (size_t)a.num_selectors * N;
-    switch (g.type) {
-      case GATE_POSEIDON: {
-        // plonky2 PoseidonGate: wires 0..11 in, 12..23 out, 24 swap, 25..28 delta, S-box inputs of full rounds
-        // 1..3 at 29.., of the 22 partial rounds at 65.., of the last 4 full rounds at 87.. (123 constraints).
-        // Textbook round structure with the lazy permutation primitives; anchors are canonicalised.
-        int c = t;
-        const uint64_t swap = w[(size_t)24 * N];
-        add_term(gl::mul(f, gl::mul(swap, gl::sub(swap, 1))), c++);
-        uint64_t st[poseidon::W];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          uint64_t l = w[(size_t)k * N], r = w[(size_t)(k + 4) * N], d = w[(size_t)(25 + k) * N];
-          add_term(gl::mul(f, gl::sub(gl::mul(swap, gl::sub(r, l)), d)), c++);
-          st[k] = gl::add(l, d);
-          st[k + 4] = gl::sub(r, d);
-        }
-#pragma unroll
-        for (int k = 8; k < 12; k++) st[k] = w[(size_t)k * N];
-#pragma unroll
-        for (int k = 0; k < 12; k++) st[k] = poseidon::add_const_lazy(st[k], poseidon::rc(k));
-        int rnd = 0;
-#pragma unroll 1
-        for (int r = 0; r < 4; r++, rnd++) {
-          if (r != 0) {
-#pragma unroll
-            for (int k = 0; k < 12; k++) {
-              uint64_t in = w[(size_t)(29 + 12 * (r - 1) + k) * N];
-              add_term(gl::mul(f, gl::sub(gl::canon(st[k]), in)), c++);
-              st[k] = in;
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < 12; k++) st[k] = poseidon::sbox_lazy(st[k]);
-          poseidon::mds_layer(st, (rnd + 1) * 12);
-        }
-#pragma unroll 1
-        for (int r = 0; r < 22; r++, rnd++) {
-          uint64_t in = w[(size_t)(65 + r) * N];
-          add_term(gl::mul(f, gl::sub(gl::canon(st[0]), in)), c++);
-          st[0] = poseidon::sbox_lazy(in);
-          poseidon::mds_layer(st, (rnd + 1) * 12);
-        }
-#pragma unroll 1
-        for (int r = 0; r < 4; r++, rnd++) {
-#pragma unroll
-          for (int k = 0; k < 12; k++) {
-            uint64_t in = w[(size_t)(87 + 12 * r + k) * N];
-            add_term(gl::mul(f, gl::sub(gl::canon(st[k]), in)), c++);
-            st[k] = in;
-          }
-#pragma unroll
-          for (int k = 0; k < 12; k++) st[k] = poseidon::sbox_lazy(st[k]);
-          poseidon::mds_layer(st, rnd + 1 < poseidon::ROUNDS ? (rnd + 1) * 12 : -1);
-        }
-#pragma unroll
-        for (int k = 0; k < 12; k++) add_term(gl::mul(f, gl::sub(gl::canon(st[k]), w[(size_t)(12 + k) * N])), c++);
-        break;
-      }
-      default:  // every other gate: the generic constraint code shared with the host verifier (gates.h)
-        gates::eval<uint64_t>(
-            g, [&](int j) { return w[(size_t)j * N]; }, [&](int j) { return consts[(size_t)j * N]; },
-            [&](int j) { return pih[j]; }, [&](int k, uint64_t v) { add_term(gl::mul(f, v), t + k); });
-        break;
-    }
-  }
-  uint64_t *out = a.out + proof * a.out_stride + i;
+  uint64_t *out = a.acc + proof * a.out_stride + s;
 #pragma unroll
   for (int c = 0; c < MAXC; c++)
-    if (c < nc) out[(size_t)c * N] = gl::mul(acc[c], zh_inv);
+    if (c < nc) out[(size_t)c * N] = gl::canon(acc[c]);
+}
+
+// grid = (N/256, B). Gate `gi` (of type TYPE): acc[c] += filter * sum_k alpha_c^(t0+k) * constraint_k
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_quot_gate(Args a, int gi, int t0) {
+  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= a.N) return;
+  const size_t proof = blockIdx.y;
+  const size_t N = a.N;
+  const uint64_t *cs = a.cs_lde[proof] + s;
+  const uint64_t *w = a.wires_lde + proof * a.wires_stride + s;
+  const uint64_t *apow = a.apow + proof * (size_t)a.nc * a.n_terms + t0;
+  const int nc = a.nc;
+  const Gate g = a.gates[gi];
+
+  uint64_t acc[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; c++) acc[c] = 0;
+  auto add_term = [&](uint64_t term, int idx) {
+#pragma unroll
+    for (int c = 0; c < MAXC; c++)
+      if (c < nc) acc[c] = gl::mul_add_lazy(term, apow[(size_t)c * a.n_terms + idx], acc[c]);  // lazy u64
+  };
+  if constexpr (TYPE == gates::POSEIDON) {
+    // plonky2 PoseidonGate: wires 0..11 in, 12..23 out, 24 swap, 25..28 delta, S-box inputs of full rounds
+    // 1..3 at 29.., of the 22 partial rounds at 65.., of the last 4 full rounds at 87.. (123 constraints).
+    // Textbook round structure with the lazy permutation primitives; anchors are canonicalised.
+    int c = 0;
+    const uint64_t swap = w[(size_t)24 * N];
+    add_term(gl::mul(swap, gl::sub(swap, 1)), c++);
+    uint64_t st[poseidon::W];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint64_t l = w[(size_t)k * N], r = w[(size_t)(k + 4) * N], d = w[(size_t)(25 + k) * N];
+      add_term(gl::sub(gl::mul(swap, gl::sub(r, l)), d), c++);
+      st[k] = gl::add(l, d);
+      st[k + 4] = gl::sub(r, d);
+    }
+#pragma unroll
+    for (int k = 8; k < 12; k++) st[k] = w[(size_t)k * N];
+#pragma unroll
+    for (int k = 0; k < 12; k++) st[k] = poseidon::add_const_lazy(st[k], poseidon::rc(k));
+    int rnd = 0;
+#pragma unroll 1
+    for (int r = 0; r < 4; r++, rnd++) {
+      if (r != 0) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+          uint64_t in = w[(size_t)(29 + 12 * (r - 1) + k) * N];
+          add_term(gl::sub(gl::canon(st[k]), in), c++);
+          st[k] = in;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 12; k++) st[k] = poseidon::sbox_lazy(st[k]);
+      poseidon::mds_layer(st, (rnd + 1) * 12);
+    }
+#pragma unroll 1
+    for (int r = 0; r < 22; r++, rnd++) {
+      uint64_t in = w[(size_t)(65 + r) * N];
+      add_term(gl::sub(gl::canon(st[0]), in), c++);
+      st[0] = poseidon::sbox_lazy(in);
+      poseidon::mds_layer(st, (rnd + 1) * 12);
+    }
+#pragma unroll 1
+    for (int r = 0; r < 4; r++, rnd++) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) {
+        uint64_t in = w[(size_t)(87 + 12 * r + k) * N];
+        add_term(gl::sub(gl::canon(st[k]), in), c++);
+        st[k] = in;
+      }
+#pragma unroll
+      for (int k = 0; k < 12; k++) st[k] = poseidon::sbox_lazy(st[k]);
+      poseidon::mds_layer(st, rnd + 1 < poseidon::ROUNDS ? (rnd + 1) * 12 : -1);
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) add_term(gl::sub(gl::canon(st[k]), w[(size_t)(12 + k) * N]), c++);
+  } else if constexpr (TYPE == gates::POSEIDON_MDS) {
+    // PoseidonMdsGate: 24 coalesced loads up front, then the circulant with its small coefficients in 128-bit
+    // integer arithmetic (sum < 2^64 * 264: one lazy reduction per output) — same values as gates.h's generic form
+    uint64_t in[24];
+#pragma unroll
+    for (int k = 0; k < 24; k++) in[k] = w[(size_t)k * N];
+#pragma unroll
+    for (int r = 0; r < 12; r++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        gl::u128 sum = r == 0 ? (gl::u128)in[h] * 8u : (gl::u128)0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) sum += (gl::u128)in[((k + r) % 12) * 2 + h] * (uint32_t)POSEIDON_MDS_CIRC[k];
+        const uint64_t computed = gl::reduce128((uint64_t)sum, (uint64_t)(sum >> 64));
+        add_term(gl::sub(w[(size_t)(24 + 2 * r + h) * N], computed), 2 * r + h);
+      }
+  } else {  // the generic constraint code shared with the host verifier (gates.h)
+    const uint64_t *consts = cs + (size_t)a.num_selectors * N;
+    const uint64_t *pih = a.pi_hash + proof * 4;
+    gates::eval_t<TYPE, uint64_t>(
+        g, [&](int j) { return w[(size_t)j * N]; }, [&](int j) { return consts[(size_t)j * N]; },
+        [&](int j) { return pih[j]; }, [&](int k, uint64_t v) { add_term(v, k); });
+  }
+  // filter of this gate inside its selector group
+  const uint64_t sv = cs[(size_t)g.selector_index * N];
+  uint64_t f = 1;
+  for (int r = g.group_start; r < g.group_end; r++)
+    if (r != gi) f = gl::mul(f, gl::sub((uint64_t)r, sv));
+  if (a.num_selectors > 1) f = gl::mul(f, gl::sub(UNUSED_SELECTOR, sv));
+  uint64_t *out = a.acc + proof * a.out_stride + s;
+#pragma unroll
+  for (int c = 0; c < MAXC; c++)
+    if (c < nc) out[(size_t)c * N] = gl::add(out[(size_t)c * N], gl::mul(f, acc[c]));
+}
+
+// grid = (N/256, B): t_c(x) = acc / Z_H(x), written to the point's natural position
+__global__ __launch_bounds__(256) void k_quot_finish(Args a) {
+  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= a.N) return;
+  const size_t proof = blockIdx.y;
+  const uint32_t i = __brev((uint32_t)s) >> (32 - a.log_N);
+  const uint64_t zh_inv = a.zh_inv[i & ((1u << a.rb) - 1)];
+  const uint64_t *in = a.acc + proof * a.out_stride + s;
+  uint64_t *out = a.out + proof * a.out_stride + i;
+  for (int c = 0; c < a.nc; c++) out[(size_t)c * a.N] = gl::mul(in[(size_t)c * a.N], zh_inv);
 }
 
 }  // namespace quot
