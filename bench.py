@@ -207,6 +207,28 @@ def main():
                 "note": "integer-VALU bound (Poseidon: no MFMA-shaped work); see roofline_ntt for the "
                         "HBM-bound kernel of this step"}
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # what actually bounds the leaf hash: integer-VALU issue. Instruction counts and busy fractions come from a
+        # separate rocprofv3 --pmc pass of this command (profiles/r01_pmc_valu_bench_v6.json); the rate is this run's.
+        roof_valu = None
+        try:
+            pv = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_valu_bench_v6.json")))["merkle::k_leaf_hash_cols"]
+            if (k, log_n) == (COLS, LOG_N):
+                insts = pv["SQ_INSTS_VALU"]          # wave-level VALU instructions per launch
+                simds, clk = 256 * 4, pv["clock_GHz_est"] * 1e9
+                roof_valu = {"kernel": "leaf_hash_cols", "bound": "valu-issue", "unit": "T lane-ops/s",
+                             "achieved": insts * 64 / (leaf_ms * 1e-3) / 1e12,
+                             "peak": simds * clk / 2 * 64 / 1e12,
+                             "peak_note": "1024 SIMDs x one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md) at the "
+                                          "clock measured under this load (GRBM_GUI_ACTIVE); only an all-VOP2 stream reaches it, "
+                                          "VOP3 / v_mad_u64_u32 issue in 3+ cycles (profiles/r01_ubench_valu.txt)",
+                             "valu_instructions_per_permutation": insts * 64 / perms,
+                             "simd_valu_busy": pv["SQ_ACTIVE_INST_VALU"] / pv["SQ_WAVE_CYCLES"] * 4,
+                             "busy_note": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x 4 resident waves per SIMD (6 fit; the kernel "
+                                          "launches 2^20 lanes = 4 waves per SIMD)",
+                             "wave_issue_stall_frac": pv["wait_inst_any_frac"], "wave_memory_wait_frac": pv["wait_any_frac"]}
+                roof_valu["frac"] = roof_valu["achieved"] / roof_valu["peak"]
+        except (OSError, ValueError, KeyError):
+            roof_valu = None
         # NTT: one pass reads + writes the batch once -> 16 B per element per pass
         pass_bytes = 16.0 * n * k
         ntt_ms = (cols_ms or 0) * (cols_l / max(args.steps, 1)) + (rows_ms or 0) * (rows_l / max(args.steps, 1))
@@ -230,7 +252,7 @@ def main():
             "config": {"workload": "configs[1]: 2^%d-row x %d-column trace, forward NTT per column "
                                    "(natural->bit-reversed) + Poseidon Merkle cap height %d" % (log_n, k, CAP_H),
                        "log_n": log_n, "columns": k, "cap_height": CAP_H, "sharding": "independent traces per GPU"},
-            "roofline": roof, "roofline_ntt": roof_ntt,
+            "roofline": roof, "roofline_valu": roof_valu, "roofline_ntt": roof_ntt,
             "kernels_ms_per_step": {name: d["total_ms"] / args.steps for name, d in prof.items()},
             "poseidon_perms_per_s": (perms / (leaf_ms * 1e-3)) if leaf_ms else None,
             "merkle_levels_ms": lvl["total_ms"] / args.steps,
