@@ -11,6 +11,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -138,6 +139,26 @@ void prof_flush(cp_ctx *ctx) {
     ctx->prof_pool.push_back(r.e1);
   }
   ctx->prof_recs.clear();
+}
+
+// Per-proof host work of a batch (the Fiat-Shamir transcripts are independent across proofs): run body(p) for
+// p < n on a few short-lived threads. The body must not touch the HIP API or the context.
+template <class Body>
+void host_for(size_t n, Body body) {
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t T = n / 4;  // at least four proofs per thread
+  if (T > 8) T = 8;
+  if (hw && T > hw) T = hw;
+  if (T <= 1) {
+    for (size_t p = 0; p < n; p++) body(p);
+    return;
+  }
+  std::vector<std::thread> ths;
+  ths.reserve(T - 1);
+  for (size_t t = 1; t < T; t++)
+    ths.emplace_back([=, &body] { for (size_t p = t; p < n; p += T) body(p); });
+  for (size_t p = 0; p < n; p += T) body(p);
+  for (auto &th : ths) th.join();
 }
 
 double host_now_ms() {
