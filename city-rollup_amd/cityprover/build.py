@@ -25,11 +25,13 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    tmp = "%s.%d.tmp" % (SO, os.getpid())   # several ranks may build at once: private name, atomic rename
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value", "-o", SO] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wno-unused-value", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    os.replace(tmp, SO)
     return SO
 
 

@@ -10,14 +10,22 @@ SO = os.path.join(HERE, "libwitgen.so")
 _lib = None
 
 
+def build():
+    """Compile libwitgen.so if missing or stale. Several ranks may get here at once: build to a private name, then
+    rename atomically."""
+    src = os.path.join(HERE, "witgen.hip")
+    if not os.path.exists(SO) or os.path.getmtime(src) > os.path.getmtime(SO):
+        tmp = "%s.%d.tmp" % (SO, os.getpid())
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC",
+                        "-Wno-unused-value", "-o", tmp, src], check=True)
+        os.replace(tmp, SO)
+    return SO
+
+
 def lib():
     global _lib
     if _lib is None:
-        src = os.path.join(HERE, "witgen.hip")
-        if not os.path.exists(SO) or os.path.getmtime(src) > os.path.getmtime(SO):
-            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC",
-                            "-Wno-unused-value", "-o", SO, src], check=True)
-        _lib = ctypes.CDLL(SO)
+        _lib = ctypes.CDLL(build())
     return _lib
 
 
