@@ -144,6 +144,32 @@ def main():
     prof = prover.profile_end()
     elapsed = D.max_over_ranks(dist, t1 - t0)
 
+    # M2's other transforms: inverse NTT and the rate-8 coset LDE 2^20 -> 2^23 (shift 7), batch 16,
+    # device-resident, HIP events around the whole call. Side measurement (not part of `value`).
+    variants = None
+    if (k, log_n) == (COLS, LOG_N) and not args.no_qbench:
+        vb = 16
+        e0, e1 = prover.event(), prover.event()
+        src = prover.alloc(vb * n)
+        prover.lib.cp_d2d(prover.ctx, src.ptr, data.ptr, vb * n * 8)
+        dst = prover.alloc(vb * (n << 3))
+
+        def timed(fn, reps=5):
+            fn()
+            prover.record(e0)
+            for _ in range(reps):
+                fn()
+            prover.record(e1)
+            return prover.elapsed_ms(e0, e1) / reps
+
+        t_inv = timed(lambda: prover.ntt_dev(src.ptr, log_n, vb, n, cp.NTT_INVERSE))
+        t_lde = timed(lambda: prover.lde_dev(src.ptr, log_n, 3, vb, dst.ptr, 7, cp.NTT_BITREV_OUT))
+        variants = {"batch": vb, "intt_ms_per_poly": t_inv / vb, "lde_rate8_ms_per_poly": t_lde / vb,
+                    "lde_GBs": vb * 8.0 * n * (1 + 8) / (t_lde * 1e-3) / 1e9,
+                    "lde_algorithmic_bytes_per_poly": 8.0 * n * (1 + 8)}
+        src.free()
+        dst.free()
+
     # Second half of BASELINE.json's metric ("block proofs/sec (qbench)"), reported beside the headline:
     # whole-proof throughput of cp_prove_batch on synthetic qbench-shaped jobs (every rank proves its own
     # jobs; 64 plonky2 proofs = one example block). Not part of the timed region above.
@@ -252,7 +278,7 @@ def main():
             "config": {"workload": "configs[1]: 2^%d-row x %d-column trace, forward NTT per column "
                                    "(natural->bit-reversed) + Poseidon Merkle cap height %d" % (log_n, k, CAP_H),
                        "log_n": log_n, "columns": k, "cap_height": CAP_H, "sharding": "independent traces per GPU"},
-            "roofline": roof, "roofline_valu": roof_valu, "roofline_ntt": roof_ntt,
+            "roofline": roof, "roofline_valu": roof_valu, "roofline_ntt": roof_ntt, "ntt_variants": variants,
             "kernels_ms_per_step": {name: d["total_ms"] / args.steps for name, d in prof.items()},
             "poseidon_perms_per_s": (perms / (leaf_ms * 1e-3)) if leaf_ms else None,
             "merkle_levels_ms": lvl["total_ms"] / args.steps,

@@ -177,6 +177,20 @@ def test_ntt_full_size_properties(prover):
     assert (prover.ntt(s) == fs).all()
 
 
+def test_lde_full_size_properties(prover):
+    """BASELINE full size: rate-8 coset LDE 2^20 -> 2^23 (shift 7), 3 polynomials: one oracle column, linearity, and
+    the defining property LDE(c)[8 j] on the sub-coset == coset NTT of c."""
+    import cityprover as cp
+    n = 1 << 20
+    c = felts(3 * n, 77).reshape(3, n)
+    c[2] = ((c[0].astype(object) + c[1].astype(object)) % P).astype(np.uint64)
+    lde = prover.lde(c, 3)
+    assert lde.shape == (3, n << 3)
+    assert (lde[1] == O.coset_lde(c[1], 3, 7)).all()
+    assert (lde[2] == ((lde[0].astype(object) + lde[1].astype(object)) % P).astype(np.uint64)).all()
+    assert (lde[0][::8] == prover.ntt(c[0], flags=cp.NTT_COSET, shift=7)).all()
+
+
 # ---- commit (PolynomialBatch::from_values) ---------------------------------------------------
 @pytest.mark.parametrize("k,log_n,rate,cap_h", [(3, 4, 3, 2), (20, 10, 3, 4), (135, 12, 3, 4), (16, 12, 3, 4),
                                                 (2, 13, 1, 0)])
