@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_pow_grind(const PowState *__restrict__ 
   for (int k = 0; k < 8; k++)
     if (k == pos) s[k] = cand;
   poseidon::permute(s);
-  if ((s[7] >> (64 - pow_bits)) == 0) atomicMin(best + proof, (unsigned long long)cand);
+  if (pow_bits <= 0 || (s[7] >> (64 - pow_bits)) == 0) atomicMin(best + proof, (unsigned long long)cand);
 }
 
 // Query gathering: one workgroup per (query round, proof); writes the bincode words of a FriQueryRound.

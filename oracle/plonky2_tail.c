@@ -24,6 +24,9 @@
 
 void or_ch_init(or_challenger *c) { memset(c, 0, sizeof *c); }
 
+/* plonky2: `response.to_canonical_u64().leading_zeros() >= proof_of_work_bits` (0 bits: always true) */
+static int pow_ok(uint64_t response, int pow_bits) { return pow_bits <= 0 || (response >> (64 - pow_bits)) == 0; }
+
 static void ch_duplex(or_challenger *c) {
   for (int i = 0; i < c->n_in; i++) c->state[i] = c->in[i];
   c->n_in = 0;
@@ -310,12 +313,12 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
       uint64_t t[12]; memcpy(t, st, sizeof t);
       t[pos] = cand;
       or_poseidon_permute(t);
-      if ((t[7] >> (64 - sh->pow_bits)) == 0) { pow_witness = cand; break; }
+      if (pow_ok(t[7], sh->pow_bits)) { pow_witness = cand; break; }
     }
     or_ch_observe(&c, &pow_witness, 1);
     uint64_t resp = or_ch_challenge(&c);
     if (dbg) dbg->pow_response = resp;
-    if (!use_pow_override && (resp >> (64 - sh->pow_bits)) != 0) return -1;
+    if (!use_pow_override && !pow_ok(resp, sh->pow_bits)) return -1;
   }
 
   /* ---- serialise ---- */
@@ -482,7 +485,7 @@ int or_verify_tail(const or_shape *sh, const uint64_t circuit_digest[4], const u
   uint64_t resp = or_ch_challenge(&c);
   if (dbg) { dbg->zeta[0] = zeta.c[0]; dbg->zeta[1] = zeta.c[1]; dbg->pow_response = resp;
              for (int l = 0; l < sh->n_arity; l++) { dbg->fri_betas[l][0] = betas[l].c[0]; dbg->fri_betas[l][1] = betas[l].c[1]; } }
-  if ((resp >> (64 - sh->pow_bits)) != 0) return -8;
+  if (!pow_ok(resp, sh->pow_bits)) return -8;
 
   /* reduced openings: sum alpha^j opening_j per batch */
   gl2_t red0 = gl2_from_base(0), red1 = gl2_from_base(0);
