@@ -53,3 +53,37 @@ def test_random_shape(prover, seed):
     cp.verify(circ, got)
     assert O.verify_full(c["shape"], c["gates"], digest, circ.cs_cap(), got) == 0, cfg
     circ.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_gate_subsets_in_one_batch(prover, seed):
+    """Random subsets of the 21 gate types (plonky2 selector grouping recomputed per subset), three different circuits of
+    one shape proved in ONE batch call."""
+    import cityprover as cp
+    import synth_gates as SG
+    rng = np.random.default_rng(5000 + seed)
+    always = [g for g in SG.ALL_GATES if g[0] in (SG.NOOP, SG.CONSTANT, SG.PUBLIC_INPUT)]
+    rest = [g for g in SG.ALL_GATES if g not in always]
+    pick = [rest[i] for i in sorted(rng.choice(len(rest), size=int(rng.integers(1, 9)), replace=False))]
+    db = int(rng.integers(6, 9))
+    arity = [(2,), (1, 2), (3, 1), (2, 2, 1), ()][int(rng.integers(0, 5))]
+    kw = dict(db=db, arity_bits=arity, cap_height=int(rng.integers(0, 4)), num_query_rounds=int(rng.integers(1, 6)),
+              pow_bits=int(rng.integers(0, 6)))
+    cases = [SG.build_gate_set(always + pick, seed=100 * seed + i, **kw) for i in range(3)]
+    sh = cp_shape_of(cp, cases[0]["shape"])
+    circs = []
+    for i, c in enumerate(cases):
+        circ = cp.Circuit(prover, sh, [seed, i, 7, 7], c["cs_values"])
+        cp.set_gates(circ, c["gate_list"], c["num_selectors"])
+        circs.append(circ)
+    got = cp.prove_batch(prover, circs, [c["public_inputs"] for c in cases], [c["wires"] for c in cases])
+    O.lib().or_set_threads(8)
+    try:
+        for i, c in enumerate(cases):
+            want, _ = O.prove_full(c["shape"], c["gates"], [seed, i, 7, 7], c["public_inputs"], c["cs_values"], c["wires"])
+            assert got[i] == want, (seed, i, [SG._ID[g[0]] for g in pick], kw)
+            cp.verify(circs[i], got[i])
+    finally:
+        O.lib().or_set_threads(1)
+    for c in circs:
+        c.close()
