@@ -76,6 +76,39 @@ def cpu_baseline(cols_host, log_n, cap_h):
     }, work, cap
 
 
+def cpu_port_proof(prover, cores):
+    """M1's CPU figure: ONE whole proof of the qbench workload by the C oracle ("port": a plain
+    restatement, OpenMP over polynomials / leaves / quotient points / PoW candidates — not the optimised Rust prover) on
+    the host cores, and a live parity check: the GPU's bytes for the same job must equal the oracle's."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import oracle_lib as O
+    import bench_prove
+    import cityprover as cp
+    c = bench_prove.cases_for(prover, 4, bench_prove.POSEIDON_FRACTION)[0]
+    sh = cp.standard_recursion_shape(num_constants=c["num_constants"])
+    osh = O.standard_shape(num_constants=c["num_constants"])
+    og = O.make_gates(c["gate_list"], c["num_selectors"], c["k_is"])
+    digest = [0, 1, 2, 3]
+    circ = cp.Circuit(prover, sh, digest, c["cs_values"])
+    cp.set_gates(circ, c["gate_list"], c["num_selectors"])
+    got = cp.prove(circ, c["wires"], c["public_inputs"])
+    circ.close()
+    O.lib().or_set_threads(cores)
+    t0 = time.perf_counter()
+    O.commit_batch(c["cs_values"], 3, 4, want=("cap",))   # circuit data: built once per circuit upstream, not per proof
+    t1 = time.perf_counter()
+    want, _ = O.prove_full(osh, og, digest, c["public_inputs"], c["cs_values"], c["wires"])
+    t2 = time.perf_counter()
+    O.lib().or_set_threads(1)
+    assert got == want, "GPU proof bytes != CPU oracle proof bytes"
+    sec = (t2 - t1) - (t1 - t0)
+    return {"proofs_per_s": 1.0 / sec, "seconds_per_proof": sec, "cores": cores, "kind": "port",
+            "sample": "1 proof of the qbench workload (n = 2^12, city-common gate set); constants/sigmas commitment "
+                      "(%.2f s) subtracted: it belongs to circuit build" % (t1 - t0),
+            "parity": "GPU proof bytes == oracle proof bytes (%d B)" % len(got)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,7 +220,10 @@ def main():
         pps = D.sum_over_ranks(dist, rt["proofs_per_s_steady"])
         pps1 = D.sum_over_ranks(dist, r1["proofs_per_s"])
         bps = D.sum_over_ranks(dist, rp["blocks_per_s"])
-        qb = {"proofs_per_s": pps, "blocks_per_s": pps / 64.0, "proofs_per_s_single_context": pps1,
+        cpu_m1 = None
+        if rank == 0 and not args.no_cpu_baseline:
+            cpu_m1 = cpu_port_proof(prover, min(len(os.sched_getaffinity(0)), 64))
+        qb = {"cpu_baseline": cpu_m1, "proofs_per_s": pps, "blocks_per_s": pps / 64.0, "proofs_per_s_single_context": pps1,
               "batch": 32, "contexts_per_gpu": 3, "proof_bytes": r1["proof_bytes"],
               "timing": "wall clock from a common start until the last of 3 contexts has finished 8 batches of 32; wire "
                         "matrices start in page-locked HOST memory (PCIe-inclusive), proofs end in host memory",

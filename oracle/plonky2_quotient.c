@@ -19,6 +19,9 @@
 
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define UNUSED_SELECTOR 0xFFFFFFFFULL /* u32::MAX */
 
@@ -290,22 +293,33 @@ int or_quotient_polys(const or_shape *sh, const or_gates *G, const uint64_t pi_h
   for (int i = 0; i < (1 << rb); i++) { zh[i] = gl_sub(gl_mul(gpn, gl_pow(w8, i)), 1); zh_inv[i] = gl_inv(zh[i]); }
   uint64_t omegaN = gl_root_of_unity(db + rb);
   uint64_t *vals = (uint64_t *)malloc((size_t)nc * N * 8); /* natural order */
-  gl2_t *consts = (gl2_t *)malloc((size_t)(ncst + W + R + 4 * nc + nc * npp) * sizeof(gl2_t));
-  gl2_t *wires = consts + ncst, *sig = wires + W, *zs = sig + R, *zsn = zs + nc, *pps = zsn + nc;
-  uint64_t x = GL_GENERATOR; /* coset point of natural index i */
-  for (size_t i = 0; i < N; i++) {
-    size_t s = bitrev_sz(i, db + rb), sn = bitrev_sz((i + ((size_t)1 << rb)) % N, db + rb);
-    for (int j = 0; j < ncst; j++) consts[j] = gl2_from_base(cs_lde[(size_t)j * N + s]);
-    for (int j = 0; j < R; j++) sig[j] = gl2_from_base(cs_lde[(size_t)(ncst + j) * N + s]);
-    for (int j = 0; j < W; j++) wires[j] = gl2_from_base(wires_lde[(size_t)j * N + s]);
-    for (int c = 0; c < nc; c++) { zs[c] = gl2_from_base(zs_lde[(size_t)c * N + s]); zsn[c] = gl2_from_base(zs_lde[(size_t)c * N + sn]); }
-    for (int j = 0; j < nc * npp; j++) pps[j] = gl2_from_base(zs_lde[(size_t)(nc + j) * N + s]);
-    /* L_0(x) = Z_H(x) / (n (x - 1)) */
-    uint64_t l0 = gl_mul(zh[i & ((1 << rb) - 1)], gl_inv(gl_mul((uint64_t)n, gl_sub(x, 1))));
-    gl2_t res[8];
-    eval_vanishing(&v, gl2_from_base(x), gl2_from_base(l0), consts, wires, zs, zsn, pps, sig, betas, gammas, alphas, res);
-    for (int c = 0; c < nc; c++) vals[(size_t)c * N + i] = gl_mul(res[c].c[0], zh_inv[i & ((1 << rb) - 1)]);
-    x = gl_mul(x, omegaN);
+  /* points are independent: the same axis rayon splits upstream (or_set_threads workers, contiguous ranges) */
+#pragma omp parallel num_threads(or_get_threads())
+  {
+    gl2_t *consts = (gl2_t *)malloc((size_t)(ncst + W + R + 4 * nc + nc * npp) * sizeof(gl2_t));
+    gl2_t *wires = consts + ncst, *sig = wires + W, *zs = sig + R, *zsn = zs + nc, *pps = zsn + nc;
+    int nt = 1, tid = 0;
+#ifdef _OPENMP
+    nt = omp_get_num_threads();
+    tid = omp_get_thread_num();
+#endif
+    const size_t lo = N * (size_t)tid / (size_t)nt, hi = N * (size_t)(tid + 1) / (size_t)nt;
+    uint64_t x = gl_mul(GL_GENERATOR, gl_pow(omegaN, lo)); /* coset point of natural index i */
+    for (size_t i = lo; i < hi; i++) {
+      size_t s = bitrev_sz(i, db + rb), sn = bitrev_sz((i + ((size_t)1 << rb)) % N, db + rb);
+      for (int j = 0; j < ncst; j++) consts[j] = gl2_from_base(cs_lde[(size_t)j * N + s]);
+      for (int j = 0; j < R; j++) sig[j] = gl2_from_base(cs_lde[(size_t)(ncst + j) * N + s]);
+      for (int j = 0; j < W; j++) wires[j] = gl2_from_base(wires_lde[(size_t)j * N + s]);
+      for (int c = 0; c < nc; c++) { zs[c] = gl2_from_base(zs_lde[(size_t)c * N + s]); zsn[c] = gl2_from_base(zs_lde[(size_t)c * N + sn]); }
+      for (int j = 0; j < nc * npp; j++) pps[j] = gl2_from_base(zs_lde[(size_t)(nc + j) * N + s]);
+      /* L_0(x) = Z_H(x) / (n (x - 1)) */
+      uint64_t l0 = gl_mul(zh[i & ((1 << rb) - 1)], gl_inv(gl_mul((uint64_t)n, gl_sub(x, 1))));
+      gl2_t res[8];
+      eval_vanishing(&v, gl2_from_base(x), gl2_from_base(l0), consts, wires, zs, zsn, pps, sig, betas, gammas, alphas, res);
+      for (int c = 0; c < nc; c++) vals[(size_t)c * N + i] = gl_mul(res[c].c[0], zh_inv[i & ((1 << rb) - 1)]);
+      x = gl_mul(x, omegaN);
+    }
+    free(consts);
   }
   /* coset iFFT: values on 7*<omega_N> -> coefficients; chunk j of challenge c = coeffs[j*n .. (j+1)*n) */
   uint64_t ginv = gl_inv(GL_GENERATOR);
@@ -316,7 +330,7 @@ int or_quotient_polys(const or_shape *sh, const or_gates *G, const uint64_t pi_h
     for (size_t i = 0; i < N; i++) { p[i] = gl_mul(p[i], sp); sp = gl_mul(sp, ginv); }
     memcpy(out_coeffs + (size_t)c * N, p, N * 8);
   }
-  free(vals); free(consts);
+  free(vals);
   return 0;
 }
 

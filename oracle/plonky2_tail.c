@@ -12,8 +12,12 @@
  * tests/golden (tests/test_oracle_fri_reference.py). Transcript order and the batching order of the
  * opened polynomials are NOT pinned by reference data ("parity unpinned" for those two facts).
  */
+#define _POSIX_C_SOURCE 200809L
 #include "cityoracle.h"
 #include "goldilocks.h"
+
+#include <stdio.h>
+#include <time.h>
 
 #include <stdlib.h>
 #include <string.h>
@@ -173,10 +177,17 @@ int or_prove_full(const or_shape *sh, const or_gates *G, const uint64_t circuit_
                     pow_override, proof_out, proof_len, dbg);
 }
 
+/* OR_TIMING=1 in the environment prints the wall time of each phase to stderr (bench diagnostics only) */
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+#define PHASE(name) do { if (timing) { double t_ = now_s(); fprintf(stderr, "[oracle] %-18s %.3f s\n", phase_name, t_ - phase_t0); phase_t0 = t_; } phase_name = name; } while (0)
+
 static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circuit_digest[4], const uint64_t *public_inputs, size_t n_pi,
                       const uint64_t *cs_values, const uint64_t *wires_values, const uint64_t *zs_pp_values,
                       const uint64_t *quotient_coeffs, int use_pow_override, uint64_t pow_override,
                       uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg) {
+  const int timing = getenv("OR_TIMING") != NULL;
+  double phase_t0 = now_s();
+  const char *phase_name = "commit cs+wires";
   const int db = sh->degree_bits, rb = sh->rate_bits, ch = sh->cap_height;
   const size_t n = (size_t)1 << db, N = n << rb;
   const size_t k_cs = sh->num_constants + sh->num_routed_wires, k_w = sh->num_wires;
@@ -199,20 +210,24 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
   for (int i = 0; i < sh->num_challenges; i++) betas[i] = or_ch_challenge(&c);
   for (int i = 0; i < sh->num_challenges; i++) gammas[i] = or_ch_challenge(&c);
   uint64_t *own_zs = NULL, *own_q = NULL;
+  PHASE("zs");
   if (G) { /* A7 */
     own_zs = (uint64_t *)malloc(k_z * n * 8);
     or_zs_partial_products(sh, wires_values, cs_values + (size_t)sh->num_constants * n, G->k_is, betas, gammas, own_zs);
     zs_pp_values = own_zs;
   }
+  PHASE("commit zs");
   batch_from_values(&B[2], zs_pp_values, k_z, db, rb, ch);
   or_ch_observe(&c, B[2].cap, cap_n * 4);
   for (int i = 0; i < sh->num_challenges; i++) alphas[i] = or_ch_challenge(&c);
+  PHASE("quotient");
   if (G) { /* A8 */
     own_q = (uint64_t *)malloc(k_q * n * 8);
     int qrc = or_quotient_polys(sh, G, pi_hash, B[0].lde, B[1].lde, B[2].lde, betas, gammas, alphas, own_q);
     if (qrc) return -200 + qrc;
     quotient_coeffs = own_q;
   }
+  PHASE("commit quotient");
   batch_from_coeffs(&B[3], quotient_coeffs, k_q, db, rb, ch);
   free(own_zs);
   free(own_q);
@@ -225,6 +240,7 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
     dbg->zeta[0] = zeta.c[0]; dbg->zeta[1] = zeta.c[1];
   }
 
+  PHASE("openings");
   /* openings: every polynomial at zeta, the Z polynomials also at g*zeta */
   size_t k_all = k_cs + k_w + k_z + k_q;
   gl2_t *open = (gl2_t *)malloc(k_all * sizeof(gl2_t));
@@ -239,6 +255,7 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
   for (size_t i = 0; i < k_all; i++) or_ch_observe(&c, open[i].c, 2);
   for (int i = 0; i < sh->num_challenges; i++) or_ch_observe(&c, open_next[i].c, 2);
 
+  PHASE("fri batch poly");
   /* ---- FRI batch polynomial: final = alpha^(#batch1) * Q0 + Q1 ---- */
   gl2_t fri_alpha = ch_ext(&c);
   gl2_t *fin = (gl2_t *)calloc(N, sizeof(gl2_t)); /* LDE-padded coefficient vector */
@@ -270,6 +287,7 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
   gl2_t *vals = (gl2_t *)malloc(N * sizeof(gl2_t));
   ext_coset_ntt(fin, db + rb, GL_GENERATOR, vals);
 
+  PHASE("fri commit");
   /* ---- commit phase ---- */
   fri_trees_t T; memset(&T, 0, sizeof T);
   T.n_layers = sh->n_arity;
@@ -302,6 +320,7 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
   size_t final_len = clen >> rb;
   for (size_t i = 0; i < final_len; i++) or_ch_observe(&c, coeffs[i].c, 2);
 
+  PHASE("pow");
   /* ---- proof of work: smallest witness whose response has >= pow_bits leading zeros ---- */
   uint64_t pow_witness = 0;
   {
@@ -309,11 +328,16 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
     for (int i = 0; i < c.n_in; i++) st[i] = c.in[i];
     int pos = c.n_in;
     if (use_pow_override) pow_witness = pow_override;
-    else for (uint64_t cand = 0;; cand++) {
-      uint64_t t[12]; memcpy(t, st, sizeof t);
-      t[pos] = cand;
-      or_poseidon_permute(t);
-      if (pow_ok(t[7], sh->pow_bits)) { pow_witness = cand; break; }
+    else for (uint64_t base = 0;; base += 4096) { /* smallest witness; blocks of candidates tried in parallel */
+      uint64_t found = UINT64_MAX;
+#pragma omp parallel for num_threads(or_get_threads()) schedule(static) reduction(min : found)
+      for (long long k = 0; k < 4096; k++) {
+        uint64_t t[12]; memcpy(t, st, sizeof t);
+        t[pos] = base + (uint64_t)k;
+        or_poseidon_permute(t);
+        if (pow_ok(t[7], sh->pow_bits) && base + (uint64_t)k < found) found = base + (uint64_t)k;
+      }
+      if (found != UINT64_MAX) { pow_witness = found; break; }
     }
     or_ch_observe(&c, &pow_witness, 1);
     uint64_t resp = or_ch_challenge(&c);
@@ -321,6 +345,7 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
     if (!use_pow_override && !pow_ok(resp, sh->pow_bits)) return -1;
   }
 
+  PHASE("queries+serialise");
   /* ---- serialise ---- */
   buf_t out = {0};
   for (int b = 1; b <= 3; b++) { buf_u64(&out, cap_n); buf_felts(&out, B[b].cap, cap_n * 4); }
@@ -554,13 +579,13 @@ void or_zs_partial_products(const or_shape *sh, const uint64_t *wires_values, co
   const int nchunks = (R + chunk - 1) / chunk; /* == npp + 1 */
   const int nc = sh->num_challenges;
   uint64_t omega = gl_root_of_unity(sh->degree_bits);
-  for (int c = 0; c < nc; c++) {
-    uint64_t *Z = out + (size_t)c * n;
-    uint64_t *PP = out + ((size_t)nc + (size_t)c * npp) * n;
-    uint64_t z = 1, x = 1;
-    for (size_t i = 0; i < n; i++) {
-      uint64_t acc = z;
-      Z[i] = z;
+  /* phase 1 (rows are independent: or_set_threads workers): the quotient of every chunk of every row */
+  uint64_t *q = (uint64_t *)malloc((size_t)nc * nchunks * n * 8);
+#pragma omp parallel for num_threads(or_get_threads()) schedule(static)
+  for (long long ii = 0; ii < (long long)n; ii++) {
+    const size_t i = (size_t)ii;
+    const uint64_t x = gl_pow(omega, i);
+    for (int c = 0; c < nc; c++)
       for (int t = 0; t < nchunks; t++) {
         uint64_t prod = 1;
         for (int j = t * chunk; j < R && j < (t + 1) * chunk; j++) {
@@ -569,11 +594,23 @@ void or_zs_partial_products(const or_shape *sh, const uint64_t *wires_values, co
           uint64_t den = gl_add(gl_add(w, gl_mul(betas[c], sigma_values[(size_t)j * n + i])), gammas[c]);
           prod = gl_mul(prod, gl_mul(num, gl_inv(den)));
         }
-        acc = gl_mul(acc, prod);
+        q[((size_t)c * nchunks + t) * n + i] = prod;
+      }
+  }
+  /* phase 2: the running product down the rows */
+  for (int c = 0; c < nc; c++) {
+    uint64_t *Z = out + (size_t)c * n;
+    uint64_t *PP = out + ((size_t)nc + (size_t)c * npp) * n;
+    uint64_t z = 1;
+    for (size_t i = 0; i < n; i++) {
+      uint64_t acc = z;
+      Z[i] = z;
+      for (int t = 0; t < nchunks; t++) {
+        acc = gl_mul(acc, q[((size_t)c * nchunks + t) * n + i]);
         if (t < npp) PP[(size_t)t * n + i] = acc;
       }
       z = acc; /* Z(g x) */
-      x = gl_mul(x, omega);
     }
   }
+  free(q);
 }
