@@ -165,6 +165,30 @@ def example_bin():
     return cfg, index, deltas, proofs
 
 
+def example_job_dag():
+    """The job DAG `plan_jobs` left in the dump (counter / goal / next-jobs triplets, proof_store.rs:41-87): per job
+    group (topic, circuit_type, group_id, sub_group_id) the number of completions it waits for (`goal`) and the jobs it
+    releases then. Data only."""
+    b = open(f"{REF}/qbench_data/example.bin", "rb").read()
+    r = Rd(b)
+    r.u64(); r.u32(); [r.u64() for _ in range(6)]
+    groups = {}
+    for _ in range(r.u64()):
+        k = parse_key(r.raw(24))
+        val = r.raw(r.u64())
+        if k["data_type"] != 16:
+            continue
+        g = groups.setdefault((k["topic"], k["circuit_type"], k["group_id"], k["sub_group_id"]), {})
+        if k["data_index"] == 1:
+            g["goal"] = struct.unpack("<I", val)[0]
+        elif k["data_index"] == 2:
+            m = struct.unpack("<Q", val[:8])[0]
+            assert len(val) == 8 + 24 * m
+            nxt = [parse_key(val[8 + 24 * i:8 + 24 * (i + 1)]) for i in range(m)]
+            g["next"] = [[x["topic"], x["circuit_type"], x["group_id"], x["sub_group_id"], x["task_index"]] for x in nxt]
+    return [{"group": list(k), "goal": v["goal"], "next": v["next"]} for k, v in sorted(groups.items())]
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; golden files are already committed")
@@ -177,6 +201,7 @@ def main():
     cfg, index, deltas, proofs = example_bin()
     json.dump({"config": cfg, "entries": index}, open(f"{OUT}/example_dump_index.json", "w"))
     json.dump(deltas, open(f"{OUT}/example_delta_merkle.json", "w"))
+    json.dump(example_job_dag(), open(f"{OUT}/example_job_dag.json", "w"), indent=0)
     # reference ProofWithPublicInputs blobs (bincode), kept verbatim as binary data:
     # the first two WrappedSignatureProof (circuit_type 64) and the first Secp256K1SignatureProof (65)
     kept = []

@@ -22,8 +22,52 @@ def test_block_dag_shape():
         assert all(d in seen for d in deps), n
         seen.add(n)
     assert Q.critical_path(dag) == 10   # leaf, agg, agg, part, min, transition, min, final, min, wrap
+    assert len(Q.job_dag()) == 46
     final = dict(dag)["sighash_final0"]
     assert "state_transition/min" in final and sum(d.endswith("/wrapper") for d in final) == 3
+
+
+def test_job_dag_equals_the_one_in_example_bin(golden_dir):
+    """The job DAG the replay uses == the DAG `plan_jobs` left in qbench_data/example.bin (counter / goal / next-jobs
+    triplets, extracted by tests/golden/make_golden.py): same jobs per (circuit type, sub group), and a job waits for
+    exactly the jobs of the groups that release it (barrier groups of topic 4 resolved transitively)."""
+    import json
+    fx = json.load(open(os.path.join(golden_dir, "example_job_dag.json")))
+    groups = {tuple(g["group"]): g for g in fx}
+    # group -> the job groups whose completion releases it, looking through the AggregateJobs barriers (topic 4)
+    released_by = {}
+    for gk, g in groups.items():
+        for nxt in g["next"]:
+            released_by.setdefault(tuple(nxt[:4]), set()).add(gk)
+
+    def real_sources(gk):
+        out = set()
+        for src in released_by.get(gk, ()):
+            out |= real_sources(src) if src[0] == 4 else {src}
+        return out
+
+    want = {}   # (circuit_type, sub_group) -> (number of jobs, set of (circuit_type, sub_group) it waits for)
+    for gk, g in groups.items():
+        if gk[0] != 0:
+            continue
+        targets = {tuple(n[:4]) for n in g["next"]}
+        want.setdefault((gk[1], gk[3]), [g["goal"], set()])
+        for t in targets:
+            if t[0] == 0:
+                n_jobs = sum(1 for n in g["next"] if tuple(n[:4]) == t)
+                want.setdefault((t[1], t[3]), [n_jobs, set()])
+    for gk in groups:
+        if gk[0] == 0:
+            want[(gk[1], gk[3])][1] = {(s[1], s[3]) for s in real_sources(gk)}
+    want = {k: (v[0], v[1]) for k, v in want.items()}
+
+    got = {}
+    key_of = {name: key for name, key, _ in Q.job_dag()}
+    for name, key, deps in Q.job_dag():
+        n, d = got.get(key[:2], (0, set()))
+        got[key[:2]] = (n + 1, d | {key_of[x][:2] for x in deps})
+    assert got == want
+    assert sum(n for n, _ in got.values()) == 46   # the 46 GenerateStandardProof jobs of the block (BASELINE.md §2)
 
 
 def test_scheduler_respects_dependencies():
