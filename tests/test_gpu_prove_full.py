@@ -166,3 +166,58 @@ def test_host_memory_entry_points(prover):
     dw.free()
     for c in circs:
         c.close()
+
+
+def test_contexts_in_parallel_are_deterministic():
+    """Three contexts on one GPU proving concurrently from three host threads (the bench / worker set-up): every proof
+    must equal the one a single context produces for the same job — no cross-context interference through the
+    page-locked staging ring, the arena or the cached tables."""
+    import threading
+    import cityprover as cp
+    cases = [build(db=9, num_routed=24, num_wires=30, chunk=8, rate_bits=3, arity_bits=(2, 2), seed=500 + i, pow_bits=6)
+             for i in range(4)]
+    B, iters, T = 8, 6, 3
+    pick = [i % len(cases) for i in range(B)]
+
+    def make(p):
+        sh = cp_shape_of(cp, cases[0]["shape"])
+        circs = []
+        for i, c in enumerate(cases):
+            circ = cp.Circuit(p, sh, [i, 4, 4, 4], c["cs_values"])
+            cp.set_gates(circ, c["gate_list"], 1)
+            circs.append(circ)
+        return circs
+
+    def run(p, circs):
+        return cp.prove_batch(p, [circs[i] for i in pick], [cases[i]["public_inputs"] for i in pick],
+                              [cases[i]["wires"] for i in pick])
+
+    p0 = cp.Prover(0)
+    c0 = make(p0)
+    want = run(p0, c0)
+    for i in range(len(cases)):
+        assert want[i] == want[i + len(cases)]          # same job twice in one batch
+    for c in c0:
+        c.close()
+    p0.close()
+    errors = []
+
+    def worker(t):
+        try:
+            p = cp.Prover(0)
+            circs = make(p)
+            for _ in range(iters):
+                if run(p, circs) != want:
+                    errors.append("thread %d: proof bytes differ" % t)
+            for c in circs:
+                c.close()
+            p.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append("thread %d: %r" % (t, e))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
