@@ -141,6 +141,49 @@ def fast_partial(RC):
     return first, K, vs, whats, init
 
 
+def plane_constants(RC):
+    """Partial-round constants pushed forward through the MDS (the form poseidon.h runs): round 0 of the partial
+    rounds gets its whole constant vector (folded into the preceding full round), round i >= 1 only a scalar K[i] on
+    element 0 — the rest of its vector commutes with the element-0 S-box and is carried through M into the next round —
+    and what is still pending after the last partial round, plus the next full round's constants, is LAST."""
+    M = mds_matrix()
+    c = [RC[(RF_HALF + i) * W:(RF_HALF + i + 1) * W] for i in range(RP)]
+    K = [0] * RP
+    R = [0] * W
+    for i in range(1, RP):
+        pend = matvec(M, R)
+        Pi = [(c[i][j] + pend[j]) % P for j in range(W)]
+        K[i] = Pi[0]
+        R = [0] + Pi[1:]
+    nxt = RC[(RF_HALF + RP) * W:(RF_HALF + RP + 1) * W]
+    pend = matvec(M, R)
+    return K, [(nxt[j] + pend[j]) % P for j in range(W)]
+
+
+def perm_planes(s, RC, K, LAST):
+    s = list(s)
+    M = mds_matrix()
+    r = 0
+    for _ in range(RF_HALF):
+        s = [(s[i] + RC[r * W + i]) % P for i in range(W)]
+        s = [pow(x, 7, P) for x in s]
+        s = matvec(M, s)
+        r += 1
+    s = [(s[i] + RC[r * W + i]) % P for i in range(W)]
+    for i in range(RP):
+        s[0] = pow((s[0] + K[i]) % P, 7, P)
+        s = matvec(M, s)
+    s = [(s[i] + LAST[i]) % P for i in range(W)]
+    r = RF_HALF + RP
+    for _ in range(RF_HALF):
+        s = [pow(x, 7, P) for x in s]
+        s = matvec(M, s)
+        r += 1
+        if r < 2 * RF_HALF + RP:
+            s = [(s[i] + RC[r * W + i]) % P for i in range(W)]
+    return s
+
+
 def perm_fast(s, RC, tabs):
     first, K, vs, whats, init = tabs
     s = list(s)
@@ -186,6 +229,10 @@ def main():
         assert perm_fast(s, RC, tabs) == perm_naive(s, RC)
     first, K, vs, whats, init = tabs
     assert K[-1] == 0
+    PK, PLAST = plane_constants(RC)
+    for _ in range(4):
+        s = [rnd.randrange(P) for _ in range(W)]
+        assert perm_planes(s, RC, PK, PLAST) == perm_naive(s, RC)
     g32 = pow(7, (P - 1) >> 32, P)
     roots = [pow(g32, 1 << (32 - k), P) for k in range(33)]
     out = "// GENERATED by gen_tables.py — do not edit. Poseidon-Goldilocks (t=12, x^7, 4+22+4) and NTT constants.\n"
@@ -197,6 +244,9 @@ def main():
     out += c_array("POSEIDON_FAST_VS", [x for row in vs for x in row], 11)
     out += c_array("POSEIDON_FAST_WHATS", [x for row in whats for x in row], 11)
     out += c_array("POSEIDON_FAST_INIT", [x for row in init for x in row], 11)
+    out += "// partial-round constants pushed forward through the MDS (gen_tables.plane_constants)\n"
+    out += c_array("POSEIDON_PLANE_K", PK)
+    out += c_array("POSEIDON_PLANE_LAST", PLAST)
     out += "// primitive 2^k-th roots of unity, k = 0..32 (7^((p-1)/2^k))\n"
     out += c_array("GL_ROOTS", roots)
     out += c_array("GL_ROOTS_INV", [pow(r, P - 2, P) for r in roots])

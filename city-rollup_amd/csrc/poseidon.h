@@ -38,6 +38,23 @@ GL_HD uint64_t rc(int i) {
   return POSEIDON_RC[i];
 #endif
 }
+// partial-round constants pushed forward through the MDS (see `permute`)
+__constant__ uint64_t d_PK[22];
+__constant__ uint64_t d_PLAST[12];
+GL_HD uint64_t plane_k(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return d_PK[i];
+#else
+  return POSEIDON_PLANE_K[i];
+#endif
+}
+GL_HD uint64_t plane_last(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return d_PLAST[i];
+#else
+  return POSEIDON_PLANE_LAST[i];
+#endif
+}
 
 // ---- lazy field helpers: inputs/outputs are arbitrary u64 congruent to the value ----------
 GL_HD uint64_t mul_lazy(uint64_t a, uint64_t b) {
@@ -168,8 +185,9 @@ GL_HD void mds_layer(uint64_t (&s)[W], int next_rc_base) {
     s[i] = recombine(y0[i], y1[i], y2[i], next_rc_base >= 0 ? rc(next_rc_base + i) : 0);
 }
 
-// Textbook round structure: 30 x (constants, S-box, MDS); state lazy, canonical on exit.
-GL_HD void permute(uint64_t (&s)[W]) {
+// Textbook round structure: 30 x (constants, S-box, MDS); state lazy, canonical on exit. Kept as the plain
+// statement of the permutation (tests compare `permute` with it); the kernels use `permute` below.
+GL_HD void permute_textbook(uint64_t (&s)[W]) {
 #pragma unroll
   for (int i = 0; i < W; i++) s[i] = add_const_lazy(s[i], rc(i));
 #pragma unroll 1
@@ -182,6 +200,69 @@ GL_HD void permute(uint64_t (&s)[W]) {
   for (int r = HALF_FULL; r < HALF_FULL + PARTIAL; r++) {
     s[0] = sbox_lazy(s[0]);
     mds_layer(s, (r + 1) * W);
+  }
+#pragma unroll 1
+  for (int r = HALF_FULL + PARTIAL; r < ROUNDS; r++) {
+#pragma unroll
+    for (int i = 0; i < W; i++) s[i] = sbox_lazy(s[i]);
+    mds_layer(s, r + 1 < ROUNDS ? (r + 1) * W : -1);
+  }
+#pragma unroll
+  for (int i = 0; i < W; i++) s[i] = gl::canon(s[i]);
+}
+
+// ---- partial rounds with the state resident in limb planes ------------------------------------------------
+// Only element 0 meets an S-box in a partial round; the other eleven go from one MDS straight into the next.
+// They therefore stay in their three 22-bit limb planes for all 22 rounds: after each MDS a carry
+// normalisation (13 integer ops per element) replaces recombine-to-u64 + split-again (24), and they need no
+// round constants at all — those are pushed forward through the MDS offline (gen_tables.plane_constants:
+// a scalar K[i] on element 0 per round, one vector LAST at the end).
+GL_HD void split3(uint64_t v, uint32_t &a, uint32_t &b, uint32_t &c) {
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  a = lo & 0x3FFFFFu;
+  b = ((lo >> 22) | (hi << 10)) & 0x3FFFFFu;
+  c = hi >> 12;
+}
+// MDS outputs of one element (y0, y1 < 2^31.1, y2 < 2^28.1) -> limbs l0, l1 < 2^23, l2 < 2^20 of a congruent value.
+// The part above 2^64 (top) is folded with 2^64 == 2^32 - 1: +top*2^10 on plane 1, -top on plane 0, the latter
+// paid for by borrowing one unit of plane 1 (only when top != 0, so nothing ever goes negative).
+GL_HD void renorm(uint32_t y0, uint32_t y1, uint32_t y2, uint32_t &l0, uint32_t &l1, uint32_t &l2) {
+  const uint32_t t1 = y1 + (y0 >> 22);
+  const uint32_t t2 = y2 + (t1 >> 22);
+  const uint32_t top = t2 >> 20;
+  const uint32_t adj = top < 1u ? top : 1u;
+  l0 = (y0 & 0x3FFFFFu) + (adj << 22) - top;
+  l1 = (t1 & 0x3FFFFFu) + (top << 10) - adj;
+  l2 = t2 & 0xFFFFFu;
+}
+
+GL_HD void permute(uint64_t (&s)[W]) {
+#pragma unroll
+  for (int i = 0; i < W; i++) s[i] = add_const_lazy(s[i], rc(i));
+#pragma unroll 1
+  for (int r = 0; r < HALF_FULL; r++) {
+#pragma unroll
+    for (int i = 0; i < W; i++) s[i] = sbox_lazy(s[i]);
+    mds_layer(s, (r + 1) * W);  // r = 3: adds the whole constant vector of the first partial round
+  }
+  {
+    uint32_t l0[W], l1[W], l2[W], y0[W], y1[W], y2[W];
+#pragma unroll
+    for (int k = 1; k < W; k++) split3(s[k], l0[k], l1[k], l2[k]);
+    uint64_t x0 = s[0];
+#pragma unroll 1
+    for (int i = 0; i < PARTIAL; i++) {
+      x0 = sbox_lazy(x0);
+      split3(x0, l0[0], l1[0], l2[0]);
+      mds_limb(l0, y0);
+      mds_limb(l1, y1);
+      mds_limb(l2, y2);
+#pragma unroll
+      for (int k = 0; k < W; k++) renorm(y0[k], y1[k], y2[k], l0[k], l1[k], l2[k]);
+      if (i + 1 < PARTIAL) x0 = recombine(l0[0], l1[0], l2[0], plane_k(i + 1));
+    }
+#pragma unroll
+    for (int k = 0; k < W; k++) s[k] = recombine(l0[k], l1[k], l2[k], plane_last(k));
   }
 #pragma unroll 1
   for (int r = HALF_FULL + PARTIAL; r < ROUNDS; r++) {

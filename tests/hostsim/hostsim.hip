@@ -13,6 +13,16 @@ void hs_poseidon_permute(uint64_t *states, size_t n) {
     for (int k = 0; k < 12; k++) states[12 * i + k] = s[k];
   }
 }
+void hs_poseidon_permute_textbook(uint64_t *states, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    uint64_t s[12];
+    for (int k = 0; k < 12; k++) s[k] = states[12 * i + k];
+    poseidon::permute_textbook(s);
+    for (int k = 0; k < 12; k++) states[12 * i + k] = s[k];
+  }
+}
+// carry normalisation of the plane-resident partial rounds: returns the limbs; value must be preserved mod p
+void hs_renorm(const uint32_t *y, uint32_t *l) { poseidon::renorm(y[0], y[1], y[2], l[0], l[1], l[2]); }
 uint64_t hs_mul(uint64_t a, uint64_t b) { return gl::mul(a, b); }
 uint64_t hs_mul_lazy(uint64_t a, uint64_t b) { return poseidon::mul_lazy(a, b); }
 uint64_t hs_add(uint64_t a, uint64_t b) { return gl::add(a, b); }

@@ -92,3 +92,38 @@ def test_radix16_register_butterfly_is_a_16_point_dif_ntt(hs):
     inv16 = pow(16, P - 2, P)
     want = O.bit_reverse(O.intt(x))
     assert [int(v) * inv16 % P for v in got] == [int(v) for v in want]
+
+
+def test_plane_resident_permute_equals_textbook(hs):
+    """`permute` (partial rounds resident in limb planes, constants pushed forward) == `permute_textbook` == oracle, on
+    random states and on states full of boundary words."""
+    hs.hs_poseidon_permute_textbook.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t]
+    rng = np.random.default_rng(9)
+    st = O.splitmix64_felts(7, 12 * 400).reshape(-1, 12)
+    edge = np.array([0, 1, 2, P - 1, P - 2, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000, 0xFFFFFFFE00000001,
+                     1 << 63, 0x3FFFFF, 0x400000, 0xFFFFF00000000000, 0xFFFFEFFFFFFFFFFF], np.uint64)
+    for i in range(200):   # rows built only from boundary words
+        st[i] = rng.choice(edge, 12)
+    a, b = st.copy(), st.copy()
+    p64 = ctypes.POINTER(ctypes.c_uint64)
+    hs.hs_poseidon_permute(a.ctypes.data_as(p64), a.shape[0])
+    hs.hs_poseidon_permute_textbook(b.ctypes.data_as(p64), b.shape[0])
+    assert (a == b).all()
+    assert (a == O.permute_many(st).reshape(-1, 12)).all()
+
+
+def test_renorm_preserves_the_value_and_bounds(hs):
+    """Carry normalisation of MDS outputs: limbs within their bounds, value congruent mod p, for extreme inputs."""
+    hs.hs_renorm.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 2
+    rng = np.random.default_rng(3)
+    hi01, hi2 = 264 * (1 << 23), 264 * (1 << 20)     # largest outputs the MDS can produce from normalised limbs
+    cases = [(0, 0, 0), (hi01 - 1, hi01 - 1, hi2 - 1), (0, 0, hi2 - 1), ((1 << 22) - 1, (1 << 22) - 1, (1 << 20) - 1),
+             (0, 0, 1 << 20), (5, 0, 1 << 20), (0, (1 << 22) - 1, (1 << 20) - 1), ((1 << 22), 0, 0)]
+    cases += [(int(rng.integers(0, hi01)), int(rng.integers(0, hi01)), int(rng.integers(0, hi2))) for _ in range(2000)]
+    for y in cases:
+        yy = (ctypes.c_uint32 * 3)(*y)
+        ll = (ctypes.c_uint32 * 3)()
+        hs.hs_renorm(yy, ll)
+        l0, l1, l2 = ll[0], ll[1], ll[2]
+        assert l0 < (1 << 23) and l1 < (1 << 23) and l2 < (1 << 20), (y, l0, l1, l2)
+        assert (l0 + (l1 << 22) + (l2 << 44)) % P == (y[0] + (y[1] << 22) + (y[2] << 44)) % P, y

@@ -79,15 +79,16 @@ __device__ __forceinline__ void permute_sparse(uint64_t (&s)[W]) {
   for (int i = 0; i < W; i++) s[i] = gl::canon(s[i]);
 }
 
-template <bool SPARSE>
+template <int VARIANT>  // 0: textbook rounds, 1: sparse partial rounds (this file), 2: poseidon::permute (plane-resident)
 __global__ __launch_bounds__(256) void k_chain(uint64_t *out, uint64_t seed, int reps) {
   uint64_t s[W];
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 #pragma unroll
   for (int i = 0; i < W; i++) s[i] = gl::canon(seed * (i + 1) + t * 0x9E3779B97F4A7C15ull + i);
   for (int r = 0; r < reps; r++) {
-    if (SPARSE) permute_sparse(s);
-    else poseidon::permute(s);
+    if (VARIANT == 1) permute_sparse(s);
+    else if (VARIANT == 2) poseidon::permute(s);
+    else poseidon::permute_textbook(s);
   }
   uint64_t acc = 0;
 #pragma unroll
@@ -138,30 +139,38 @@ int main() {
   uint64_t *a, *b;
   hipMalloc(&a, n * 8);
   hipMalloc(&b, n * 8);
-  hipLaunchKernelGGL(sp::k_chain<false>, dim3(blocks), dim3(256), 0, 0, a, 12345ull, 3);
-  hipLaunchKernelGGL(sp::k_chain<true>, dim3(blocks), dim3(256), 0, 0, b, 12345ull, 3);
-  std::vector<uint64_t> ha(n), hb(n);
+  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_PK), POSEIDON_PLANE_K, sizeof POSEIDON_PLANE_K);
+  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_PLAST), POSEIDON_PLANE_LAST, sizeof POSEIDON_PLANE_LAST);
+  uint64_t *c;
+  hipMalloc(&c, n * 8);
+  hipLaunchKernelGGL(sp::k_chain<0>, dim3(blocks), dim3(256), 0, 0, a, 12345ull, 3);
+  hipLaunchKernelGGL(sp::k_chain<1>, dim3(blocks), dim3(256), 0, 0, b, 12345ull, 3);
+  hipLaunchKernelGGL(sp::k_chain<2>, dim3(blocks), dim3(256), 0, 0, c, 12345ull, 3);
+  std::vector<uint64_t> ha(n), hb(n), hc(n);
   hipMemcpy(ha.data(), a, n * 8, hipMemcpyDeviceToHost);
   hipMemcpy(hb.data(), b, n * 8, hipMemcpyDeviceToHost);
+  hipMemcpy(hc.data(), c, n * 8, hipMemcpyDeviceToHost);
   size_t bad = 0;
-  for (size_t i = 0; i < n; i++) bad += ha[i] != hb[i];
+  for (size_t i = 0; i < n; i++) bad += (ha[i] != hb[i]) + (ha[i] != hc[i]);
   printf("mismatches: %zu of %zu\n", bad, n);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  for (int variant = 0; variant < 2; variant++) {
+  const char *names[3] = {"textbook rounds            ", "sparse partial rounds      ", "plane-resident partial rnds"};
+  for (int variant = 0; variant < 3; variant++) {
     float best = 1e9f;
     for (int it = 0; it < 3; it++) {
       hipEventRecord(e0, 0);
-      if (variant) hipLaunchKernelGGL(sp::k_chain<true>, dim3(blocks), dim3(256), 0, 0, b, 777ull, reps);
-      else hipLaunchKernelGGL(sp::k_chain<false>, dim3(blocks), dim3(256), 0, 0, a, 777ull, reps);
+      if (variant == 1) hipLaunchKernelGGL(sp::k_chain<1>, dim3(blocks), dim3(256), 0, 0, b, 777ull, reps);
+      else if (variant == 2) hipLaunchKernelGGL(sp::k_chain<2>, dim3(blocks), dim3(256), 0, 0, c, 777ull, reps);
+      else hipLaunchKernelGGL(sp::k_chain<0>, dim3(blocks), dim3(256), 0, 0, a, 777ull, reps);
       hipEventRecord(e1, 0);
       hipEventSynchronize(e1);
       float ms;
       hipEventElapsedTime(&ms, e0, e1);
       if (ms < best) best = ms;
     }
-    printf("%s: %.3f ms for %zu permutations -> %.3f G perm/s\n", variant ? "sparse partial rounds" : "current permute      ", best,
+    printf("%s: %.3f ms for %zu permutations -> %.3f G perm/s\n", names[variant], best,
            n * reps, (double)n * reps / best / 1e6);
   }
   return bad != 0;
