@@ -270,10 +270,10 @@ def main():
                         "HBM-bound kernel of this step"}
         roof["frac"] = roof["achieved"] / roof["peak"]
         # what actually bounds the leaf hash: integer-VALU issue. Instruction counts and busy fractions come from a
-        # separate rocprofv3 --pmc pass of this command (profiles/r01_pmc_valu_bench_v6.json); the rate is this run's.
+        # separate rocprofv3 --pmc pass of this command (profiles/r01_pmc_valu_bench_v10.json); the rate is this run's.
         roof_valu = None
         try:
-            pv = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_valu_bench_v6.json")))["merkle::k_leaf_hash_cols"]
+            pv = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_valu_bench_v10.json")))["merkle::k_leaf_hash_cols"]
             if (k, log_n) == (COLS, LOG_N):
                 insts = pv["SQ_INSTS_VALU"]          # wave-level VALU instructions per launch
                 simds, clk = 256 * 4, pv["clock_GHz_est"] * 1e9
