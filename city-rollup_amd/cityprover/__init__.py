@@ -333,7 +333,10 @@ class Shape(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "degree_bits", "num_constants", "num_routed_wires", "num_wires", "num_challenges",
         "num_partial_products", "quotient_degree_factor", "rate_bits", "cap_height", "pow_bits",
-        "num_query_rounds", "n_arity")] + [("arity_bits", ctypes.c_int * 8)]
+        "num_query_rounds", "n_arity")] + [("arity_bits", ctypes.c_int * 8), ("zero_knowledge", ctypes.c_int)]
+
+
+SALT_SIZE = 4
 
 
 def standard_recursion_shape(**over):
@@ -341,7 +344,7 @@ def standard_recursion_shape(**over):
     circuits use (SURVEY.md §5 'Config / flags', Appendix A)."""
     d = dict(degree_bits=12, num_constants=5, num_routed_wires=80, num_wires=135, num_challenges=2,
              num_partial_products=9, quotient_degree_factor=8, rate_bits=3, cap_height=4, pow_bits=16,
-             num_query_rounds=28, arity_bits=(4, 4))
+             num_query_rounds=28, arity_bits=(4, 4), zero_knowledge=0)
     d.update(over)
     ab = d.pop("arity_bits")
     s = Shape(**d, n_arity=len(ab))
@@ -521,6 +524,41 @@ def prove_batch(prover, circuits, public_inputs, wires, pow_overrides=None):
     outs = (ctypes.POINTER(ctypes.c_uint8) * B)()
     lens = (ctypes.c_size_t * B)()
     prover._check(prover.lib.cp_prove_batch_host(prover.ctx, B, cs, pi_ptrs, n_pis, w_ptrs, use, _ptr(ov), outs, lens))
+    res = []
+    for i in range(B):
+        res.append(ctypes.string_at(outs[i], lens[i]))
+        prover.lib.cp_free(outs[i])
+    return res
+
+
+ABI["cp_prove_batch_zk_host"] = (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp), ctypes.POINTER(_u64p),
+                                                ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(_u64p), ctypes.POINTER(_u64p),
+                                                ctypes.POINTER(ctypes.c_int), _u64p,
+                                                ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)),
+                                                ctypes.POINTER(ctypes.c_size_t)])
+
+
+def prove_batch_zk(prover, circuits, public_inputs, wires, salts, pow_overrides=None):
+    """Zero-knowledge circuits: salts[p] = [3][SALT_SIZE][N] uint64 random field elements (cp_prove_batch_zk_host)."""
+    B = len(circuits)
+    cs = (_vp * B)(*[c.handle for c in circuits])
+    pis = [_as_u64(p) for p in public_inputs]
+    pi_ptrs = (_u64p * B)(*[_ptr(p) if p.size else None for p in pis])
+    n_pis = (ctypes.c_size_t * B)(*[p.size for p in pis])
+    ws, sl = [_as_u64(w) for w in wires], [_as_u64(x) for x in salts]
+    for c, w, x in zip(circuits, ws, sl):   # the C ABI takes bare pointers: sizes are checked here
+        if w.size != c.shape.num_wires << c.shape.degree_bits:
+            raise ValueError("wires must be [num_wires][n]")
+        if x.size != 3 * SALT_SIZE << (c.shape.degree_bits + c.shape.rate_bits):
+            raise ValueError("salts must be [3][SALT_SIZE][N]")
+    w_ptrs = (_u64p * B)(*[_ptr(w) for w in ws])
+    s_ptrs = (_u64p * B)(*[_ptr(x) for x in sl])
+    use = (ctypes.c_int * B)(*[0 if (pow_overrides is None or pow_overrides[i] is None) else 1 for i in range(B)])
+    ov = np.array([0 if (pow_overrides is None or pow_overrides[i] is None) else pow_overrides[i] for i in range(B)],
+                  dtype=np.uint64)
+    outs = (ctypes.POINTER(ctypes.c_uint8) * B)()
+    lens = (ctypes.c_size_t * B)()
+    prover._check(prover.lib.cp_prove_batch_zk_host(prover.ctx, B, cs, pi_ptrs, n_pis, w_ptrs, s_ptrs, use, _ptr(ov), outs, lens))
     res = []
     for i in range(B):
         res.append(ctypes.string_at(outs[i], lens[i]))

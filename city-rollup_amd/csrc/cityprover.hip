@@ -407,16 +407,21 @@ int merkle_levels(cp_ctx *ctx, uint64_t *D, size_t per_tree, size_t n_leaves, si
 // n_trees Merkle trees over column-major leaves; tree t reads cols + t*tree_cols_stride.
 int merkle_cols_batch(cp_ctx *ctx, const uint64_t *cols, size_t n_leaves, size_t leaf_len,
                       size_t col_stride, size_t n_trees, size_t tree_cols_stride, int cap_height,
-                      uint64_t *digests, uint64_t *caps) {
+                      uint64_t *digests, uint64_t *caps, const uint64_t *salt = nullptr, int n_salt = 0,
+                      size_t salt_tree_stride = 0) {
   size_t per_tree = merkle_words_per_tree(n_leaves, cap_height);
   uint64_t *D = digests;
   if (!D) {
     CP_TRY(ensure_scratch(ctx, n_trees * per_tree * sizeof(uint64_t)));
     D = (uint64_t *)ctx->scratch;
   }
-  LAUNCH(ctx, "leaf_hash_cols", merkle::k_leaf_hash_cols,
-         dim3(blocks_for(n_leaves, merkle::THREADS), (unsigned)n_trees), dim3(merkle::THREADS), cols, n_leaves,
-         (int)leaf_len, col_stride, D, tree_cols_stride, per_tree);
+  const dim3 grid(blocks_for(n_leaves, merkle::THREADS), (unsigned)n_trees), block(merkle::THREADS);
+  if (salt && n_salt > 0)
+    LAUNCH(ctx, "leaf_hash_cols", merkle::k_leaf_hash_cols<true>, grid, block, cols, n_leaves, (int)leaf_len, col_stride, D,
+           tree_cols_stride, per_tree, salt, n_salt, salt_tree_stride);
+  else
+    LAUNCH(ctx, "leaf_hash_cols", merkle::k_leaf_hash_cols<false>, grid, block, cols, n_leaves, (int)leaf_len, col_stride, D,
+           tree_cols_stride, per_tree, (const uint64_t *)nullptr, 0, (size_t)0);
   return merkle_levels(ctx, D, per_tree, n_leaves, n_trees, cap_height, caps);
 }
 

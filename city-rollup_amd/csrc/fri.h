@@ -220,6 +220,9 @@ struct QueryRefs {
   const uint64_t *digests[4];       //               + proof*dig_stride[b]
   size_t lde_stride[4], dig_stride[4];
   int k[4];
+  const uint64_t *salt[4];          // zero-knowledge: n_salt[b] extra leaf elements per oracle ([proof][n_salt][N]), else null
+  size_t salt_stride[4];
+  int n_salt[4];
   size_t N;
   int depth0;                       // log2(N) - cap_height
   int n_layers;
@@ -255,10 +258,13 @@ __global__ __launch_bounds__(256) void k_gather_queries(QueryRefs r, const uint6
   for (int b = 0; b < 4; b++) {
     const uint64_t *lde = b == 0 ? r.lde0[proof] : r.lde[b] + proof * r.lde_stride[b];
     const uint64_t *dig = b == 0 ? r.digests0[proof] : r.digests[b] + proof * r.dig_stride[b];
-    if (threadIdx.x == 0) o[w] = (uint64_t)r.k[b];
+    const int ns = r.salt[b] ? r.n_salt[b] : 0;
+    if (threadIdx.x == 0) o[w] = (uint64_t)(r.k[b] + ns);   // the whole leaf: values, then the salt
     w += 1;
     for (int p = threadIdx.x; p < r.k[b]; p += blockDim.x) o[w + p] = lde[(size_t)p * r.N + x];
     w += r.k[b];
+    for (int p = threadIdx.x; p < ns; p += blockDim.x) o[w + p] = r.salt[b][proof * r.salt_stride[b] + (size_t)p * r.N + x];
+    w += ns;
     if (threadIdx.x == 0) o[w] = (uint64_t)r.depth0;
     w += 1;
     copy_path(dig, r.N, r.depth0, x, o + w);

@@ -16,32 +16,43 @@ constexpr int THREADS = 256;
 
 // leaf digests: digest[i] = hash_or_noop(leaf i)
 // blockIdx.y = tree index (batched commitments: tree t reads cols + t*tree_cols_stride)
+// SALT (zero-knowledge circuits, FRI `hiding`): the leaf is the leaf_len column values followed by n_salt salt
+// elements read from a second column-major array (salt + t*salt_tree_stride, column stride = col_stride).
+template <bool SALT>
 __global__ __launch_bounds__(THREADS) void k_leaf_hash_cols(const uint64_t *__restrict__ cols,
                                                             size_t n_leaves, int leaf_len,
                                                             size_t col_stride,
                                                             uint64_t *__restrict__ digests,
                                                             size_t tree_cols_stride,
-                                                            size_t tree_dig_stride) {
+                                                            size_t tree_dig_stride,
+                                                            const uint64_t *__restrict__ salt, int n_salt,
+                                                            size_t salt_tree_stride) {
   size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
   if (i >= n_leaves) return;
   cols += (size_t)blockIdx.y * tree_cols_stride;
   digests += (size_t)blockIdx.y * tree_dig_stride;
+  if (SALT) salt += (size_t)blockIdx.y * salt_tree_stride;
+  const int total = SALT ? leaf_len + n_salt : leaf_len;
+  auto elem = [&](int j) -> uint64_t {
+    if (SALT && j >= leaf_len) return salt[(size_t)(j - leaf_len) * col_stride + i];
+    return cols[(size_t)j * col_stride + i];
+  };
   uint64_t s[poseidon::W];
 #pragma unroll
   for (int k = 0; k < poseidon::W; k++) s[k] = 0;
-  if (leaf_len <= 4) {
-    for (int j = 0; j < leaf_len; j++) s[j] = cols[(size_t)j * col_stride + i];
+  if (total <= 4) {
+    for (int j = 0; j < total; j++) s[j] = elem(j);
   } else {
     int j = 0;
-    for (; j + poseidon::RATE <= leaf_len; j += poseidon::RATE) {
+    for (; j + poseidon::RATE <= total; j += poseidon::RATE) {
 #pragma unroll
-      for (int k = 0; k < poseidon::RATE; k++) s[k] = cols[(size_t)(j + k) * col_stride + i];
+      for (int k = 0; k < poseidon::RATE; k++) s[k] = elem(j + k);
       poseidon::permute(s);
     }
-    if (j < leaf_len) {  // partial last chunk overwrites only its own lanes (overwrite-mode sponge)
+    if (j < total) {  // partial last chunk overwrites only its own lanes (overwrite-mode sponge)
 #pragma unroll
       for (int k = 0; k < poseidon::RATE; k++)
-        if (j + k < leaf_len) s[k] = cols[(size_t)(j + k) * col_stride + i];
+        if (j + k < total) s[k] = elem(j + k);
       poseidon::permute(s);
     }
   }

@@ -168,7 +168,11 @@ typedef struct cp_shape {
   int rate_bits, cap_height, pow_bits, num_query_rounds;
   int n_arity;
   int arity_bits[8];
+  int zero_knowledge; /* CircuitConfig::zero_knowledge (standard_recursion_zk_config, the user-side signature
+                         circuits: city_common_circuit/src/circuits/zk_signature/inner.rs:50,116-117): FRI `hiding`, i.e.
+                         the Merkle leaves of the wires / Z / quotient oracles end with CP_SALT_SIZE random elements */
 } cp_shape;
+#define CP_SALT_SIZE 4
 
 typedef struct cp_circuit cp_circuit;
 
@@ -275,6 +279,17 @@ int cp_prove_batch_host(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circuit
 int cp_prove(cp_circuit *circuit, const uint64_t *wires_values_host, const uint64_t *public_inputs_host,
              size_t n_public_inputs, int use_pow_override, uint64_t pow_override, uint8_t **proof_out,
              size_t *proof_len);
+/* Zero-knowledge circuits (shape.zero_knowledge = 1). plonky2 draws the leaf salts from its RNG inside
+ * `PolynomialBatch::from_values(.., blinding = true, ..)`; here the CALLER supplies them, so the choice of RNG stays
+ * on the Rust side and a run is reproducible: salts_host[p] = [3 oracles: wires, Z/partial products, quotient]
+ * [CP_SALT_SIZE][N = n << rate_bits] uniformly random canonical field elements, indexed by LEAF (the order is
+ * immaterial for random data). Everything else — the blinding rows `CircuitBuilder::blind_and_pad` adds — is part
+ * of the circuit and the witness. The plain entry points refuse zero-knowledge circuits and vice versa. */
+int cp_prove_batch_zk_host(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circuits,
+                           const uint64_t *const *public_inputs_host, const size_t *n_public_inputs,
+                           const uint64_t *const *wires_values_host, const uint64_t *const *salts_host,
+                           const int *use_pow_override, const uint64_t *pow_override, uint8_t **proofs_out,
+                           size_t *proof_lens);
 /* plonky2 `CircuitData::verify` (reference call site: city_common_circuit/src/proof_minifier/
  * pm_chain.rs:264-268): transcript, vanishing identity at zeta, proof of work, every query round's
  * Merkle paths, fri_combine_initial, fold chain and final polynomial. Runs on the host (a few thousand

@@ -104,7 +104,10 @@ typedef struct {
   int rate_bits, cap_height, pow_bits, num_query_rounds;
   int n_arity;
   int arity_bits[8];
+  int zero_knowledge; /* CircuitConfig::zero_knowledge: FRI `hiding` — the leaves of the wires / Z / quotient oracles
+                         carry SALT_SIZE = 4 random elements (plonky2 PlonkOracle::{WIRES,ZS_PARTIAL_PRODUCTS,QUOTIENT}.blinding) */
 } or_shape;
+#define OR_SALT_SIZE 4
 
 typedef struct {
   uint64_t betas[8], gammas[8], alphas[8];
@@ -170,6 +173,14 @@ int or_prove_full(const or_shape *sh, const or_gates *G, const uint64_t circuit_
                   const uint64_t *public_inputs, size_t n_pi, const uint64_t *cs_values,
                   const uint64_t *wires_values, int use_pow_override, uint64_t pow_override,
                   uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg);
+
+/* zero-knowledge variant: salts = [3 oracles: wires, zs/partial products, quotient][OR_SALT_SIZE][N] random field
+ * elements in LEAF order (the prover appends them to the Merkle leaves; plonky2 draws them from its RNG). Requires
+ * sh->zero_knowledge != 0. */
+int or_prove_full_zk(const or_shape *sh, const or_gates *G, const uint64_t circuit_digest[4],
+                     const uint64_t *public_inputs, size_t n_pi, const uint64_t *cs_values,
+                     const uint64_t *wires_values, const uint64_t *salts, int use_pow_override, uint64_t pow_override,
+                     uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg);
 
 /* A7: Z and partial-product polynomials of the permutation argument (values over <omega_n>).
  * wires_values: num_wires x n (only the routed ones are read); sigma_values: num_routed_wires x n;

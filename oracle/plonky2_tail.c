@@ -58,10 +58,11 @@ static gl2_t ch_ext(or_challenger *c) {
 /* polynomial batches */
 
 typedef struct {
-  size_t k;
+  size_t k;      /* polynomials */
+  size_t n_salt; /* extra leaf elements after the k polynomial values (zero-knowledge: OR_SALT_SIZE, else 0) */
   int log_n, rate_bits, cap_height;
   uint64_t *coeffs;  /* k x n */
-  uint64_t *lde;     /* k x N, bit-reversed index order */
+  uint64_t *lde;     /* (k + n_salt) x N, bit-reversed index order; the salt columns come last */
   uint64_t *digests; /* levels below the cap */
   uint64_t *cap;     /* 2^cap_height x 4 */
 } batch_t;
@@ -71,29 +72,36 @@ static size_t digest_nodes(size_t n_leaves, int cap_height) {
   return n_leaves > cap_n ? 2 * n_leaves - 2 * cap_n : 0;
 }
 
-static void batch_alloc(batch_t *b, size_t k, int log_n, int rate_bits, int cap_height) {
+static void batch_alloc(batch_t *b, size_t k, int log_n, int rate_bits, int cap_height, const uint64_t *salt) {
   size_t n = (size_t)1 << log_n, N = n << rate_bits;
   b->k = k; b->log_n = log_n; b->rate_bits = rate_bits; b->cap_height = cap_height;
+  b->n_salt = salt ? OR_SALT_SIZE : 0;
   b->coeffs = (uint64_t *)malloc(k * n * 8);
-  b->lde = (uint64_t *)malloc(k * N * 8);
+  b->lde = (uint64_t *)malloc((k + b->n_salt) * N * 8);
+  if (salt) memcpy(b->lde + k * N, salt, b->n_salt * N * 8);
   b->digests = (uint64_t *)malloc((digest_nodes(N, cap_height) + 1) * 32);
   b->cap = (uint64_t *)malloc(((size_t)1 << cap_height) * 32);
 }
 static void batch_free(batch_t *b) { free(b->coeffs); free(b->lde); free(b->digests); free(b->cap); }
 
-static void batch_from_values(batch_t *b, const uint64_t *values, size_t k, int log_n, int rate_bits, int cap_height) {
-  batch_alloc(b, k, log_n, rate_bits, cap_height);
+static void batch_from_values(batch_t *b, const uint64_t *values, size_t k, int log_n, int rate_bits, int cap_height,
+                              const uint64_t *salt) {
+  batch_alloc(b, k, log_n, rate_bits, cap_height, salt);
   or_commit_batch(values, k, log_n, rate_bits, cap_height, b->coeffs, b->lde, b->digests, b->cap);
+  if (salt) /* the leaves are longer than what or_commit_batch hashed: redo the tree over k + n_salt columns */
+    or_merkle_tree_cols(b->lde, (size_t)1 << (log_n + rate_bits), k + b->n_salt, (size_t)1 << (log_n + rate_bits), cap_height,
+                        b->digests, b->cap);
 }
-static void batch_from_coeffs(batch_t *b, const uint64_t *coeffs, size_t k, int log_n, int rate_bits, int cap_height) {
-  batch_alloc(b, k, log_n, rate_bits, cap_height);
+static void batch_from_coeffs(batch_t *b, const uint64_t *coeffs, size_t k, int log_n, int rate_bits, int cap_height,
+                              const uint64_t *salt) {
+  batch_alloc(b, k, log_n, rate_bits, cap_height, salt);
   size_t n = (size_t)1 << log_n, N = n << rate_bits;
   memcpy(b->coeffs, coeffs, k * n * 8);
   for (size_t p = 0; p < k; p++) {
     or_coset_lde(coeffs + p * n, log_n, rate_bits, GL_GENERATOR, b->lde + p * N);
     or_bit_reverse(b->lde + p * N, log_n + rate_bits);
   }
-  or_merkle_tree_cols(b->lde, N, k, N, cap_height, b->digests, b->cap);
+  or_merkle_tree_cols(b->lde, N, k + b->n_salt, N, cap_height, b->digests, b->cap);
 }
 
 /* Merkle path of leaf `idx` out of the level-by-level digest array */
@@ -156,7 +164,7 @@ typedef struct {
 
 static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circuit_digest[4], const uint64_t *public_inputs, size_t n_pi,
                       const uint64_t *cs_values, const uint64_t *wires_values, const uint64_t *zs_pp_values,
-                      const uint64_t *quotient_coeffs, int use_pow_override, uint64_t pow_override,
+                      const uint64_t *quotient_coeffs, const uint64_t *salts, int use_pow_override, uint64_t pow_override,
                       uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg);
 
 int or_prove_tail(const or_shape *sh, const uint64_t circuit_digest[4], const uint64_t *public_inputs, size_t n_pi,
@@ -164,7 +172,7 @@ int or_prove_tail(const or_shape *sh, const uint64_t circuit_digest[4], const ui
                   const uint64_t *quotient_coeffs, int use_pow_override, uint64_t pow_override,
                   uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg) {
   return prove_impl(sh, NULL, circuit_digest, public_inputs, n_pi, cs_values, wires_values, zs_pp_values, quotient_coeffs,
-                    use_pow_override, pow_override, proof_out, proof_len, dbg);
+                    NULL, use_pow_override, pow_override, proof_out, proof_len, dbg);
 }
 
 /* The whole of CircuitData::prove after witness generation: wires -> proof. Z / partial products (A7)
@@ -173,7 +181,15 @@ int or_prove_full(const or_shape *sh, const or_gates *G, const uint64_t circuit_
                   size_t n_pi, const uint64_t *cs_values, const uint64_t *wires_values, int use_pow_override,
                   uint64_t pow_override, uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg) {
   if (!G) return -100;
-  return prove_impl(sh, G, circuit_digest, public_inputs, n_pi, cs_values, wires_values, NULL, NULL, use_pow_override,
+  return prove_impl(sh, G, circuit_digest, public_inputs, n_pi, cs_values, wires_values, NULL, NULL, NULL, use_pow_override,
+                    pow_override, proof_out, proof_len, dbg);
+}
+
+int or_prove_full_zk(const or_shape *sh, const or_gates *G, const uint64_t circuit_digest[4], const uint64_t *public_inputs,
+                     size_t n_pi, const uint64_t *cs_values, const uint64_t *wires_values, const uint64_t *salts,
+                     int use_pow_override, uint64_t pow_override, uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg) {
+  if (!G || !salts) return -100;
+  return prove_impl(sh, G, circuit_digest, public_inputs, n_pi, cs_values, wires_values, NULL, NULL, salts, use_pow_override,
                     pow_override, proof_out, proof_len, dbg);
 }
 
@@ -183,8 +199,9 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 
 static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circuit_digest[4], const uint64_t *public_inputs, size_t n_pi,
                       const uint64_t *cs_values, const uint64_t *wires_values, const uint64_t *zs_pp_values,
-                      const uint64_t *quotient_coeffs, int use_pow_override, uint64_t pow_override,
+                      const uint64_t *quotient_coeffs, const uint64_t *salts, int use_pow_override, uint64_t pow_override,
                       uint8_t **proof_out, size_t *proof_len, or_tail_debug *dbg) {
+  if ((sh->zero_knowledge != 0) != (salts != NULL)) return -3; /* salts exactly when the circuit is zero-knowledge */
   const int timing = getenv("OR_TIMING") != NULL;
   double phase_t0 = now_s();
   const char *phase_name = "commit cs+wires";
@@ -196,10 +213,11 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
   const size_t cap_n = (size_t)1 << ch;
 
   batch_t B[4];
-  batch_from_values(&B[0], cs_values, k_cs, db, rb, ch);
+  const uint64_t *salt1 = salts, *salt2 = salts ? salts + (size_t)OR_SALT_SIZE * N : NULL, *salt3 = salts ? salts + (size_t)2 * OR_SALT_SIZE * N : NULL;
+  batch_from_values(&B[0], cs_values, k_cs, db, rb, ch, NULL);
   uint64_t pi_hash[4];
   or_hash_no_pad(public_inputs, n_pi, pi_hash);
-  batch_from_values(&B[1], wires_values, k_w, db, rb, ch);
+  batch_from_values(&B[1], wires_values, k_w, db, rb, ch, salt1);
 
   or_challenger c;
   or_ch_init(&c);
@@ -217,7 +235,7 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
     zs_pp_values = own_zs;
   }
   PHASE("commit zs");
-  batch_from_values(&B[2], zs_pp_values, k_z, db, rb, ch);
+  batch_from_values(&B[2], zs_pp_values, k_z, db, rb, ch, salt2);
   or_ch_observe(&c, B[2].cap, cap_n * 4);
   for (int i = 0; i < sh->num_challenges; i++) alphas[i] = or_ch_challenge(&c);
   PHASE("quotient");
@@ -228,7 +246,7 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
     quotient_coeffs = own_q;
   }
   PHASE("commit quotient");
-  batch_from_coeffs(&B[3], quotient_coeffs, k_q, db, rb, ch);
+  batch_from_coeffs(&B[3], quotient_coeffs, k_q, db, rb, ch, salt3);
   free(own_zs);
   free(own_q);
   or_ch_observe(&c, B[3].cap, cap_n * 4);
@@ -372,8 +390,8 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
     if (dbg && qi < 64) dbg->query_indices[qi] = x;
     buf_u64(&out, 4);
     for (int b = 0; b < 4; b++) {
-      buf_u64(&out, B[b].k);
-      for (size_t p = 0; p < B[b].k; p++) buf_u64(&out, B[b].lde[p * N + x]);
+      buf_u64(&out, B[b].k + B[b].n_salt); /* the whole leaf, salt included */
+      for (size_t p = 0; p < B[b].k + B[b].n_salt; p++) buf_u64(&out, B[b].lde[p * N + x]);
       merkle_path(B[b].digests, N, ch, x, sib);
       buf_u64(&out, depth0); buf_felts(&out, sib, (size_t)depth0 * 4);
     }
@@ -466,9 +484,13 @@ int or_verify_tail(const or_shape *sh, const uint64_t circuit_digest[4], const u
   /* skip the queries to reach final poly / pow / public inputs */
   int depth0 = db + rb - ch;
   size_t kk[4] = {k_cs, k_w, k_z, k_q};
+  /* FriParams::hiding: the blinded oracles' leaves carry OR_SALT_SIZE salt elements after the polynomial values; the
+   * Merkle check covers the whole leaf, fri_combine_initial only the unsalted part (FriInitialTreeProof::unsalted_eval) */
+  size_t leaf_len[4];
+  for (int b = 0; b < 4; b++) leaf_len[b] = kk[b] + ((sh->zero_knowledge && b >= 1) ? OR_SALT_SIZE : 0);
   for (int qi = 0; qi < sh->num_query_rounds; qi++) {
     if (rd_u64(&r) != 4) return -6;
-    for (int b = 0; b < 4; b++) { if (rd_u64(&r) != kk[b]) return -6; rd_felts(&r, kk[b]); if (rd_u64(&r) != (uint64_t)depth0) return -6; rd_felts(&r, (size_t)depth0 * 4); }
+    for (int b = 0; b < 4; b++) { if (rd_u64(&r) != leaf_len[b]) return -6; rd_felts(&r, leaf_len[b]); if (rd_u64(&r) != (uint64_t)depth0) return -6; rd_felts(&r, (size_t)depth0 * 4); }
     if (rd_u64(&r) != (uint64_t)sh->n_arity) return -6;
     size_t nl = N;
     for (int l = 0; l < sh->n_arity; l++) {
@@ -525,9 +547,9 @@ int or_verify_tail(const or_shape *sh, const uint64_t circuit_digest[4], const u
     rd_u64(&q);
     const uint64_t *ev[4];
     for (int b = 0; b < 4; b++) {
-      rd_u64(&q); ev[b] = rd_felts(&q, kk[b]); rd_u64(&q);
+      rd_u64(&q); ev[b] = rd_felts(&q, leaf_len[b]); rd_u64(&q);
       const uint64_t *sibs = rd_felts(&q, (size_t)depth0 * 4);
-      if (!or_merkle_verify(ev[b], kk[b], x_index, sibs, depth0, caps[b], ch)) return -10 - b;
+      if (!or_merkle_verify(ev[b], leaf_len[b], x_index, sibs, depth0, caps[b], ch)) return -10 - b;
     }
     uint64_t x = or_fri_query_point(x_index, db + rb);
     /* fri_combine_initial */

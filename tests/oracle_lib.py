@@ -203,7 +203,7 @@ class Shape(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "degree_bits", "num_constants", "num_routed_wires", "num_wires", "num_challenges",
         "num_partial_products", "quotient_degree_factor", "rate_bits", "cap_height", "pow_bits",
-        "num_query_rounds", "n_arity")] + [("arity_bits", ctypes.c_int * 8)]
+        "num_query_rounds", "n_arity")] + [("arity_bits", ctypes.c_int * 8), ("zero_knowledge", ctypes.c_int)]
 
 
 class TailDebug(ctypes.Structure):
@@ -302,6 +302,27 @@ def prove_full(shape, gates, circuit_digest, public_inputs, cs_values, wires_val
     rc = L.or_prove_full(ctypes.byref(shape), ctypes.byref(gates), ptr(cd), ptr(pi), ctypes.c_size_t(pi.size), ptr(a),
                          ptr(b), ctypes.c_int(0 if pow_override is None else 1), ctypes.c_uint64(pow_override or 0),
                          ctypes.byref(out), ctypes.byref(ln), ctypes.byref(dbg))
+    assert rc == 0, rc
+    data = ctypes.string_at(out, ln.value)
+    L.or_free(out)
+    return data, dbg
+
+
+SALT_SIZE = 4
+
+
+def prove_full_zk(shape, gates, circuit_digest, public_inputs, cs_values, wires_values, salts, pow_override=None):
+    """Zero-knowledge circuits (shape.zero_knowledge = 1): salts = [3][SALT_SIZE][N] uint64, leaf order."""
+    L = lib()
+    L.or_prove_full_zk.restype = ctypes.c_int
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    ln = ctypes.c_size_t()
+    dbg = TailDebug()
+    cd, pi, a, b, sl = arr(circuit_digest), arr(public_inputs), arr(cs_values), arr(wires_values), arr(salts)
+    assert sl.size == 3 * SALT_SIZE << (shape.degree_bits + shape.rate_bits)
+    rc = L.or_prove_full_zk(ctypes.byref(shape), ctypes.byref(gates), ptr(cd), ptr(pi), ctypes.c_size_t(pi.size), ptr(a),
+                            ptr(b), ptr(sl), ctypes.c_int(0 if pow_override is None else 1),
+                            ctypes.c_uint64(pow_override or 0), ctypes.byref(out), ctypes.byref(ln), ctypes.byref(dbg))
     assert rc == 0, rc
     data = ctypes.string_at(out, ln.value)
     L.or_free(out)

@@ -24,7 +24,8 @@ def cp_shape_of(cp, s):
                                        quotient_degree_factor=s.quotient_degree_factor, rate_bits=s.rate_bits,
                                        cap_height=s.cap_height, pow_bits=s.pow_bits,
                                        num_query_rounds=s.num_query_rounds,
-                                       arity_bits=tuple(s.arity_bits[i] for i in range(s.n_arity)))
+                                       arity_bits=tuple(s.arity_bits[i] for i in range(s.n_arity)),
+                                       zero_knowledge=s.zero_knowledge)
 
 
 @pytest.mark.parametrize("db,R,W,arity,B", [(5, 16, 20, (2,), 2), (8, 24, 30, (2, 2), 3), (12, 80, 135, (4, 4), 2)])
@@ -221,3 +222,40 @@ def test_contexts_in_parallel_are_deterministic():
     for th in ths:
         th.join()
     assert not errors, errors
+
+
+def test_zero_knowledge_circuits(prover):
+    """standard_recursion_zk_config path: salted leaves on the wires / Z / quotient oracles (FRI hiding). GPU bytes ==
+    oracle bytes for the same salts (three different circuits in one batch), cp_verify and the oracle verifier accept,
+    and the plain / zk entry points refuse each other's circuits."""
+    import cityprover as cp
+    from test_oracle_full import zk_case
+    cases = [zk_case(seed=70 + i, db=7) for i in range(3)]
+    sh = cp_shape_of(cp, cases[0]["shape"])
+    assert sh.zero_knowledge == 1
+    circs = []
+    for i, c in enumerate(cases):
+        circ = cp.Circuit(prover, sh, [i, 6, 6, 6], c["cs_values"])
+        cp.set_gates(circ, c["gate_list"], 1)
+        circs.append(circ)
+    pis = [c["public_inputs"] for c in cases]
+    got = cp.prove_batch_zk(prover, circs, pis, [c["wires"] for c in cases], [c["salts"] for c in cases])
+    for i, c in enumerate(cases):
+        want, _ = O.prove_full_zk(c["shape"], c["gates"], [i, 6, 6, 6], c["public_inputs"], c["cs_values"], c["wires"], c["salts"])
+        assert got[i] == want
+        cp.verify(circs[i], got[i])
+        assert O.verify_full(c["shape"], c["gates"], [i, 6, 6, 6], circs[i].cs_cap(), got[i]) == 0
+    bad = bytearray(got[0])
+    bad[-200] ^= 1    # inside the final polynomial
+    with pytest.raises(cp.CityProverError):
+        cp.verify(circs[0], bytes(bad))
+    with pytest.raises(cp.CityProverError, match="zero-knowledge"):
+        cp.prove_batch(prover, circs, pis, [c["wires"] for c in cases])
+    plain = build(db=7, num_routed=16, num_wires=24, chunk=8, rate_bits=3, arity_bits=(2, 1), seed=70, cap_height=2)
+    pc = cp.Circuit(prover, cp_shape_of(cp, plain["shape"]), [9, 9, 9, 9], plain["cs_values"])
+    cp.set_gates(pc, plain["gate_list"], 1)
+    with pytest.raises(cp.CityProverError, match="not zero-knowledge"):
+        cp.prove_batch_zk(prover, [pc], [plain["public_inputs"]], [plain["wires"]], [cases[0]["salts"]])
+    pc.close()
+    for c in circs:
+        c.close()

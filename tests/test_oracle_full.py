@@ -143,3 +143,52 @@ def test_comparison_witness_semantics():
         r = comparison_row(a, b)
         assert r[2] == int(a <= b)
         assert len(r) == 4 + 5 * 16 + 3
+
+
+def zk_case(seed=61, db=6):
+    """A circuit in zero-knowledge mode: FRI `hiding` salts on the wires / Z / quotient leaves (the blinding ROWS plonky2
+    adds at build time are part of the circuit + witness and need nothing from the prover)."""
+    c = build(db=db, num_routed=16, num_wires=24, chunk=8, rate_bits=3, arity_bits=(2, 1), seed=seed, cap_height=2)
+    c["shape"].zero_knowledge = 1
+    N = 1 << (db + 3)
+    rng = np.random.default_rng(seed)
+    c["salts"] = rng.integers(0, P, (3, O.SALT_SIZE, N), dtype=np.uint64)
+    return c
+
+
+def test_zero_knowledge_salted_leaves():
+    """standard_recursion_zk_config path (city_common_circuit/src/circuits/zk_signature/inner.rs:50): the three blinded
+    oracles' leaves carry 4 salt elements — present in every query opening, covered by the Merkle paths, ignored by
+    fri_combine_initial. Accepts; rejects a touched salt; refuses salts without the flag and the flag without salts."""
+    c = zk_case()
+    digest = [5, 5, 5, 5]
+    proof, _ = O.prove_full_zk(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], c["wires"], c["salts"])
+    cap = cs_cap(c)
+    assert O.verify_full(c["shape"], c["gates"], digest, cap, proof) == 0
+    pr = parse_proof(proof)
+    q0 = pr["queries"][0]["initial"]
+    assert [len(e) for e, _ in q0] == [16 + 3, 24 + 4, 2 * (1 + 1) + 4, 16 + 4]   # constants+sigmas unsalted
+    x = None
+    N = c["salts"].shape[2]
+    for i in range(N):   # the wires leaf of query 0 ends with that leaf's salt
+        if [int(v) for v in c["salts"][0, :, i]] == [int(v) for v in q0[1][0][-4:]]:
+            x = i
+    assert x is not None
+    # different salts -> different caps and proof, same openings
+    s2 = c["salts"].copy()
+    s2[0, 0, x] = (int(s2[0, 0, x]) + 1) % P
+    proof2, _ = O.prove_full_zk(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], c["wires"], s2)
+    assert proof2 != proof and O.verify_full(c["shape"], c["gates"], digest, cap, proof2) == 0
+    # a salt altered inside the proof breaks that leaf's Merkle path
+    bad = bytearray(proof)
+    pos = proof.index(np.array(q0[1][0][-4:], dtype=np.uint64).tobytes())
+    bad[pos] ^= 1
+    assert O.verify_full(c["shape"], c["gates"], digest, cap, bytes(bad)) != 0
+    # the verifier must know the circuit is zero-knowledge
+    c["shape"].zero_knowledge = 0
+    assert O.verify_full(c["shape"], c["gates"], digest, cap, proof) != 0
+    with pytest.raises(AssertionError):
+        O.prove_full_zk(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], c["wires"], c["salts"])
+    c["shape"].zero_knowledge = 1
+    with pytest.raises(AssertionError):
+        O.prove_full(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], c["wires"])
