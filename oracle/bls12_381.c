@@ -1,0 +1,180 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY (see goldilocks.h).
+ *
+ * BLS12-381 G1 arithmetic and a naive multi-scalar multiplication, the checker for the MSM kernels of SURVEY.md
+ * §8(a) A12 (Groth16 wrap proof: `gnark_plonky2_wrapper::wrap_plonky2_proof`, called at
+ * city_rollup_circuit/src/worker/toolbox/root.rs:296-304; the arithmetic lives in gnark-crypto, a Go dependency that is
+ * not in the tree). Restated from the published curve definition: y^2 = x^3 + 4 over F_p,
+ *   p = (x-1)^2 (x^4 - x^2 + 1)/3 + x,  r = x^4 - x^2 + 1,  x = -0xd201000000010000,
+ * with the standard generator. PARITY: the constants are pinned by those identities, by the curve equation on the
+ * generator and by r*G = infinity (tests/test_oracle_bls.py); the reference holds no MSM vectors (SURVEY.md §8(c):
+ * Groth16/MSM parity unpinned).
+ *
+ * Field elements cross the API as 6 little-endian u64 limbs of the canonical value; points as affine (x, y) = 12 limbs
+ * plus an infinity flag; scalars as 4 little-endian u64 limbs (any value < 2^256, reduced implicitly by the group order).
+ */
+#include "cityoracle.h"
+
+#include <string.h>
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t l[6]; } fp_t;        /* Montgomery form, R = 2^384 */
+typedef struct { fp_t x, y, z; } g1_t;         /* Jacobian, z = 0: infinity */
+
+static const uint64_t P[6] = {0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL,
+                              0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL};
+static const uint64_t GX[6] = {0xfb3af00adb22c6bbULL, 0x6c55e83ff97a1aefULL, 0xa14e3a3f171bac58ULL,
+                               0xc3688c4f9774b905ULL, 0x2695638c4fa9ac0fULL, 0x17f1d3a73197d794ULL};
+static const uint64_t GY[6] = {0x0caa232946c5e7e1ULL, 0xd03cc744a2888ae4ULL, 0x00db18cb2c04b3edULL,
+                               0xfcf5e095d5d00af6ULL, 0xa09e30ed741d8ae4ULL, 0x08b3f481e3aaa0f1ULL};
+static const uint64_t R_ORDER[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+
+static uint64_t N0;      /* -p^-1 mod 2^64 */
+static fp_t R1, R2;      /* R mod p, R^2 mod p */
+static int ready = 0;
+
+static int ge_p(const uint64_t a[6]) {
+  for (int i = 5; i >= 0; i--) { if (a[i] > P[i]) return 1; if (a[i] < P[i]) return 0; }
+  return 1;
+}
+static void sub_p(uint64_t a[6]) {
+  u128 b = 0;
+  for (int i = 0; i < 6; i++) { u128 d = (u128)a[i] - P[i] - (uint64_t)b; a[i] = (uint64_t)d; b = (d >> 64) & 1; }
+}
+static fp_t fp_add(fp_t a, fp_t b) {
+  fp_t r; u128 c = 0;
+  for (int i = 0; i < 6; i++) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+  if (c || ge_p(r.l)) sub_p(r.l); /* a, b < p < 2^381: no carry out of 384 bits in practice */
+  return r;
+}
+static fp_t fp_sub(fp_t a, fp_t b) {
+  fp_t r; u128 br = 0;
+  for (int i = 0; i < 6; i++) { u128 d = (u128)a.l[i] - b.l[i] - (uint64_t)br; r.l[i] = (uint64_t)d; br = (d >> 64) & 1; }
+  if (br) { u128 c = 0; for (int i = 0; i < 6; i++) { c += (u128)r.l[i] + P[i]; r.l[i] = (uint64_t)c; c >>= 64; } }
+  return r;
+}
+/* Montgomery product a*b/R mod p (CIOS) */
+static fp_t fp_mul(fp_t a, fp_t b) {
+  uint64_t t[8] = {0};
+  for (int i = 0; i < 6; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 6; j++) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    c += t[6]; t[6] = (uint64_t)c; t[7] = (uint64_t)(c >> 64);
+    uint64_t m = t[0] * N0;
+    c = ((u128)m * P[0] + t[0]) >> 64;
+    for (int j = 1; j < 6; j++) { c += (u128)m * P[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+    c += t[6]; t[5] = (uint64_t)c; t[6] = t[7] + (uint64_t)(c >> 64);
+  }
+  fp_t r; memcpy(r.l, t, 48);
+  if (t[6] || ge_p(r.l)) sub_p(r.l);
+  return r;
+}
+static fp_t fp_sqr(fp_t a) { return fp_mul(a, a); }
+static int fp_is_zero(fp_t a) { uint64_t o = 0; for (int i = 0; i < 6; i++) o |= a.l[i]; return o == 0; }
+static int fp_eq(fp_t a, fp_t b) { return memcmp(a.l, b.l, 48) == 0; }
+
+static void init(void) {
+  if (ready) return;
+  uint64_t inv = 1; /* Newton: inv = p^-1 mod 2^64 */
+  for (int i = 0; i < 6; i++) inv *= 2 - P[0] * inv;
+  N0 = (uint64_t)0 - inv;
+  /* R mod p by doubling 1 exactly 384 times; R^2 by 384 more */
+  fp_t one = {{1, 0, 0, 0, 0, 0}}, v = one;
+  for (int i = 0; i < 768; i++) { v = fp_add(v, v); if (i == 383) R1 = v; }
+  R2 = v;
+  ready = 1;
+}
+static fp_t fp_from_canonical(const uint64_t a[6]) { fp_t t; memcpy(t.l, a, 48); return fp_mul(t, R2); }
+static void fp_to_canonical(fp_t a, uint64_t out[6]) { fp_t one = {{1, 0, 0, 0, 0, 0}}; fp_t r = fp_mul(a, one); memcpy(out, r.l, 48); }
+static fp_t fp_inv(fp_t a) { /* a^(p-2) */
+  uint64_t e[6]; memcpy(e, P, 48); e[0] -= 2;
+  fp_t r = R1;
+  for (int i = 383; i >= 0; i--) { r = fp_sqr(r); if ((e[i / 64] >> (i % 64)) & 1) r = fp_mul(r, a); }
+  return r;
+}
+
+/* ---- G1, Jacobian coordinates (x = X/Z^2, y = Y/Z^3) ---- */
+static g1_t g1_inf(void) { g1_t r; memset(&r, 0, sizeof r); r.x = R1; r.y = R1; return r; }
+static g1_t g1_double(g1_t p) { /* a = 0: dbl-2009-l */
+  if (fp_is_zero(p.z)) return p;
+  fp_t A = fp_sqr(p.x), B = fp_sqr(p.y), C = fp_sqr(B);
+  fp_t t = fp_add(p.x, B); t = fp_sqr(t); t = fp_sub(fp_sub(t, A), C);
+  fp_t D = fp_add(t, t), E = fp_add(fp_add(A, A), A), F = fp_sqr(E);
+  g1_t r;
+  r.x = fp_sub(F, fp_add(D, D));
+  fp_t C8 = fp_add(C, C); C8 = fp_add(C8, C8); C8 = fp_add(C8, C8);
+  r.y = fp_sub(fp_mul(E, fp_sub(D, r.x)), C8);
+  r.z = fp_mul(p.y, p.z); r.z = fp_add(r.z, r.z);
+  return r;
+}
+static g1_t g1_add(g1_t p, g1_t q) {
+  if (fp_is_zero(p.z)) return q;
+  if (fp_is_zero(q.z)) return p;
+  fp_t z1z1 = fp_sqr(p.z), z2z2 = fp_sqr(q.z);
+  fp_t u1 = fp_mul(p.x, z2z2), u2 = fp_mul(q.x, z1z1);
+  fp_t s1 = fp_mul(fp_mul(p.y, q.z), z2z2), s2 = fp_mul(fp_mul(q.y, p.z), z1z1);
+  if (fp_eq(u1, u2)) return fp_eq(s1, s2) ? g1_double(p) : g1_inf();
+  fp_t h = fp_sub(u2, u1), rr = fp_sub(s2, s1);
+  fp_t hh = fp_sqr(h), hhh = fp_mul(h, hh), v = fp_mul(u1, hh);
+  g1_t r;
+  r.x = fp_sub(fp_sub(fp_sqr(rr), hhh), fp_add(v, v));
+  r.y = fp_sub(fp_mul(rr, fp_sub(v, r.x)), fp_mul(s1, hhh));
+  r.z = fp_mul(fp_mul(p.z, q.z), h);
+  return r;
+}
+static g1_t g1_from_affine(const uint64_t xy[12], int inf) {
+  if (inf) return g1_inf();
+  g1_t r; r.x = fp_from_canonical(xy); r.y = fp_from_canonical(xy + 6); r.z = R1;
+  return r;
+}
+static void g1_to_affine(g1_t p, uint64_t xy[12], int *inf) {
+  if (fp_is_zero(p.z)) { memset(xy, 0, 96); *inf = 1; return; }
+  fp_t zi = fp_inv(p.z), zi2 = fp_sqr(zi);
+  fp_to_canonical(fp_mul(p.x, zi2), xy);
+  fp_to_canonical(fp_mul(p.y, fp_mul(zi2, zi)), xy + 6);
+  *inf = 0;
+}
+static g1_t g1_mul(g1_t p, const uint64_t k[4]) {
+  g1_t r = g1_inf();
+  for (int i = 255; i >= 0; i--) { r = g1_double(r); if ((k[i / 64] >> (i % 64)) & 1) r = g1_add(r, p); }
+  return r;
+}
+
+/* ---- exported ---- */
+void or_bls_constants(uint64_t p[6], uint64_t r[4], uint64_t gen_xy[12]) {
+  memcpy(p, P, 48); memcpy(r, R_ORDER, 32); memcpy(gen_xy, GX, 48); memcpy(gen_xy + 6, GY, 48);
+}
+int or_bls_g1_on_curve(const uint64_t xy[12]) { /* canonical coordinates < p and y^2 == x^3 + 4 */
+  init();
+  if (ge_p(xy) || ge_p(xy + 6)) return 0;
+  fp_t x = fp_from_canonical(xy), y = fp_from_canonical(xy + 6);
+  const uint64_t four[6] = {4, 0, 0, 0, 0, 0};
+  return fp_eq(fp_sqr(y), fp_add(fp_mul(fp_sqr(x), x), fp_from_canonical(four)));
+}
+void or_bls_g1_add(const uint64_t a_xy[12], int a_inf, const uint64_t b_xy[12], int b_inf, uint64_t out_xy[12], int *out_inf) {
+  init();
+  g1_to_affine(g1_add(g1_from_affine(a_xy, a_inf), g1_from_affine(b_xy, b_inf)), out_xy, out_inf);
+}
+void or_bls_g1_mul(const uint64_t xy[12], int inf, const uint64_t k[4], uint64_t out_xy[12], int *out_inf) {
+  init();
+  g1_to_affine(g1_mul(g1_from_affine(xy, inf), k), out_xy, out_inf);
+}
+/* sum_i scalars[i] * points[i], by definition (double-and-add per term); or_set_threads workers */
+void or_bls_g1_msm(const uint64_t *scalars, const uint64_t *points_xy, const uint8_t *points_inf, size_t n,
+                   uint64_t out_xy[12], int *out_inf) {
+  init();
+  int nt = or_get_threads();
+  if (nt < 1) nt = 1;
+  g1_t *part = (g1_t *)__builtin_alloca(sizeof(g1_t) * (size_t)nt);
+  for (int t = 0; t < nt; t++) part[t] = g1_inf();
+#pragma omp parallel for num_threads(nt) schedule(static)
+  for (int t = 0; t < nt; t++) {
+    g1_t acc = g1_inf();
+    for (size_t i = n * (size_t)t / (size_t)nt; i < n * (size_t)(t + 1) / (size_t)nt; i++)
+      acc = g1_add(acc, g1_mul(g1_from_affine(points_xy + 12 * i, points_inf ? points_inf[i] : 0), scalars + 4 * i));
+    part[t] = acc;
+  }
+  g1_t acc = g1_inf();
+  for (int t = 0; t < nt; t++) acc = g1_add(acc, part[t]);
+  g1_to_affine(acc, out_xy, out_inf);
+}

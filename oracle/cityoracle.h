@@ -189,6 +189,16 @@ void or_zs_partial_products(const or_shape *sh, const uint64_t *wires_values, co
                             const uint64_t *k_is, const uint64_t *betas, const uint64_t *gammas,
                             uint64_t *out);
 
+/* ---- BLS12-381 G1 (bls12_381.c): checker for the Groth16-wrap MSM kernels ----
+ * field elements: 6 little-endian u64 limbs of the canonical value; points: affine x||y (12 limbs) + infinity flag;
+ * scalars: 4 little-endian u64 limbs. */
+void or_bls_constants(uint64_t p[6], uint64_t r[4], uint64_t gen_xy[12]);
+int or_bls_g1_on_curve(const uint64_t xy[12]);
+void or_bls_g1_add(const uint64_t a_xy[12], int a_inf, const uint64_t b_xy[12], int b_inf, uint64_t out_xy[12], int *out_inf);
+void or_bls_g1_mul(const uint64_t xy[12], int inf, const uint64_t k[4], uint64_t out_xy[12], int *out_inf);
+void or_bls_g1_msm(const uint64_t *scalars, const uint64_t *points_xy, const uint8_t *points_inf, size_t n,
+                   uint64_t out_xy[12], int *out_inf);
+
 /* number of worker threads the oracle uses for the batch entry points
  * (or_poseidon_permute_many, or_merkle_tree*, or_commit_batch); default 1 */
 void or_set_threads(int n);

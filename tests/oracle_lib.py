@@ -353,3 +353,62 @@ GATE_COMPARISON, GATE_U32_ARITHMETIC, GATE_U32_RANGE_CHECK = 5, 6, 7
 GATE_U32_ADD_MANY, GATE_U32_SUBTRACTION, GATE_U32_INTERLEAVE, GATE_UNINTERLEAVE_TO_U32, GATE_UNINTERLEAVE_TO_B32 = 8, 9, 10, 11, 12
 (GATE_ARITHMETIC_EXT, GATE_MUL_EXT, GATE_BASE_SUM, GATE_RANDOM_ACCESS, GATE_REDUCING, GATE_REDUCING_EXT, GATE_POSEIDON_MDS,
  GATE_COSET_INTERPOLATION) = 13, 14, 15, 16, 17, 18, 19, 20
+
+
+# ---- BLS12-381 G1 (oracle/bls12_381.c) ---------------------------------------------------------------------
+def _limbs(v, n):
+    return np.array([(int(v) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)], dtype=np.uint64)
+
+
+def _int(limbs):
+    return sum(int(x) << (64 * i) for i, x in enumerate(limbs))
+
+
+def bls_constants():
+    p, r, g = np.zeros(6, np.uint64), np.zeros(4, np.uint64), np.zeros(12, np.uint64)
+    lib().or_bls_constants(ptr(p), ptr(r), ptr(g))
+    return _int(p), _int(r), (_int(g[:6]), _int(g[6:]))
+
+
+def bls_point(pt):
+    """pt: None (infinity) or (x, y) ints -> (xy limbs, inf flag)"""
+    if pt is None:
+        return np.zeros(12, np.uint64), 1
+    return np.concatenate([_limbs(pt[0], 6), _limbs(pt[1], 6)]), 0
+
+
+def _bls_out(xy, inf):
+    return None if inf.value else (_int(xy[:6]), _int(xy[6:]))
+
+
+def bls_g1_mul(pt, k):
+    xy, inf = bls_point(pt)
+    out, oi = np.zeros(12, np.uint64), ctypes.c_int()
+    kk = _limbs(k, 4)
+    lib().or_bls_g1_mul(ptr(xy), ctypes.c_int(inf), ptr(kk), ptr(out), ctypes.byref(oi))
+    return _bls_out(out, oi)
+
+
+def bls_g1_add(a, b):
+    axy, ai = bls_point(a)
+    bxy, bi = bls_point(b)
+    out, oi = np.zeros(12, np.uint64), ctypes.c_int()
+    lib().or_bls_g1_add(ptr(axy), ctypes.c_int(ai), ptr(bxy), ctypes.c_int(bi), ptr(out), ctypes.byref(oi))
+    return _bls_out(out, oi)
+
+
+def bls_g1_on_curve(pt):
+    xy, _ = bls_point(pt)
+    lib().or_bls_g1_on_curve.restype = ctypes.c_int
+    return bool(lib().or_bls_g1_on_curve(ptr(xy)))
+
+
+def bls_g1_msm(scalars, points_xy, points_inf=None):
+    """scalars: (n, 4) uint64; points_xy: (n, 12) uint64 affine canonical; points_inf: optional (n,) uint8"""
+    s, pxy = arr(scalars), arr(points_xy)
+    n = s.shape[0]
+    out, oi = np.zeros(12, np.uint64), ctypes.c_int()
+    pi = None if points_inf is None else np.ascontiguousarray(points_inf, dtype=np.uint8)
+    lib().or_bls_g1_msm(ptr(s), ptr(pxy), None if pi is None else pi.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                        ctypes.c_size_t(n), ptr(out), ctypes.byref(oi))
+    return _bls_out(out, oi)
