@@ -589,3 +589,54 @@ def verify(circuit, proof_bytes):
     """CircuitData::verify. Returns None when the proof is accepted; raises CityProverError naming the
     first failing check otherwise."""
     circuit.prover._check(circuit.prover.lib.cp_verify(circuit.handle, proof_bytes, len(proof_bytes)))
+
+
+# ---- BLS12-381 G1 MSM (SURVEY.md §8(a) A12) -------------------------------------------------------------------
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+ABI["cp_msm_bls12381_g1"] = (ctypes.c_int, [_vp, _u64p, _u64p, _u8p, ctypes.c_size_t, _u64p, ctypes.POINTER(ctypes.c_int)])
+ABI["cp_msm_bls12381_g1_prepare_dev"] = (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp])
+ABI["cp_msm_bls12381_g1_dev"] = (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _u64p, ctypes.POINTER(ctypes.c_int)])
+G1_AFFINE_BYTES = 96
+
+
+def _g1_out(xy, inf):
+    if inf.value:
+        return None
+    return (sum(int(v) << (64 * i) for i, v in enumerate(xy[:6])), sum(int(v) << (64 * i) for i, v in enumerate(xy[6:])))
+
+
+def msm_g1(prover, scalars, points_xy, points_inf=None):
+    """sum_i scalars[i] * points[i] on BLS12-381 G1. scalars: (n, 4) uint64 LE limbs; points_xy: (n, 12) uint64 affine
+    canonical x || y; points_inf: optional (n,) uint8. Returns None (infinity) or (x, y) Python ints."""
+    s, p = _as_u64(scalars).reshape(-1, 4), _as_u64(points_xy).reshape(-1, 12)
+    if s.shape[0] != p.shape[0]:
+        raise ValueError("scalars and points differ in count")
+    n = s.shape[0]
+    inf = None if points_inf is None else np.ascontiguousarray(points_inf, dtype=np.uint8)
+    out, oi = np.zeros(12, np.uint64), ctypes.c_int()
+    prover._check(prover.lib.cp_msm_bls12381_g1(prover.ctx, _ptr(s) if n else None, _ptr(p) if n else None,
+                                                None if inf is None else inf.ctypes.data_as(_u8p), n, _ptr(out),
+                                                ctypes.byref(oi)))
+    return _g1_out(out, oi)
+
+
+class G1Points:
+    """A fixed point set resident on the device in the library's internal form (a proving key)."""
+
+    def __init__(self, prover, points_xy):
+        p = _as_u64(points_xy).reshape(-1, 12)
+        self.prover, self.n = prover, p.shape[0]
+        raw = prover.to_device(p)
+        self.buf = prover.alloc(self.n * G1_AFFINE_BYTES // 8)
+        prover._check(prover.lib.cp_msm_bls12381_g1_prepare_dev(prover.ctx, raw.ptr, self.n, self.buf.ptr))
+        prover.sync()
+        raw.free()
+
+    def msm_dev(self, scalars_ptr):
+        out, oi = np.zeros(12, np.uint64), ctypes.c_int()
+        self.prover._check(self.prover.lib.cp_msm_bls12381_g1_dev(self.prover.ctx, scalars_ptr, self.buf.ptr, None, self.n,
+                                                                  _ptr(out), ctypes.byref(oi)))
+        return _g1_out(out, oi)
+
+    def free(self):
+        self.buf.free()

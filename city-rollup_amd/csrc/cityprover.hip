@@ -872,3 +872,5 @@ int cp_commit_dev(cp_ctx *ctx, const uint64_t *values, size_t k, int log_n, int 
 #include "quotient.h"
 #include "prover_tail.inc"
 #include "verify.inc"
+#include "msm.h"
+#include "msm.inc"

@@ -1,0 +1,133 @@
+// Multi-scalar multiplication over BLS12-381 G1 (the G1 MSMs of the Groth16 wrap proof),
+// bucket method: sum_i k_i P_i = sum_w 2^(c w) sum_d d * B[w][d], B[w][d] = sum of the points whose w-th c-bit digit is d.
+//
+//   k_points_to_mont   canonical affine points -> Montgomery form (once per point set: a proving key is fixed)
+//   k_hist / k_scan / k_scatter   counting sort of the point indices by digit, per window (atomics; the order inside
+//                      a bucket is arbitrary, the group law does not care)
+//   k_bucket_sum       one lane per (window, digit): mixed additions of its points into a Jacobian accumulator
+//   k_segment_reduce   one lane per (window, run of SEG buckets): sum_d d*B_d over the run by the running-sum trick plus
+//                      a small scalar multiple for the run's offset
+//   k_pair_reduce      tree reduction of the runs of a window
+// The 2^(c w) combination of the window sums and the final inversion run on the host (a few hundred point operations).
+// Exact integer arithmetic: the result is the same group element whatever the summation order.
+#pragma once
+#include "bls12_381.h"
+
+namespace msm {
+
+using bls::Affine;
+using bls::Fp;
+using bls::Jac;
+
+constexpr int SCALAR_WORDS = 8;  // 256-bit scalars, little-endian 32-bit words
+constexpr int SEG = 32;          // buckets per k_segment_reduce lane
+
+__device__ __forceinline__ uint32_t digit(const uint32_t *k, int w, int c) {
+  const int bit = w * c;
+  if (bit >= 32 * SCALAR_WORDS) return 0;
+  const int word = bit >> 5, sh = bit & 31;
+  uint64_t v = k[word];
+  if (word + 1 < SCALAR_WORDS) v |= (uint64_t)k[word + 1] << 32;
+  return (uint32_t)(v >> sh) & ((1u << c) - 1);
+}
+
+__global__ __launch_bounds__(128) void k_points_to_mont(const uint32_t *__restrict__ xy, size_t n, Affine *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i].x = bls::fp_from_canonical(xy + 24 * i);
+  out[i].y = bls::fp_from_canonical(xy + 24 * i + 12);
+}
+
+// grid = (n/256, windows)
+__global__ void k_hist(const uint32_t *__restrict__ scalars, const uint8_t *__restrict__ inf, size_t n, int c,
+                       uint32_t *__restrict__ counts) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || (inf && inf[i])) return;
+  const int w = blockIdx.y;
+  const uint32_t d = digit(scalars + SCALAR_WORDS * i, w, c);
+  if (d) atomicAdd(&counts[((size_t)w << c) + d], 1u);
+}
+// one workgroup of 1024 lanes per window: exclusive scan of its 2^c counts -> offsets, cursor = offsets
+__global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ counts, int c, uint32_t *__restrict__ offsets,
+                                               uint32_t *__restrict__ cursor) {
+  __shared__ uint32_t part[1024];
+  const size_t base = (size_t)blockIdx.x << c;
+  const uint32_t nb = 1u << c, per = (nb + 1023) / 1024;
+  const uint32_t lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+  uint32_t s = 0;
+  for (uint32_t d = lo; d < hi; d++) s += counts[base + d];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    uint32_t v = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+  for (uint32_t d = lo; d < hi; d++) {
+    offsets[base + d] = run;
+    cursor[base + d] = run;
+    run += counts[base + d];
+  }
+}
+__global__ void k_scatter(const uint32_t *__restrict__ scalars, const uint8_t *__restrict__ inf, size_t n, int c,
+                          uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || (inf && inf[i])) return;
+  const int w = blockIdx.y;
+  const uint32_t d = digit(scalars + SCALAR_WORDS * i, w, c);
+  if (!d) return;
+  const uint32_t pos = atomicAdd(&cursor[((size_t)w << c) + d], 1u);
+  sorted[(size_t)w * n + pos] = (uint32_t)i;
+}
+
+// grid = (2^c / 128, windows): bucket (w, d) = sum of its points
+__global__ __launch_bounds__(128) void k_bucket_sum(const Affine *__restrict__ pts, const uint32_t *__restrict__ counts,
+                                                    const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ sorted,
+                                                    size_t n, int c, Jac *__restrict__ buckets) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >> c) return;
+  const int w = blockIdx.y;
+  const size_t b = ((size_t)w << c) + d;
+  Jac acc = bls::jac_inf();
+  if (d) {
+    const uint32_t *idx = sorted + (size_t)w * n + offsets[b];
+    const uint32_t cnt = counts[b];
+    for (uint32_t t = 0; t < cnt; t++) acc = bls::jac_add_mixed(acc, pts[idx[t]]);
+  }
+  buckets[b] = acc;
+}
+
+// grid = ((2^c / SEG) / 64, windows): out[w][seg] = sum_{d in run} d * B[w][d]
+__global__ __launch_bounds__(64) void k_segment_reduce(const Jac *__restrict__ buckets, int c, Jac *__restrict__ out) {
+  const uint32_t segs = (1u << c) / SEG;
+  const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= segs) return;
+  const int w = blockIdx.y;
+  const uint32_t s = seg * SEG;
+  const Jac *B = buckets + ((size_t)w << c);
+  Jac running = bls::jac_inf(), acc = bls::jac_inf();
+  for (int d = (int)(s + SEG) - 1; d >= (int)s; d--) {
+    running = bls::jac_add(running, B[d]);
+    acc = bls::jac_add(acc, running);
+  }
+  // acc = sum (d - s + 1) B_d, running = T = sum B_d  ->  sum d B_d = acc + (s - 1) T
+  Jac off;
+  if (s == 0) {  // -T
+    off = running;
+    off.y = bls::fp_sub(bls::fp_zero(), off.y);
+  } else {
+    off = bls::jac_mul_small(running, s - 1);
+  }
+  out[(size_t)w * segs + seg] = bls::jac_add(acc, off);
+}
+// data[w][i] += data[w][i + half] for i < half   (grid = (half/64, windows))
+__global__ __launch_bounds__(64) void k_pair_reduce(Jac *__restrict__ data, uint32_t stride, uint32_t half) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= half) return;
+  Jac *row = data + (size_t)blockIdx.y * stride;
+  row[i] = bls::jac_add(row[i], row[i + half]);
+}
+
+}  // namespace msm

@@ -297,6 +297,23 @@ int cp_prove_batch_zk_host(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circ
 int cp_verify(cp_circuit *circuit, const uint8_t *proof, size_t proof_len);
 void cp_free(void *ptr);
 
+/* ---- BLS12-381 G1 multi-scalar multiplication ---------------------------------
+ * The G1 MSMs of the Groth16 wrap proof: replaces the CPU MSM inside `gnark_plonky2_wrapper::wrap_plonky2_proof`
+ * (reference call sites: city_rollup_circuit/src/worker/toolbox/root.rs:296-304,
+ * city_rollup_core_worker/src/lib.rs:121; the arithmetic itself is gnark-crypto's, a Go dependency outside the tree).
+ * Scalars: 4 little-endian u64 per scalar (any 256-bit integer). Points: affine x || y, 6 + 6 little-endian u64 of the
+ * canonical (non-Montgomery) coordinates; points_inf: optional byte flags, non-zero = the point at infinity.
+ * Result: affine canonical coordinates + infinity flag. First step of row A12 (G2 MSM, F_r NTTs and the witness
+ * solver are not built). */
+int cp_msm_bls12381_g1(cp_ctx *ctx, const uint64_t *scalars_host, const uint64_t *points_xy_host,
+                       const uint8_t *points_inf_host, size_t n, uint64_t out_xy[12], int *out_is_infinity);
+/* Device-resident variant for a fixed point set (a proving key): convert once to the library's internal form
+ * (points_mont_dev: n * CP_G1_AFFINE_BYTES bytes, caller-allocated), then run any number of MSMs against it. */
+#define CP_G1_AFFINE_BYTES 96
+int cp_msm_bls12381_g1_prepare_dev(cp_ctx *ctx, const uint64_t *points_xy_dev, size_t n, void *points_mont_dev);
+int cp_msm_bls12381_g1_dev(cp_ctx *ctx, const uint64_t *scalars_dev, const void *points_mont_dev,
+                           const uint8_t *points_inf_dev, size_t n, uint64_t out_xy[12], int *out_is_infinity);
+
 #ifdef __cplusplus
 }
 #endif

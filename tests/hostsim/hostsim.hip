@@ -50,3 +50,45 @@ void hs_round16(uint64_t *x, int inverse) {
   for (int i = 0; i < 16; i++) x[i] = r[i];
 }
 }
+
+// ---- BLS12-381 (csrc/bls12_381.h) ----
+#include "../../city-rollup_amd/csrc/bls12_381.h"
+extern "C" {
+// canonical 12-word operands -> canonical (a*b mod p, a+b, a-b by op 0/1/2; 3: a^-1)
+void hs_bls_fp_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *out) {
+  bls::Fp x = bls::fp_from_canonical(a), y = bls::fp_from_canonical(b), r;
+  switch (op) {
+    case 0: r = bls::fp_mul(x, y); break;
+    case 1: r = bls::fp_add(x, y); break;
+    case 2: r = bls::fp_sub(x, y); break;
+    default: r = bls::fp_inv(x); break;
+  }
+  bls::fp_to_canonical(r, out);
+}
+static bls::Jac hs_load(const uint32_t *xy, int inf) {
+  if (inf) return bls::jac_inf();
+  bls::Jac p;
+  p.x = bls::fp_from_canonical(xy);
+  p.y = bls::fp_from_canonical(xy + 12);
+  p.z = bls::fp_one();
+  return p;
+}
+// op 0: general add (both lifted to Jacobian, p scaled to a non-trivial z first), 1: mixed add, 2: double p, 3: p * k
+int hs_bls_g1_op(int op, const uint32_t *p_xy, int p_inf, const uint32_t *q_xy, int q_inf, uint32_t k, uint32_t *out_xy) {
+  bls::Jac p = hs_load(p_xy, p_inf), q = hs_load(q_xy, q_inf), r;
+  if (!p_inf) {  // give p a z != 1 so the projective formulas are exercised: (x z^2, y z^3, z), z = 3 (Montgomery)
+    bls::Fp z = bls::fp_add(bls::fp_one(), bls::fp_add(bls::fp_one(), bls::fp_one()));
+    bls::Fp z2 = bls::fp_sqr(z);
+    p.x = bls::fp_mul(p.x, z2);
+    p.y = bls::fp_mul(p.y, bls::fp_mul(z2, z));
+    p.z = z;
+  }
+  switch (op) {
+    case 0: r = bls::jac_add(p, q); break;
+    case 1: { bls::Affine a{q.x, q.y}; r = q_inf ? p : bls::jac_add_mixed(p, a); break; }
+    case 2: r = bls::jac_double(p); break;
+    default: r = bls::jac_mul_small(p, k); break;
+  }
+  return bls::jac_to_affine_canonical(r, out_xy) ? 1 : 0;
+}
+}

@@ -1,0 +1,107 @@
+"""GPU parity of the BLS12-381 G1 MSM (cp_msm_bls12381_g1) against the oracle's by-definition
+sum of scalar multiples, plus size-independent properties at sizes the oracle does not reach."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def prover():
+    import cityprover
+    p = cityprover.Prover(0)
+    yield p
+    p.close()
+
+
+def limbs(v, n):
+    return [(int(v) >> (64 * i)) & (2**64 - 1) for i in range(n)]
+
+
+def make_points(count, seed):
+    """count distinct multiples of the generator, via the oracle (affine canonical limbs)"""
+    _, r, G = O.bls_constants()
+    rng = np.random.default_rng(seed)
+    ks = [int.from_bytes(rng.bytes(32), "little") % r for _ in range(count)]
+    pts = [O.bls_g1_mul(G, k) for k in ks]
+    return ks, pts, np.array([limbs(P[0], 6) + limbs(P[1], 6) for P in pts], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 100, 1000])
+def test_msm_matches_oracle(prover, n):
+    import cityprover as cp
+    _, r, G = O.bls_constants()
+    rng = np.random.default_rng(n)
+    base_k, pts, xy = make_points(min(n, 24), n)
+    idx = rng.integers(0, len(pts), n)
+    xy_n = xy[idx]
+    scal = [int.from_bytes(rng.bytes(32), "little") for _ in range(n)]     # full 256-bit scalars (not reduced mod r)
+    edge = [0, 1, 2, r - 1, r, r + 1, 2**256 - 1, 2**255, 65535, 65536]
+    for i, e in enumerate(edge[:n]):
+        scal[i] = e
+    sc = np.array([limbs(k, 4) for k in scal], dtype=np.uint64)
+    O.lib().or_set_threads(8)
+    try:
+        want = O.bls_g1_msm(sc, xy_n)
+    finally:
+        O.lib().or_set_threads(1)
+    assert cp.msm_g1(prover, sc, xy_n) == want
+    # the answer is also (sum k_i * a_i) * G for points a_i * G
+    assert want == O.bls_g1_mul(G, sum(k * base_k[j] for k, j in zip(scal, idx)) % r)
+
+
+def test_msm_special_inputs(prover):
+    import cityprover as cp
+    p, r, G = O.bls_constants()
+    g = np.array([limbs(G[0], 6) + limbs(G[1], 6)], dtype=np.uint64)
+    neg = np.array([limbs(G[0], 6) + limbs(p - G[1], 6)], dtype=np.uint64)
+    one = np.array([limbs(1, 4)], dtype=np.uint64)
+    assert cp.msm_g1(prover, np.zeros((0, 4), np.uint64), np.zeros((0, 12), np.uint64)) is None
+    assert cp.msm_g1(prover, one, g) == G
+    assert cp.msm_g1(prover, np.array([limbs(0, 4)], dtype=np.uint64), g) is None
+    assert cp.msm_g1(prover, np.array([limbs(r, 4)], dtype=np.uint64), g) is None
+    # identical points land in the same bucket (doubling branch); a point and its negative cancel
+    n = 300
+    assert cp.msm_g1(prover, np.repeat(one, n, 0), np.repeat(g, n, 0)) == O.bls_g1_mul(G, n)
+    both = np.concatenate([np.repeat(g, 5, 0), np.repeat(neg, 5, 0)])
+    assert cp.msm_g1(prover, np.repeat(one, 10, 0), both) is None
+    # infinity flags
+    flags = np.zeros(10, np.uint8)
+    flags[5:] = 1
+    assert cp.msm_g1(prover, np.repeat(one, 10, 0), both, flags) == O.bls_g1_mul(G, 5)
+    # a coordinate >= p is refused
+    bad = g.copy()
+    bad[0, :6] = limbs(p, 6)
+    with pytest.raises(cp.CityProverError, match="canonical"):
+        cp.msm_g1(prover, one, bad)
+
+
+def test_msm_large_properties(prover):
+    """2^16 points (beyond the oracle's reach): points drawn from 64 known multiples a_j * G, so that
+    MSM = (sum k_i a_j(i)) * G; and linearity MSM(k + k') = MSM(k) + MSM(k')."""
+    import cityprover as cp
+    _, r, G = O.bls_constants()
+    n = 1 << 16
+    rng = np.random.default_rng(99)
+    base_k, pts, xy = make_points(64, 7)
+    idx = rng.integers(0, 64, n)
+    xy_n = np.ascontiguousarray(xy[idx])
+    k1 = rng.integers(0, 2**63, (n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (n, 4), dtype=np.uint64)
+    k1[:, 3] >>= np.uint64(2)     # keep k1 + k2 below 2^256
+    k2 = rng.integers(0, 2**62, (n, 4), dtype=np.uint64)
+    to_int = lambda a: [sum(int(a[i, j]) << (64 * j) for j in range(4)) for i in range(a.shape[0])]
+    i1, i2 = to_int(k1), to_int(k2)
+    base = np.array(base_k, dtype=object)
+    m1 = cp.msm_g1(prover, k1, xy_n)
+    assert m1 == O.bls_g1_mul(G, int(sum(k * base_k[j] for k, j in zip(i1, idx)) % r))
+    ksum = np.array([limbs(a + b, 4) for a, b in zip(i1, i2)], dtype=np.uint64)
+    m2 = cp.msm_g1(prover, k2, xy_n)
+    assert cp.msm_g1(prover, ksum, xy_n) == O.bls_g1_add(m1, m2)
+    # device-resident point set
+    P = cp.G1Points(prover, xy_n)
+    ds = prover.to_device(k1)
+    assert P.msm_dev(ds.ptr) == m1
+    ds.free()
+    P.free()

@@ -127,3 +127,52 @@ def test_renorm_preserves_the_value_and_bounds(hs):
         l0, l1, l2 = ll[0], ll[1], ll[2]
         assert l0 < (1 << 23) and l1 < (1 << 23) and l2 < (1 << 20), (y, l0, l1, l2)
         assert (l0 + (l1 << 22) + (l2 << 44)) % P == (y[0] + (y[1] << 22) + (y[2] << 44)) % P, y
+
+
+# ---- BLS12-381 device formulas (csrc/bls12_381.h) on the host ------------------------------------------------
+def _w32(v, n=12):
+    return (ctypes.c_uint32 * n)(*[(int(v) >> (32 * i)) & 0xFFFFFFFF for i in range(n)])
+
+
+def _from_w32(w):
+    return sum(int(x) << (32 * i) for i, x in enumerate(w))
+
+
+def test_bls_field_ops_match_python_integers(hs):
+    p, r, G = O.bls_constants()
+    rng = np.random.default_rng(4)
+    vals = [0, 1, 2, p - 1, p - 2, (1 << 380) + 12345, G[0], G[1]] + [int.from_bytes(rng.bytes(48), "little") % p for _ in range(40)]
+    out = (ctypes.c_uint32 * 12)()
+    for i in range(len(vals) - 1):
+        a, b = vals[i], vals[i + 1]
+        for op, want in ((0, a * b % p), (1, (a + b) % p), (2, (a - b) % p)):
+            hs.hs_bls_fp_op(op, _w32(a), _w32(b), out)
+            assert _from_w32(out) == want, (op, hex(a), hex(b))
+    for a in vals[1:12]:
+        hs.hs_bls_fp_op(3, _w32(a), _w32(0), out)
+        assert _from_w32(out) * a % p == 1
+
+
+def test_bls_group_law_matches_oracle(hs):
+    p, r, G = O.bls_constants()
+    rng = np.random.default_rng(5)
+
+    def run(op, P, Q, k=0):
+        pxy = (ctypes.c_uint32 * 24)(*(list(_w32(P[0])) + list(_w32(P[1])))) if P else (ctypes.c_uint32 * 24)()
+        qxy = (ctypes.c_uint32 * 24)(*(list(_w32(Q[0])) + list(_w32(Q[1])))) if Q else (ctypes.c_uint32 * 24)()
+        out = (ctypes.c_uint32 * 24)()
+        inf = hs.hs_bls_g1_op(op, pxy, 0 if P else 1, qxy, 0 if Q else 1, k, out)
+        return None if inf else (_from_w32(out[:12]), _from_w32(out[12:]))
+
+    pts = [O.bls_g1_mul(G, int.from_bytes(rng.bytes(32), "little") % r) for _ in range(5)] + [G]
+    neg = lambda P: (P[0], p - P[1])
+    for A in pts:
+        for B in pts[:3]:
+            assert run(0, A, B) == O.bls_g1_add(A, B)
+            assert run(1, A, B) == O.bls_g1_add(A, B)
+        assert run(0, A, A) == run(1, A, A) == run(2, A, None) == O.bls_g1_mul(A, 2)     # the doubling branch
+        assert run(0, A, neg(A)) is None and run(1, A, neg(A)) is None                    # the cancelling branch
+        assert run(0, A, None) == A and run(0, None, A) == A and run(1, None, A) == A
+        for k in (0, 1, 2, 3, 255, 65535, 40000):
+            assert run(3, A, None, k) == O.bls_g1_mul(A, k)
+    assert run(2, None, None) is None and run(3, None, None, 7) is None
