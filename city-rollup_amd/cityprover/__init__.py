@@ -596,6 +596,7 @@ _u8p = ctypes.POINTER(ctypes.c_uint8)
 ABI["cp_msm_bls12381_g1"] = (ctypes.c_int, [_vp, _u64p, _u64p, _u8p, ctypes.c_size_t, _u64p, ctypes.POINTER(ctypes.c_int)])
 ABI["cp_msm_bls12381_g1_prepare_dev"] = (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp])
 ABI["cp_msm_bls12381_g1_dev"] = (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _u64p, ctypes.POINTER(ctypes.c_int)])
+ABI["cp_msm_bls12381_g1_synthetic_points_dev"] = (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_size_t, _vp])
 G1_AFFINE_BYTES = 96
 
 
@@ -631,6 +632,17 @@ class G1Points:
         prover._check(prover.lib.cp_msm_bls12381_g1_prepare_dev(prover.ctx, raw.ptr, self.n, self.buf.ptr))
         prover.sync()
         raw.free()
+
+    @classmethod
+    def synthetic(cls, prover, generator, a, b, n):
+        """P_i = (a*i + b) * generator, built on the device (bench / large tests)."""
+        self = cls.__new__(cls)
+        self.prover, self.n = prover, n
+        self.buf = prover.alloc(n * G1_AFFINE_BYTES // 8)
+        g = np.array([(int(generator[h]) >> (64 * i)) & (2**64 - 1) for h in range(2) for i in range(6)], dtype=np.uint64)
+        prover._check(prover.lib.cp_msm_bls12381_g1_synthetic_points_dev(prover.ctx, _ptr(g), a, b, n, self.buf.ptr))
+        prover.sync()
+        return self
 
     def msm_dev(self, scalars_ptr):
         out, oi = np.zeros(12, np.uint64), ctypes.c_int()

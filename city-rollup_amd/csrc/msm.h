@@ -21,6 +21,7 @@ using bls::Jac;
 
 constexpr int SCALAR_WORDS = 8;  // 256-bit scalars, little-endian 32-bit words
 constexpr int SEG = 32;          // buckets per k_segment_reduce lane
+constexpr uint32_t HEAVY = 128;  // buckets with more points than this are summed by a whole workgroup (k_heavy_sum)
 
 __device__ __forceinline__ uint32_t digit(const uint32_t *k, int w, int c) {
   const int bit = w * c;
@@ -36,6 +37,20 @@ __global__ __launch_bounds__(128) void k_points_to_mont(const uint32_t *__restri
   if (i >= n) return;
   out[i].x = bls::fp_from_canonical(xy + 24 * i);
   out[i].y = bls::fp_from_canonical(xy + 24 * i + 12);
+}
+
+// synthetic point set for benches and large-size tests: P_i = (a*i + b) * G, a and b < 2^16, written in the internal
+// (Montgomery affine) form. Independent lanes: two small scalar multiples, one addition, one inversion each.
+__global__ __launch_bounds__(64) void k_synthetic_points(Affine g, uint32_t a, uint32_t b, size_t n, Affine *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Jac G;
+  G.x = g.x; G.y = g.y; G.z = bls::fp_one();
+  // (a*i + b) G = i * (a G) + b G, with i < 2^32
+  Jac p = bls::jac_add(bls::jac_mul_small(bls::jac_mul_small(G, a), (uint32_t)i), bls::jac_mul_small(G, b));
+  const Fp zi = bls::fp_inv(p.z), zi2 = bls::fp_sqr(zi);
+  out[i].x = bls::fp_mul(p.x, zi2);
+  out[i].y = bls::fp_mul(p.y, bls::fp_mul(zi2, zi));
 }
 
 // grid = (n/256, windows)
@@ -94,9 +109,40 @@ __global__ __launch_bounds__(128) void k_bucket_sum(const Affine *__restrict__ p
   if (d) {
     const uint32_t *idx = sorted + (size_t)w * n + offsets[b];
     const uint32_t cnt = counts[b];
+    if (cnt > HEAVY) return;  // k_heavy_sum writes this one
     for (uint32_t t = 0; t < cnt; t++) acc = bls::jac_add_mixed(acc, pts[idx[t]]);
   }
   buckets[b] = acc;
+}
+
+// Skewed scalars (few distinct digits in a window; witness vectors full of 0/1) put many points into one bucket; a
+// single lane would add them one after the other. Heavy buckets are listed here ...
+__global__ void k_heavy_list(const uint32_t *__restrict__ counts, size_t total_buckets, uint32_t *__restrict__ n_heavy,
+                             uint32_t *__restrict__ heavy) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= total_buckets || counts[b] <= HEAVY) return;
+  heavy[atomicAdd(n_heavy, 1u)] = (uint32_t)b;
+}
+// ... and each is summed by one workgroup: 256 strided partial sums, then a tree in LDS.
+__global__ __launch_bounds__(256) void k_heavy_sum(const Affine *__restrict__ pts, const uint32_t *__restrict__ counts,
+                                                   const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ sorted,
+                                                   size_t n, int c, const uint32_t *__restrict__ n_heavy,
+                                                   const uint32_t *__restrict__ heavy, Jac *__restrict__ buckets) {
+  __shared__ Jac part[256];
+  if (blockIdx.x >= *n_heavy) return;
+  const size_t b = heavy[blockIdx.x];
+  const size_t w = b >> c;
+  const uint32_t *idx = sorted + w * n + offsets[b];
+  const uint32_t cnt = counts[b];
+  Jac acc = bls::jac_inf();
+  for (uint32_t t = threadIdx.x; t < cnt; t += 256) acc = bls::jac_add_mixed(acc, pts[idx[t]]);
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int half = 128; half >= 1; half >>= 1) {
+    if ((int)threadIdx.x < half) part[threadIdx.x] = bls::jac_add(part[threadIdx.x], part[threadIdx.x + half]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) buckets[b] = part[0];
 }
 
 // grid = ((2^c / SEG) / 64, windows): out[w][seg] = sum_{d in run} d * B[w][d]

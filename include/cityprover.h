@@ -311,6 +311,11 @@ int cp_msm_bls12381_g1(cp_ctx *ctx, const uint64_t *scalars_host, const uint64_t
  * (points_mont_dev: n * CP_G1_AFFINE_BYTES bytes, caller-allocated), then run any number of MSMs against it. */
 #define CP_G1_AFFINE_BYTES 96
 int cp_msm_bls12381_g1_prepare_dev(cp_ctx *ctx, const uint64_t *points_xy_dev, size_t n, void *points_mont_dev);
+/* Bench / test helper: fills points_mont_dev with P_i = (a*i + b) * G for i < n (a, b in [1, 65535]), G = any curve
+ * point given by its affine canonical coordinates — distinct points without a 100 MB upload, and a closed form for the
+ * expected MSM: (sum_i k_i (a i + b)) * G. */
+int cp_msm_bls12381_g1_synthetic_points_dev(cp_ctx *ctx, const uint64_t generator_xy[12], uint32_t a, uint32_t b,
+                                            size_t n, void *points_mont_dev);
 int cp_msm_bls12381_g1_dev(cp_ctx *ctx, const uint64_t *scalars_dev, const void *points_mont_dev,
                            const uint8_t *points_inf_dev, size_t n, uint64_t out_xy[12], int *out_is_infinity);
 

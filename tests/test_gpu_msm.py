@@ -105,3 +105,21 @@ def test_msm_large_properties(prover):
     assert P.msm_dev(ds.ptr) == m1
     ds.free()
     P.free()
+
+
+def test_msm_skewed_scalars(prover):
+    """Witness-like scalars: half are 0 or 1, the rest tiny — one bucket receives a large share of the points (the
+    workgroup path for heavy buckets), the upper windows are empty."""
+    import cityprover as cp
+    _, r, G = O.bls_constants()
+    n = 1 << 14
+    P = cp.G1Points.synthetic(prover, G, 5, 2, n)
+    rng = np.random.default_rng(11)
+    vals = rng.choice([0, 1, 1, 1, 2, 3, 255, 65537], n)
+    k = np.zeros((n, 4), np.uint64)
+    k[:, 0] = vals.astype(np.uint64)
+    ds = prover.to_device(k)
+    got = P.msm_dev(ds.ptr)
+    ds.free()
+    P.free()
+    assert got == O.bls_g1_mul(G, int(sum(int(v) * (5 * i + 2) for i, v in enumerate(vals)) % r))
