@@ -72,8 +72,10 @@ GL_HD Fp fp_sub(const Fp &a, const Fp &b) {
 }
 GL_HD Fp fp_dbl(const Fp &a) { return fp_add(a, a); }
 
-// Montgomery product a*b/R mod p (CIOS, 32-bit words)
-GL_HD Fp fp_mul(const Fp &a, const Fp &b) {
+// Montgomery product a*b/R mod p (CIOS, 32-bit words). Deliberately NOT inlined: the unrolled body is ~2 K
+// instructions and a point addition holds 11-16 of them — inlined, one kernel outgrows the instruction cache (and the
+// library takes minutes to compile); the call passes 24 + 12 VGPRs.
+__host__ __device__ __attribute__((noinline)) inline Fp fp_mul(const Fp &a, const Fp &b) {
   uint32_t t[NL + 2];
 #pragma unroll
   for (int i = 0; i < NL + 2; i++) t[i] = 0;
