@@ -126,7 +126,10 @@ def main():
     rank, local_rank, world = D.env_rank()
     dist = D.init("gloo")  # control plane only: barrier + max-reduce of the timing, no data path
 
-    prover = cp.Prover(local_rank)
+    # one rank per GPU; with more ranks than GPUs (a rehearsal of the N > 1 path on a one-GPU box) ranks share devices
+    n_dev = cp.load_library().cp_device_count()
+    device = local_rank % n_dev if n_dev > 0 else local_rank
+    prover = cp.Prover(device)
     k, log_n, n = args.cols, args.log_n, 1 << args.log_n
     # weak scaling: rank r commits its own trace (unit r of `world` independent units)
     host = splitmix64_felts(D.unit_seed(SEED, D.shard_units(world, rank, world)[0]), k * n).reshape(k, n)
@@ -214,9 +217,11 @@ def main():
         import bench_prove
         barrier()
         r1 = bench_prove.run(prover, 32, 3)
-        rt = bench_prove.run_threads(3, 32, 8, device=local_rank, host_wires=True)
+        barrier()
+        rt = bench_prove.run_threads(3, 32, 8, device=device, host_wires=True)
         import qbench_replay
-        rp = qbench_replay.run(32, threads=3, max_batch=32, device=local_rank)
+        barrier()
+        rp = qbench_replay.run(32, threads=3, max_batch=32, device=device)
         pps = D.sum_over_ranks(dist, rt["proofs_per_s_steady"])
         pps1 = D.sum_over_ranks(dist, r1["proofs_per_s"])
         bps = D.sum_over_ranks(dist, rp["blocks_per_s"])
