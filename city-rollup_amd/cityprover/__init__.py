@@ -597,7 +597,7 @@ ABI["cp_msm_bls12381_g1"] = (ctypes.c_int, [_vp, _u64p, _u64p, _u8p, ctypes.c_si
 ABI["cp_msm_bls12381_g1_prepare_dev"] = (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp])
 ABI["cp_msm_bls12381_g1_dev"] = (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _u64p, ctypes.POINTER(ctypes.c_int)])
 ABI["cp_msm_bls12381_g1_synthetic_points_dev"] = (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_size_t, _vp])
-G1_AFFINE_BYTES = 96
+G1_AFFINE_BYTES = 112
 
 
 def _g1_out(xy, inf):

@@ -5,8 +5,12 @@
 // parameterisation. __host__ __device__ throughout: the host side of the library (final affine conversion) and the
 // CPU unit tests (tests/hostsim) run the very same code as the kernels.
 //
-// Fp: 12 x 32-bit limbs, Montgomery form with R = 2^384. A product is a fully unrolled 12 x 12 CIOS whose inner
-// step is one v_mad_u64_u32 (32 x 32 + 64) plus a 32-bit carry add.
+// Fp: 14 UNSATURATED limbs of 28 bits (392 bits for the 381-bit modulus), Montgomery form with R = 2^392. With 28-bit
+// limbs a column of the schoolbook product — up to 28 partial products below 2^56 — fits a 64-bit accumulator, so the
+// product-scanning Montgomery multiplication is nothing but v_mad_u64_u32 with the accumulator as its own 64-bit
+// addend: no carry propagation and no zero-extension moves between the multiply-adds (a 12 x 32-bit CIOS spends half
+// its instructions on those). ~500 instructions per product instead of ~1300. Values are kept fully reduced (< p, limbs
+// < 2^28); additions and subtractions are plain limb loops with a 28-bit carry.
 #pragma once
 #include <stdint.h>
 
@@ -15,7 +19,10 @@
 
 namespace bls {
 
-constexpr int NL = 12;
+constexpr int NL = 14;
+constexpr int LB = 28;
+constexpr uint32_t LM = (1u << LB) - 1;
+constexpr int NW = 12;  // 32-bit words of a canonical coordinate at the API
 struct Fp { uint32_t l[NL]; };
 
 GL_HD Fp fp_zero() { Fp r; for (int i = 0; i < NL; i++) r.l[i] = 0; return r; }
@@ -23,15 +30,15 @@ GL_HD Fp fp_one() { Fp r; for (int i = 0; i < NL; i++) r.l[i] = BLS_R1[i]; retur
 GL_HD bool fp_is_zero(const Fp &a) { uint32_t o = 0; for (int i = 0; i < NL; i++) o |= a.l[i]; return o == 0; }
 GL_HD bool fp_eq(const Fp &a, const Fp &b) { uint32_t o = 0; for (int i = 0; i < NL; i++) o |= a.l[i] ^ b.l[i]; return o == 0; }
 
-// r = a - p if a >= p (a < 2p)
+// a -= p if a >= p (a < 2p, limbs < 2^28)
 GL_HD void fp_cond_sub_p(Fp &a) {
   uint32_t t[NL];
-  uint64_t br = 0;
+  uint32_t br = 0;
 #pragma unroll
   for (int i = 0; i < NL; i++) {
-    uint64_t d = (uint64_t)a.l[i] - BLS_P[i] - br;
-    t[i] = (uint32_t)d;
-    br = (d >> 32) & 1;
+    const uint32_t d = a.l[i] - BLS_P[i] - br;
+    t[i] = d & LM;
+    br = d >> 31;
   }
   if (!br) {
 #pragma unroll
@@ -40,98 +47,99 @@ GL_HD void fp_cond_sub_p(Fp &a) {
 }
 GL_HD Fp fp_add(const Fp &a, const Fp &b) {
   Fp r;
-  uint64_t c = 0;
+  uint32_t c = 0;
 #pragma unroll
   for (int i = 0; i < NL; i++) {
-    c += (uint64_t)a.l[i] + b.l[i];
-    r.l[i] = (uint32_t)c;
-    c >>= 32;
+    const uint32_t s = a.l[i] + b.l[i] + c;
+    r.l[i] = s & LM;
+    c = s >> LB;
   }
-  fp_cond_sub_p(r);  // a, b < p < 2^381: the sum fits 384 bits
+  fp_cond_sub_p(r);  // a, b < p < 2^381: the sum fits the 392 bits
   return r;
 }
 GL_HD Fp fp_sub(const Fp &a, const Fp &b) {
   Fp r;
-  uint64_t br = 0;
+  uint32_t br = 0;
 #pragma unroll
   for (int i = 0; i < NL; i++) {
-    uint64_t d = (uint64_t)a.l[i] - b.l[i] - br;
-    r.l[i] = (uint32_t)d;
-    br = (d >> 32) & 1;
+    const uint32_t d = a.l[i] - b.l[i] - br;
+    r.l[i] = d & LM;
+    br = d >> 31;
   }
-  if (br) {
-    uint64_t c = 0;
+  if (br) {  // went below zero: the limbs hold a - b + 2^392; adding p and dropping the carry gives a - b + p
+    uint32_t c = 0;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-      c += (uint64_t)r.l[i] + BLS_P[i];
-      r.l[i] = (uint32_t)c;
-      c >>= 32;
+      const uint32_t s = r.l[i] + BLS_P[i] + c;
+      r.l[i] = s & LM;
+      c = s >> LB;
     }
   }
   return r;
 }
 GL_HD Fp fp_dbl(const Fp &a) { return fp_add(a, a); }
 
-// Montgomery product a*b/R mod p (CIOS, 32-bit words). Deliberately NOT inlined: the unrolled body is ~2 K
-// instructions and a point addition holds 11-16 of them — inlined, one kernel outgrows the instruction cache (and the
-// library takes minutes to compile); the call passes 24 + 12 VGPRs.
-__host__ __device__ __attribute__((noinline)) inline Fp fp_mul(const Fp &a, const Fp &b) {
-  uint32_t t[NL + 2];
-#pragma unroll
-  for (int i = 0; i < NL + 2; i++) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < NL; i++) {
-    uint64_t c = 0;
-#pragma unroll
-    for (int j = 0; j < NL; j++) {
-      c += (uint64_t)a.l[j] * b.l[i] + t[j];
-      t[j] = (uint32_t)c;
-      c >>= 32;
-    }
-    c += t[NL];
-    t[NL] = (uint32_t)c;
-    t[NL + 1] = (uint32_t)(c >> 32);
-    const uint32_t m = t[0] * BLS_N0;
-    c = ((uint64_t)m * BLS_P[0] + t[0]) >> 32;
-#pragma unroll
-    for (int j = 1; j < NL; j++) {
-      c += (uint64_t)m * BLS_P[j] + t[j];
-      t[j - 1] = (uint32_t)c;
-      c >>= 32;
-    }
-    c += t[NL];
-    t[NL - 1] = (uint32_t)c;
-    t[NL] = t[NL + 1] + (uint32_t)(c >> 32);
-  }
+// Montgomery product a*b/R mod p, product scanning. Deliberately NOT inlined: a point addition holds 11-16 of these —
+// inlined, one kernel outgrows the instruction cache and the library takes minutes to compile.
+__host__ __device__ __attribute__((noinline)) inline Fp fp_mul(Fp a, Fp b) {  // by value: operands travel in VGPRs, not through scratch
+  uint32_t m[NL];
   Fp r;
+  uint64_t acc = 0;
 #pragma unroll
-  for (int i = 0; i < NL; i++) r.l[i] = t[i];
-  // result < 2p; t[NL] is 0 because p < 2^381 leaves three spare bits
+  for (int k = 0; k < NL; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * BLS_P[k - i];
+    m[k] = ((uint32_t)acc * BLS_N0) & LM;
+    acc += (uint64_t)m[k] * BLS_P[0];  // the low 28 bits of the column are now zero
+    acc >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL; k++) {
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)a.l[i] * b.l[k - i] + (uint64_t)m[i] * BLS_P[k - i];
+    if (k - NL < NL) r.l[k - NL] = (uint32_t)acc & LM;
+    acc >>= LB;
+  }
+  // result < 2p (both operands < p, R > 4p)
   fp_cond_sub_p(r);
   return r;
 }
 GL_HD Fp fp_sqr(const Fp &a) { return fp_mul(a, a); }
 
-GL_HD Fp fp_from_canonical(const uint32_t *w) {  // 12 little-endian 32-bit words of a value < p
+// 12 little-endian 32-bit words of a canonical value (< p)  <->  Montgomery limbs
+GL_HD Fp fp_from_canonical(const uint32_t *w) {
   Fp t, r2;
-  for (int i = 0; i < NL; i++) { t.l[i] = w[i]; r2.l[i] = BLS_R2[i]; }
+  for (int i = 0; i < NL; i++) {
+    const int bit = LB * i, word = bit >> 5, sh = bit & 31;
+    uint64_t v = word < NW ? w[word] : 0;
+    if (word + 1 < NW) v |= (uint64_t)w[word + 1] << 32;
+    t.l[i] = (uint32_t)(v >> sh) & LM;
+    r2.l[i] = BLS_R2[i];
+  }
   return fp_mul(t, r2);
 }
 GL_HD void fp_to_canonical(const Fp &a, uint32_t *w) {
   Fp one = fp_zero();
   one.l[0] = 1;
-  Fp r = fp_mul(a, one);
-  for (int i = 0; i < NL; i++) w[i] = r.l[i];
+  const Fp r = fp_mul(a, one);
+  for (int i = 0; i < NW; i++) w[i] = 0;
+  for (int i = 0; i < NL; i++) {
+    const int bit = LB * i, word = bit >> 5, sh = bit & 31;
+    const uint64_t v = (uint64_t)r.l[i] << sh;
+    if (word < NW) w[word] |= (uint32_t)v;
+    if (word + 1 < NW) w[word + 1] |= (uint32_t)(v >> 32);
+  }
 }
 // a^(p-2) — host side only in practice (one inversion per MSM)
 GL_HD Fp fp_inv(const Fp &a) {
-  uint32_t e[NL];
-  for (int i = 0; i < NL; i++) e[i] = BLS_P[i];
-  e[0] -= 2;
   Fp r = fp_one();
-  for (int i = 32 * NL - 1; i >= 0; i--) {
+  for (int i = 32 * NW - 1; i >= 0; i--) {
     r = fp_sqr(r);
-    if ((e[i / 32] >> (i % 32)) & 1) r = fp_mul(r, a);
+    uint32_t e = BLS_P32[i / 32];
+    if (i / 32 == 0) e -= 2;  // p - 2: the low word of p ends in ...aaab, no borrow
+    if ((e >> (i % 32)) & 1) r = fp_mul(r, a);
   }
   return r;
 }
@@ -200,15 +208,15 @@ GL_HD Jac jac_mul_small(const Jac &p, uint32_t k) {
   }
   return r;
 }
-// host side: Jacobian -> affine canonical words (x: 12 words, y: 12 words); returns true for infinity
+// host side: Jacobian -> affine canonical words (x: 12 x 32-bit words, then y); returns true for infinity
 GL_HD bool jac_to_affine_canonical(const Jac &p, uint32_t *xy) {
   if (jac_is_inf(p)) {
-    for (int i = 0; i < 2 * NL; i++) xy[i] = 0;
+    for (int i = 0; i < 2 * NW; i++) xy[i] = 0;
     return true;
   }
   const Fp zi = fp_inv(p.z), zi2 = fp_sqr(zi);
   fp_to_canonical(fp_mul(p.x, zi2), xy);
-  fp_to_canonical(fp_mul(p.y, fp_mul(zi2, zi)), xy + NL);
+  fp_to_canonical(fp_mul(p.y, fp_mul(zi2, zi)), xy + NW);
   return false;
 }
 GL_HD bool affine_on_curve(const Affine &q) {

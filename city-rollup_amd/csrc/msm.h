@@ -20,7 +20,7 @@ using bls::Fp;
 using bls::Jac;
 
 constexpr int SCALAR_WORDS = 8;  // 256-bit scalars, little-endian 32-bit words
-constexpr int SEG = 32;          // buckets per k_segment_reduce lane
+constexpr int SEG = 8;           // buckets per k_segment_reduce lane (short runs: the reduction is latency-bound)
 constexpr uint32_t HEAVY = 128;  // buckets with more points than this are summed by a whole workgroup (k_heavy_sum)
 
 __device__ __forceinline__ uint32_t digit(const uint32_t *k, int w, int c) {

@@ -309,7 +309,7 @@ int cp_msm_bls12381_g1(cp_ctx *ctx, const uint64_t *scalars_host, const uint64_t
                        const uint8_t *points_inf_host, size_t n, uint64_t out_xy[12], int *out_is_infinity);
 /* Device-resident variant for a fixed point set (a proving key): convert once to the library's internal form
  * (points_mont_dev: n * CP_G1_AFFINE_BYTES bytes, caller-allocated), then run any number of MSMs against it. */
-#define CP_G1_AFFINE_BYTES 96
+#define CP_G1_AFFINE_BYTES 112
 int cp_msm_bls12381_g1_prepare_dev(cp_ctx *ctx, const uint64_t *points_xy_dev, size_t n, void *points_mont_dev);
 /* Bench / test helper: fills points_mont_dev with P_i = (a*i + b) * G for i < n (a, b in [1, 65535]), G = any curve
  * point given by its affine canonical coordinates — distinct points without a 100 MB upload, and a closed form for the
