@@ -178,3 +178,118 @@ void or_bls_g1_msm(const uint64_t *scalars, const uint64_t *points_xy, const uin
   for (int t = 0; t < nt; t++) acc = g1_add(acc, part[t]);
   g1_to_affine(acc, out_xy, out_inf);
 }
+
+/* ================================================================================================================
+ * G2: the twist y^2 = x^3 + 4(1 + u) over F_p^2 = F_p[u]/(u^2 + 1). Points cross the API as 24 limbs:
+ * x.c0, x.c1, y.c0, y.c1 (value c0 + c1*u), 6 little-endian u64 each.
+ * ================================================================================================================ */
+typedef struct { fp_t c0, c1; } fp2_t;
+typedef struct { fp2_t x, y, z; } g2_t;
+
+static const uint64_t G2X0[6] = {0xd48056c8c121bdb8ULL, 0x0bac0326a805bbefULL, 0xb4510b647ae3d177ULL, 0xc6e47ad4fa403b02ULL, 0x260805272dc51051ULL, 0x024aa2b2f08f0a91ULL};
+static const uint64_t G2X1[6] = {0xe5ac7d055d042b7eULL, 0x334cf11213945d57ULL, 0xb5da61bbdc7f5049ULL, 0x596bd0d09920b61aULL, 0x7dacd3a088274f65ULL, 0x13e02b6052719f60ULL};
+static const uint64_t G2Y0[6] = {0xe193548608b82801ULL, 0x923ac9cc3baca289ULL, 0x6d429a695160d12cULL, 0xadfd9baa8cbdd3a7ULL, 0x8cc9cdc6da2e351aULL, 0x0ce5d527727d6e11ULL};
+static const uint64_t G2Y1[6] = {0xaaa9075ff05f79beULL, 0x3f370d275cec1da1ULL, 0x267492ab572e99abULL, 0xcb3e287e85a763afULL, 0x32acd2b02bc28b99ULL, 0x0606c4a02ea734ccULL};
+
+static fp2_t fp2_add(fp2_t a, fp2_t b) { fp2_t r = {fp_add(a.c0, b.c0), fp_add(a.c1, b.c1)}; return r; }
+static fp2_t fp2_sub(fp2_t a, fp2_t b) { fp2_t r = {fp_sub(a.c0, b.c0), fp_sub(a.c1, b.c1)}; return r; }
+static fp2_t fp2_mul(fp2_t a, fp2_t b) { /* schoolbook, u^2 = -1 */
+  fp2_t r = {fp_sub(fp_mul(a.c0, b.c0), fp_mul(a.c1, b.c1)), fp_add(fp_mul(a.c0, b.c1), fp_mul(a.c1, b.c0))};
+  return r;
+}
+static fp2_t fp2_sqr(fp2_t a) { return fp2_mul(a, a); }
+static int fp2_is_zero(fp2_t a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
+static int fp2_eq(fp2_t a, fp2_t b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
+static fp2_t fp2_inv(fp2_t a) { /* conj(a) / (c0^2 + c1^2) */
+  fp_t d = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));
+  fp_t z = {{0, 0, 0, 0, 0, 0}};
+  fp2_t r = {fp_mul(a.c0, d), fp_mul(fp_sub(z, a.c1), d)};
+  return r;
+}
+static fp2_t fp2_one(void) { fp_t z = {{0, 0, 0, 0, 0, 0}}; fp2_t r = {R1, z}; return r; }
+
+static g2_t g2_inf(void) { g2_t r; memset(&r, 0, sizeof r); r.x = fp2_one(); r.y = fp2_one(); return r; }
+static g2_t g2_double(g2_t p) {
+  if (fp2_is_zero(p.z)) return p;
+  fp2_t A = fp2_sqr(p.x), B = fp2_sqr(p.y), C = fp2_sqr(B);
+  fp2_t t = fp2_sqr(fp2_add(p.x, B)); t = fp2_sub(fp2_sub(t, A), C);
+  fp2_t D = fp2_add(t, t), E = fp2_add(fp2_add(A, A), A), F = fp2_sqr(E);
+  g2_t r;
+  r.x = fp2_sub(F, fp2_add(D, D));
+  fp2_t C8 = fp2_add(C, C); C8 = fp2_add(C8, C8); C8 = fp2_add(C8, C8);
+  r.y = fp2_sub(fp2_mul(E, fp2_sub(D, r.x)), C8);
+  r.z = fp2_mul(p.y, p.z); r.z = fp2_add(r.z, r.z);
+  return r;
+}
+static g2_t g2_add(g2_t p, g2_t q) {
+  if (fp2_is_zero(p.z)) return q;
+  if (fp2_is_zero(q.z)) return p;
+  fp2_t z1z1 = fp2_sqr(p.z), z2z2 = fp2_sqr(q.z);
+  fp2_t u1 = fp2_mul(p.x, z2z2), u2 = fp2_mul(q.x, z1z1);
+  fp2_t s1 = fp2_mul(fp2_mul(p.y, q.z), z2z2), s2 = fp2_mul(fp2_mul(q.y, p.z), z1z1);
+  if (fp2_eq(u1, u2)) return fp2_eq(s1, s2) ? g2_double(p) : g2_inf();
+  fp2_t h = fp2_sub(u2, u1), rr = fp2_sub(s2, s1);
+  fp2_t hh = fp2_sqr(h), hhh = fp2_mul(h, hh), v = fp2_mul(u1, hh);
+  g2_t r;
+  r.x = fp2_sub(fp2_sub(fp2_sqr(rr), hhh), fp2_add(v, v));
+  r.y = fp2_sub(fp2_mul(rr, fp2_sub(v, r.x)), fp2_mul(s1, hhh));
+  r.z = fp2_mul(fp2_mul(p.z, q.z), h);
+  return r;
+}
+static g2_t g2_from_affine(const uint64_t xy[24], int inf) {
+  if (inf) return g2_inf();
+  g2_t r;
+  r.x.c0 = fp_from_canonical(xy); r.x.c1 = fp_from_canonical(xy + 6);
+  r.y.c0 = fp_from_canonical(xy + 12); r.y.c1 = fp_from_canonical(xy + 18);
+  r.z = fp2_one();
+  return r;
+}
+static void g2_to_affine(g2_t p, uint64_t xy[24], int *inf) {
+  if (fp2_is_zero(p.z)) { memset(xy, 0, 192); *inf = 1; return; }
+  fp2_t zi = fp2_inv(p.z), zi2 = fp2_sqr(zi);
+  fp2_t x = fp2_mul(p.x, zi2), y = fp2_mul(p.y, fp2_mul(zi2, zi));
+  fp_to_canonical(x.c0, xy); fp_to_canonical(x.c1, xy + 6);
+  fp_to_canonical(y.c0, xy + 12); fp_to_canonical(y.c1, xy + 18);
+  *inf = 0;
+}
+static g2_t g2_mul(g2_t p, const uint64_t k[4]) {
+  g2_t r = g2_inf();
+  for (int i = 255; i >= 0; i--) { r = g2_double(r); if ((k[i / 64] >> (i % 64)) & 1) r = g2_add(r, p); }
+  return r;
+}
+
+void or_bls_g2_generator(uint64_t xy[24]) { memcpy(xy, G2X0, 48); memcpy(xy + 6, G2X1, 48); memcpy(xy + 12, G2Y0, 48); memcpy(xy + 18, G2Y1, 48); }
+int or_bls_g2_on_curve(const uint64_t xy[24]) {
+  init();
+  for (int k = 0; k < 4; k++) if (ge_p(xy + 6 * k)) return 0;
+  g2_t p = g2_from_affine(xy, 0);
+  const uint64_t four[6] = {4, 0, 0, 0, 0, 0};
+  fp2_t b = {fp_from_canonical(four), fp_from_canonical(four)}; /* 4 (1 + u) */
+  return fp2_eq(fp2_sqr(p.y), fp2_add(fp2_mul(fp2_sqr(p.x), p.x), b));
+}
+void or_bls_g2_add(const uint64_t a_xy[24], int a_inf, const uint64_t b_xy[24], int b_inf, uint64_t out_xy[24], int *out_inf) {
+  init();
+  g2_to_affine(g2_add(g2_from_affine(a_xy, a_inf), g2_from_affine(b_xy, b_inf)), out_xy, out_inf);
+}
+void or_bls_g2_mul(const uint64_t xy[24], int inf, const uint64_t k[4], uint64_t out_xy[24], int *out_inf) {
+  init();
+  g2_to_affine(g2_mul(g2_from_affine(xy, inf), k), out_xy, out_inf);
+}
+void or_bls_g2_msm(const uint64_t *scalars, const uint64_t *points_xy, const uint8_t *points_inf, size_t n,
+                   uint64_t out_xy[24], int *out_inf) {
+  init();
+  int nt = or_get_threads();
+  if (nt < 1) nt = 1;
+  g2_t *part = (g2_t *)__builtin_alloca(sizeof(g2_t) * (size_t)nt);
+  for (int t = 0; t < nt; t++) part[t] = g2_inf();
+#pragma omp parallel for num_threads(nt) schedule(static)
+  for (int t = 0; t < nt; t++) {
+    g2_t acc = g2_inf();
+    for (size_t i = n * (size_t)t / (size_t)nt; i < n * (size_t)(t + 1) / (size_t)nt; i++)
+      acc = g2_add(acc, g2_mul(g2_from_affine(points_xy + 24 * i, points_inf ? points_inf[i] : 0), scalars + 4 * i));
+    part[t] = acc;
+  }
+  g2_t acc = g2_inf();
+  for (int t = 0; t < nt; t++) acc = g2_add(acc, part[t]);
+  g2_to_affine(acc, out_xy, out_inf);
+}

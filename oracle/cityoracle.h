@@ -199,6 +199,14 @@ void or_bls_g1_mul(const uint64_t xy[12], int inf, const uint64_t k[4], uint64_t
 void or_bls_g1_msm(const uint64_t *scalars, const uint64_t *points_xy, const uint8_t *points_inf, size_t n,
                    uint64_t out_xy[12], int *out_inf);
 
+/* G2 (twist over F_p^2): points = x.c0, x.c1, y.c0, y.c1 (24 limbs) + infinity flag */
+void or_bls_g2_generator(uint64_t xy[24]);
+int or_bls_g2_on_curve(const uint64_t xy[24]);
+void or_bls_g2_add(const uint64_t a_xy[24], int a_inf, const uint64_t b_xy[24], int b_inf, uint64_t out_xy[24], int *out_inf);
+void or_bls_g2_mul(const uint64_t xy[24], int inf, const uint64_t k[4], uint64_t out_xy[24], int *out_inf);
+void or_bls_g2_msm(const uint64_t *scalars, const uint64_t *points_xy, const uint8_t *points_inf, size_t n,
+                   uint64_t out_xy[24], int *out_inf);
+
 /* number of worker threads the oracle uses for the batch entry points
  * (or_poseidon_permute_many, or_merkle_tree*, or_commit_batch); default 1 */
 void or_set_threads(int n);

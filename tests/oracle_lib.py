@@ -412,3 +412,53 @@ def bls_g1_msm(scalars, points_xy, points_inf=None):
     lib().or_bls_g1_msm(ptr(s), ptr(pxy), None if pi is None else pi.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
                         ctypes.c_size_t(n), ptr(out), ctypes.byref(oi))
     return _bls_out(out, oi)
+
+
+# ---- G2: points are ((x0, x1), (y0, y1)) with coordinates c0 + c1*u ----
+def bls_g2_generator():
+    g = np.zeros(24, np.uint64)
+    lib().or_bls_g2_generator(ptr(g))
+    return ((_int(g[0:6]), _int(g[6:12])), (_int(g[12:18]), _int(g[18:24])))
+
+
+def bls_point2(pt):
+    if pt is None:
+        return np.zeros(24, np.uint64), 1
+    (x0, x1), (y0, y1) = pt
+    return np.concatenate([_limbs(x0, 6), _limbs(x1, 6), _limbs(y0, 6), _limbs(y1, 6)]), 0
+
+
+def _bls_out2(xy, inf):
+    return None if inf.value else ((_int(xy[0:6]), _int(xy[6:12])), (_int(xy[12:18]), _int(xy[18:24])))
+
+
+def bls_g2_mul(pt, k):
+    xy, inf = bls_point2(pt)
+    out, oi = np.zeros(24, np.uint64), ctypes.c_int()
+    kk = _limbs(k, 4)
+    lib().or_bls_g2_mul(ptr(xy), ctypes.c_int(inf), ptr(kk), ptr(out), ctypes.byref(oi))
+    return _bls_out2(out, oi)
+
+
+def bls_g2_add(a, b):
+    axy, ai = bls_point2(a)
+    bxy, bi = bls_point2(b)
+    out, oi = np.zeros(24, np.uint64), ctypes.c_int()
+    lib().or_bls_g2_add(ptr(axy), ctypes.c_int(ai), ptr(bxy), ctypes.c_int(bi), ptr(out), ctypes.byref(oi))
+    return _bls_out2(out, oi)
+
+
+def bls_g2_on_curve(pt):
+    xy, _ = bls_point2(pt)
+    lib().or_bls_g2_on_curve.restype = ctypes.c_int
+    return bool(lib().or_bls_g2_on_curve(ptr(xy)))
+
+
+def bls_g2_msm(scalars, points_xy, points_inf=None):
+    s, pxy = arr(scalars), arr(points_xy)
+    n = s.shape[0]
+    out, oi = np.zeros(24, np.uint64), ctypes.c_int()
+    pi = None if points_inf is None else np.ascontiguousarray(points_inf, dtype=np.uint8)
+    lib().or_bls_g2_msm(ptr(s), ptr(pxy), None if pi is None else pi.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                        ctypes.c_size_t(n), ptr(out), ctypes.byref(oi))
+    return _bls_out2(out, oi)

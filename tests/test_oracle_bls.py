@@ -76,3 +76,65 @@ def test_msm_is_the_sum_of_the_scalar_multiples():
         assert O.bls_g1_msm(scal, xy) == want
     O.lib().or_set_threads(1)
     assert want == O.bls_g1_mul(G, sum(k * (3 + i) for i, k in enumerate(ks)) % r)
+
+
+# ---- G2 ------------------------------------------------------------------------------------------------------
+def f2_mul(a, b, p):
+    return ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
+
+
+def f2_inv(a, p):
+    d = pow((a[0] * a[0] + a[1] * a[1]) % p, p - 2, p)
+    return (a[0] * d % p, -a[1] * d % p)
+
+
+def affine2_add(P, Q, p):
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    (x1, y1), (x2, y2) = P, Q
+    if x1 == x2:
+        if ((y1[0] + y2[0]) % p, (y1[1] + y2[1]) % p) == (0, 0):
+            return None
+        lam = f2_mul(f2_mul((3, 0), f2_mul(x1, x1, p), p), f2_inv(((2 * y1[0]) % p, (2 * y1[1]) % p), p), p)
+    else:
+        lam = f2_mul(((y2[0] - y1[0]) % p, (y2[1] - y1[1]) % p), f2_inv(((x2[0] - x1[0]) % p, (x2[1] - x1[1]) % p), p), p)
+    l2 = f2_mul(lam, lam, p)
+    x3 = ((l2[0] - x1[0] - x2[0]) % p, (l2[1] - x1[1] - x2[1]) % p)
+    t = f2_mul(lam, ((x1[0] - x3[0]) % p, (x1[1] - x3[1]) % p), p)
+    return x3, ((t[0] - y1[0]) % p, (t[1] - y1[1]) % p)
+
+
+def affine2_mul(k, P, p):
+    R = None
+    while k:
+        if k & 1:
+            R = affine2_add(R, P, p)
+        P = affine2_add(P, P, p)
+        k >>= 1
+    return R
+
+
+def test_g2_generator_and_group_law():
+    p, r, _ = O.bls_constants()
+    G2 = O.bls_g2_generator()
+    x, y = G2
+    x3 = f2_mul(f2_mul(x, x, p), x, p)
+    assert f2_mul(y, y, p) == ((x3[0] + 4) % p, (x3[1] + 4) % p) and O.bls_g2_on_curve(G2)     # y^2 = x^3 + 4(1 + u)
+    assert not O.bls_g2_on_curve((x, ((y[0] + 1) % p, y[1])))
+    assert O.bls_g2_mul(G2, r) is None
+    rng = np.random.default_rng(8)
+    for _ in range(3):
+        a, b = (int.from_bytes(rng.bytes(32), "little") % r for _ in range(2))
+        A, B = O.bls_g2_mul(G2, a), O.bls_g2_mul(G2, b)
+        assert A == affine2_mul(a, G2, p)
+        assert O.bls_g2_add(A, B) == affine2_add(A, B, p) == O.bls_g2_mul(G2, (a + b) % r)
+    assert O.bls_g2_add(G2, G2) == O.bls_g2_mul(G2, 2) == affine2_add(G2, G2, p)
+    neg = (x, ((-y[0]) % p, (-y[1]) % p))
+    assert O.bls_g2_add(G2, neg) is None and O.bls_g2_add(G2, None) == G2
+    ks = [int.from_bytes(rng.bytes(32), "little") % r for _ in range(5)]
+    pts = [O.bls_g2_mul(G2, 2 + i) for i in range(5)]
+    scal = np.array([[(k >> (64 * j)) & (2**64 - 1) for j in range(4)] for k in ks], dtype=np.uint64)
+    xy = np.array([O.bls_point2(P)[0] for P in pts], dtype=np.uint64)
+    assert O.bls_g2_msm(scal, xy) == O.bls_g2_mul(G2, sum(k * (2 + i) for i, k in enumerate(ks)) % r)
