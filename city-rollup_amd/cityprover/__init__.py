@@ -652,3 +652,56 @@ class G1Points:
 
     def free(self):
         self.buf.free()
+
+
+# ---- G2 (coordinates c0 + c1*u in F_p^2; a point is 24 uint64: x.c0, x.c1, y.c0, y.c1) ----
+ABI["cp_msm_bls12381_g2"] = (ctypes.c_int, [_vp, _u64p, _u64p, _u8p, ctypes.c_size_t, _u64p, ctypes.POINTER(ctypes.c_int)])
+ABI["cp_msm_bls12381_g2_prepare_dev"] = (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp])
+ABI["cp_msm_bls12381_g2_synthetic_points_dev"] = (ctypes.c_int, [_vp, _u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_size_t, _vp])
+ABI["cp_msm_bls12381_g2_dev"] = (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _u64p, ctypes.POINTER(ctypes.c_int)])
+G2_AFFINE_BYTES = 224
+
+
+def _g2_out(xy, inf):
+    if inf.value:
+        return None
+    v = [sum(int(x) << (64 * i) for i, x in enumerate(xy[6 * k:6 * k + 6])) for k in range(4)]
+    return ((v[0], v[1]), (v[2], v[3]))
+
+
+def msm_g2(prover, scalars, points_xy, points_inf=None):
+    """G2 MSM. points_xy: (n, 24) uint64. Returns None or ((x0, x1), (y0, y1))."""
+    s, p = _as_u64(scalars).reshape(-1, 4), _as_u64(points_xy).reshape(-1, 24)
+    if s.shape[0] != p.shape[0]:
+        raise ValueError("scalars and points differ in count")
+    n = s.shape[0]
+    inf = None if points_inf is None else np.ascontiguousarray(points_inf, dtype=np.uint8)
+    out, oi = np.zeros(24, np.uint64), ctypes.c_int()
+    prover._check(prover.lib.cp_msm_bls12381_g2(prover.ctx, _ptr(s) if n else None, _ptr(p) if n else None,
+                                                None if inf is None else inf.ctypes.data_as(_u8p), n, _ptr(out),
+                                                ctypes.byref(oi)))
+    return _g2_out(out, oi)
+
+
+class G2Points:
+    """A fixed G2 point set resident on the device in the library's internal form."""
+
+    @classmethod
+    def synthetic(cls, prover, generator, a, b, n):
+        self = cls.__new__(cls)
+        self.prover, self.n = prover, n
+        self.buf = prover.alloc(n * G2_AFFINE_BYTES // 8)
+        (x0, x1), (y0, y1) = generator
+        g = np.array([(int(c) >> (64 * i)) & (2**64 - 1) for c in (x0, x1, y0, y1) for i in range(6)], dtype=np.uint64)
+        prover._check(prover.lib.cp_msm_bls12381_g2_synthetic_points_dev(prover.ctx, _ptr(g), a, b, n, self.buf.ptr))
+        prover.sync()
+        return self
+
+    def msm_dev(self, scalars_ptr):
+        out, oi = np.zeros(24, np.uint64), ctypes.c_int()
+        self.prover._check(self.prover.lib.cp_msm_bls12381_g2_dev(self.prover.ctx, scalars_ptr, self.buf.ptr, None, self.n,
+                                                                  _ptr(out), ctypes.byref(oi)))
+        return _g2_out(out, oi)
+
+    def free(self):
+        self.buf.free()

@@ -144,85 +144,151 @@ GL_HD Fp fp_inv(const Fp &a) {
   return r;
 }
 
-// ---- G1 -----------------------------------------------------------------------------------------------------
-struct Affine { Fp x, y; };        // Montgomery coordinates; infinity is carried separately by the callers
-struct Jac { Fp x, y, z; };        // x = X/Z^2, y = Y/Z^3; z = 0: infinity
+// ---- F_p^2 = F_p[u]/(u^2 + 1): the coordinate field of G2 ------------------------------------------------------
+struct Fp2 { Fp c0, c1; };
+GL_HD Fp2 fp2_add(const Fp2 &a, const Fp2 &b) { return {fp_add(a.c0, b.c0), fp_add(a.c1, b.c1)}; }
+GL_HD Fp2 fp2_sub(const Fp2 &a, const Fp2 &b) { return {fp_sub(a.c0, b.c0), fp_sub(a.c1, b.c1)}; }
+GL_HD Fp2 fp2_mul(const Fp2 &a, const Fp2 &b) {  // Karatsuba: three base-field products
+  const Fp v0 = fp_mul(a.c0, b.c0), v1 = fp_mul(a.c1, b.c1);
+  const Fp s = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+  return {fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
+}
+GL_HD Fp2 fp2_sqr(const Fp2 &a) {  // (c0 + c1)(c0 - c1) + 2 c0 c1 u
+  const Fp t = fp_mul(a.c0, a.c1);
+  return {fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)), fp_dbl(t)};
+}
+GL_HD Fp2 fp2_inv(const Fp2 &a) {  // conj(a) / (c0^2 + c1^2)
+  const Fp d = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));
+  return {fp_mul(a.c0, d), fp_mul(fp_sub(fp_zero(), a.c1), d)};
+}
 
-GL_HD Jac jac_inf() { Jac r; r.x = fp_one(); r.y = fp_one(); r.z = fp_zero(); return r; }
-GL_HD bool jac_is_inf(const Jac &p) { return fp_is_zero(p.z); }
+// ---- one group law for both groups: the coordinate field is a template parameter ----------------------------
+// generic field interface (overloads) + per-field constants
+GL_HD Fp f_add(const Fp &a, const Fp &b) { return fp_add(a, b); }
+GL_HD Fp f_sub(const Fp &a, const Fp &b) { return fp_sub(a, b); }
+GL_HD Fp f_dbl(const Fp &a) { return fp_dbl(a); }
+GL_HD Fp f_mul(const Fp &a, const Fp &b) { return fp_mul(a, b); }
+GL_HD Fp f_sqr(const Fp &a) { return fp_sqr(a); }
+GL_HD Fp f_inv(const Fp &a) { return fp_inv(a); }
+GL_HD bool f_is_zero(const Fp &a) { return fp_is_zero(a); }
+GL_HD bool f_eq(const Fp &a, const Fp &b) { return fp_eq(a, b); }
+GL_HD Fp2 f_add(const Fp2 &a, const Fp2 &b) { return fp2_add(a, b); }
+GL_HD Fp2 f_sub(const Fp2 &a, const Fp2 &b) { return fp2_sub(a, b); }
+GL_HD Fp2 f_dbl(const Fp2 &a) { return fp2_add(a, a); }
+GL_HD Fp2 f_mul(const Fp2 &a, const Fp2 &b) { return fp2_mul(a, b); }
+GL_HD Fp2 f_sqr(const Fp2 &a) { return fp2_sqr(a); }
+GL_HD Fp2 f_inv(const Fp2 &a) { return fp2_inv(a); }
+GL_HD bool f_is_zero(const Fp2 &a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
+GL_HD bool f_eq(const Fp2 &a, const Fp2 &b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
 
-GL_HD Jac jac_double(const Jac &p) {  // a = 0 ("dbl-2009-l")
+template <class F> struct Field;
+template <> struct Field<Fp> {
+  static constexpr int WORDS = NW;  // 32-bit words of a canonical element at the API
+  static GL_HD Fp zero() { return fp_zero(); }
+  static GL_HD Fp one() { return fp_one(); }
+  static GL_HD Fp curve_b() { Fp b; for (int i = 0; i < NL; i++) b.l[i] = BLS_B_MONT[i]; return b; }  // y^2 = x^3 + 4
+  static GL_HD Fp from_canonical(const uint32_t *w) { return fp_from_canonical(w); }
+  static GL_HD void to_canonical(const Fp &a, uint32_t *w) { fp_to_canonical(a, w); }
+};
+template <> struct Field<Fp2> {
+  static constexpr int WORDS = 2 * NW;  // c0 then c1
+  static GL_HD Fp2 zero() { return {fp_zero(), fp_zero()}; }
+  static GL_HD Fp2 one() { return {fp_one(), fp_zero()}; }
+  static GL_HD Fp2 curve_b() { const Fp b = Field<Fp>::curve_b(); return {b, b}; }  // twist: y^2 = x^3 + 4 (1 + u)
+  static GL_HD Fp2 from_canonical(const uint32_t *w) { return {fp_from_canonical(w), fp_from_canonical(w + NW)}; }
+  static GL_HD void to_canonical(const Fp2 &a, uint32_t *w) { fp_to_canonical(a.c0, w); fp_to_canonical(a.c1, w + NW); }
+};
+
+template <class F> struct AffineT { F x, y; };  // Montgomery coordinates; infinity is carried separately by the callers
+template <class F> struct JacT { F x, y, z; };  // x = X/Z^2, y = Y/Z^3; z = 0: infinity
+using Affine = AffineT<Fp>;   // G1
+using Jac = JacT<Fp>;
+using Affine2 = AffineT<Fp2>; // G2
+using Jac2 = JacT<Fp2>;
+
+template <class F> GL_HD JacT<F> jac_inf() { return {Field<F>::one(), Field<F>::one(), Field<F>::zero()}; }
+template <class F> GL_HD bool jac_is_inf(const JacT<F> &p) { return f_is_zero(p.z); }
+
+template <class F> GL_HD JacT<F> jac_double(const JacT<F> &p) {  // a = 0 ("dbl-2009-l")
   if (jac_is_inf(p)) return p;
-  const Fp A = fp_sqr(p.x), B = fp_sqr(p.y), C = fp_sqr(B);
-  Fp t = fp_sqr(fp_add(p.x, B));
-  t = fp_sub(fp_sub(t, A), C);
-  const Fp D = fp_dbl(t), E = fp_add(fp_dbl(A), A), F = fp_sqr(E);
-  Jac r;
-  r.x = fp_sub(F, fp_dbl(D));
-  const Fp C8 = fp_dbl(fp_dbl(fp_dbl(C)));
-  r.y = fp_sub(fp_mul(E, fp_sub(D, r.x)), C8);
-  r.z = fp_dbl(fp_mul(p.y, p.z));
+  const F A = f_sqr(p.x), B = f_sqr(p.y), C = f_sqr(B);
+  F t = f_sqr(f_add(p.x, B));
+  t = f_sub(f_sub(t, A), C);
+  const F D = f_dbl(t), E = f_add(f_dbl(A), A), Fq = f_sqr(E);
+  JacT<F> r;
+  r.x = f_sub(Fq, f_dbl(D));
+  const F C8 = f_dbl(f_dbl(f_dbl(C)));
+  r.y = f_sub(f_mul(E, f_sub(D, r.x)), C8);
+  r.z = f_dbl(f_mul(p.y, p.z));
   return r;
 }
 // p + q, q affine and not infinity
-GL_HD Jac jac_add_mixed(const Jac &p, const Affine &q) {
-  if (jac_is_inf(p)) { Jac r; r.x = q.x; r.y = q.y; r.z = fp_one(); return r; }
-  const Fp z1z1 = fp_sqr(p.z);
-  const Fp u2 = fp_mul(q.x, z1z1), s2 = fp_mul(fp_mul(q.y, p.z), z1z1);
-  if (fp_eq(p.x, u2)) {
-    if (fp_eq(p.y, s2)) return jac_double(p);
-    return jac_inf();
+template <class F> GL_HD JacT<F> jac_add_mixed(const JacT<F> &p, const AffineT<F> &q) {
+  if (jac_is_inf(p)) return {q.x, q.y, Field<F>::one()};
+  const F z1z1 = f_sqr(p.z);
+  const F u2 = f_mul(q.x, z1z1), s2 = f_mul(f_mul(q.y, p.z), z1z1);
+  if (f_eq(p.x, u2)) {
+    if (f_eq(p.y, s2)) return jac_double(p);
+    return jac_inf<F>();
   }
-  const Fp h = fp_sub(u2, p.x), rr = fp_sub(s2, p.y);
-  const Fp hh = fp_sqr(h), hhh = fp_mul(h, hh), v = fp_mul(p.x, hh);
-  Jac r;
-  r.x = fp_sub(fp_sub(fp_sqr(rr), hhh), fp_dbl(v));
-  r.y = fp_sub(fp_mul(rr, fp_sub(v, r.x)), fp_mul(p.y, hhh));
-  r.z = fp_mul(p.z, h);
+  const F h = f_sub(u2, p.x), rr = f_sub(s2, p.y);
+  const F hh = f_sqr(h), hhh = f_mul(h, hh), v = f_mul(p.x, hh);
+  JacT<F> r;
+  r.x = f_sub(f_sub(f_sqr(rr), hhh), f_dbl(v));
+  r.y = f_sub(f_mul(rr, f_sub(v, r.x)), f_mul(p.y, hhh));
+  r.z = f_mul(p.z, h);
   return r;
 }
-GL_HD Jac jac_add(const Jac &p, const Jac &q) {
+template <class F> GL_HD JacT<F> jac_add(const JacT<F> &p, const JacT<F> &q) {
   if (jac_is_inf(p)) return q;
   if (jac_is_inf(q)) return p;
-  const Fp z1z1 = fp_sqr(p.z), z2z2 = fp_sqr(q.z);
-  const Fp u1 = fp_mul(p.x, z2z2), u2 = fp_mul(q.x, z1z1);
-  const Fp s1 = fp_mul(fp_mul(p.y, q.z), z2z2), s2 = fp_mul(fp_mul(q.y, p.z), z1z1);
-  if (fp_eq(u1, u2)) {
-    if (fp_eq(s1, s2)) return jac_double(p);
-    return jac_inf();
+  const F z1z1 = f_sqr(p.z), z2z2 = f_sqr(q.z);
+  const F u1 = f_mul(p.x, z2z2), u2 = f_mul(q.x, z1z1);
+  const F s1 = f_mul(f_mul(p.y, q.z), z2z2), s2 = f_mul(f_mul(q.y, p.z), z1z1);
+  if (f_eq(u1, u2)) {
+    if (f_eq(s1, s2)) return jac_double(p);
+    return jac_inf<F>();
   }
-  const Fp h = fp_sub(u2, u1), rr = fp_sub(s2, s1);
-  const Fp hh = fp_sqr(h), hhh = fp_mul(h, hh), v = fp_mul(u1, hh);
-  Jac r;
-  r.x = fp_sub(fp_sub(fp_sqr(rr), hhh), fp_dbl(v));
-  r.y = fp_sub(fp_mul(rr, fp_sub(v, r.x)), fp_mul(s1, hhh));
-  r.z = fp_mul(fp_mul(p.z, q.z), h);
+  const F h = f_sub(u2, u1), rr = f_sub(s2, s1);
+  const F hh = f_sqr(h), hhh = f_mul(h, hh), v = f_mul(u1, hh);
+  JacT<F> r;
+  r.x = f_sub(f_sub(f_sqr(rr), hhh), f_dbl(v));
+  r.y = f_sub(f_mul(rr, f_sub(v, r.x)), f_mul(s1, hhh));
+  r.z = f_mul(f_mul(p.z, q.z), h);
   return r;
 }
+template <class F> GL_HD JacT<F> jac_neg(const JacT<F> &p) { return {p.x, f_sub(Field<F>::zero(), p.y), p.z}; }
 // k * p for a small scalar (window-reduction offsets), double-and-add from the top bit
-GL_HD Jac jac_mul_small(const Jac &p, uint32_t k) {
-  Jac r = jac_inf();
+template <class F> GL_HD JacT<F> jac_mul_small(const JacT<F> &p, uint32_t k) {
+  JacT<F> r = jac_inf<F>();
   for (int i = 31; i >= 0; i--) {
     r = jac_double(r);
     if ((k >> i) & 1) r = jac_add(r, p);
   }
   return r;
 }
-// host side: Jacobian -> affine canonical words (x: 12 x 32-bit words, then y); returns true for infinity
-GL_HD bool jac_to_affine_canonical(const Jac &p, uint32_t *xy) {
+// Jacobian -> affine, Montgomery coordinates (p must not be infinity)
+template <class F> GL_HD AffineT<F> jac_to_affine(const JacT<F> &p) {
+  const F zi = f_inv(p.z), zi2 = f_sqr(zi);
+  return {f_mul(p.x, zi2), f_mul(p.y, f_mul(zi2, zi))};
+}
+// host side: Jacobian -> affine canonical words (x then y, Field<F>::WORDS each); returns true for infinity
+template <class F> GL_HD bool jac_to_affine_canonical(const JacT<F> &p, uint32_t *xy) {
+  constexpr int W = Field<F>::WORDS;
   if (jac_is_inf(p)) {
-    for (int i = 0; i < 2 * NW; i++) xy[i] = 0;
+    for (int i = 0; i < 2 * W; i++) xy[i] = 0;
     return true;
   }
-  const Fp zi = fp_inv(p.z), zi2 = fp_sqr(zi);
-  fp_to_canonical(fp_mul(p.x, zi2), xy);
-  fp_to_canonical(fp_mul(p.y, fp_mul(zi2, zi)), xy + NW);
+  const AffineT<F> a = jac_to_affine(p);
+  Field<F>::to_canonical(a.x, xy);
+  Field<F>::to_canonical(a.y, xy + W);
   return false;
 }
-GL_HD bool affine_on_curve(const Affine &q) {
-  Fp b;
-  for (int i = 0; i < NL; i++) b.l[i] = BLS_B_MONT[i];
-  return fp_eq(fp_sqr(q.y), fp_add(fp_mul(fp_sqr(q.x), q.x), b));
+template <class F> GL_HD AffineT<F> affine_from_canonical(const uint32_t *xy) {
+  return {Field<F>::from_canonical(xy), Field<F>::from_canonical(xy + Field<F>::WORDS)};
+}
+template <class F> GL_HD bool affine_on_curve(const AffineT<F> &q) {
+  return f_eq(f_sqr(q.y), f_add(f_mul(f_sqr(q.x), q.x), Field<F>::curve_b()));
 }
 
 }  // namespace bls

@@ -1,4 +1,5 @@
-// Multi-scalar multiplication over BLS12-381 G1 (the G1 MSMs of the Groth16 wrap proof),
+// Multi-scalar multiplication over BLS12-381 G1 and G2 (the MSMs of the Groth16 wrap proof; the
+// kernels are templates over the coordinate field F = Fp (G1) or Fp2 (G2)),
 // bucket method: sum_i k_i P_i = sum_w 2^(c w) sum_d d * B[w][d], B[w][d] = sum of the points whose w-th c-bit digit is d.
 //
 //   k_points_to_mont   canonical affine points -> Montgomery form (once per point set: a proving key is fixed)
@@ -15,13 +16,15 @@
 
 namespace msm {
 
-using bls::Affine;
-using bls::Fp;
-using bls::Jac;
+using bls::AffineT;
+using bls::Field;
+using bls::JacT;
 
 constexpr int SCALAR_WORDS = 8;  // 256-bit scalars, little-endian 32-bit words
 constexpr int SEG = 8;           // buckets per k_segment_reduce lane (short runs: the reduction is latency-bound)
 constexpr uint32_t HEAVY = 128;  // buckets with more points than this are summed by a whole workgroup (k_heavy_sum)
+// lanes of that workgroup: the LDS tree holds one Jacobian point per lane (168 B for G1, 336 B for G2; 64 KB limit)
+template <class F> constexpr int HEAVY_LANES = sizeof(JacT<F>) <= 168 ? 256 : 128;
 
 __device__ __forceinline__ uint32_t digit(const uint32_t *k, int w, int c) {
   const int bit = w * c;
@@ -32,25 +35,23 @@ __device__ __forceinline__ uint32_t digit(const uint32_t *k, int w, int c) {
   return (uint32_t)(v >> sh) & ((1u << c) - 1);
 }
 
-__global__ __launch_bounds__(128) void k_points_to_mont(const uint32_t *__restrict__ xy, size_t n, Affine *__restrict__ out) {
+template <class F>
+__global__ __launch_bounds__(128) void k_points_to_mont(const uint32_t *__restrict__ xy, size_t n, AffineT<F> *__restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  out[i].x = bls::fp_from_canonical(xy + 24 * i);
-  out[i].y = bls::fp_from_canonical(xy + 24 * i + 12);
+  out[i] = bls::affine_from_canonical<F>(xy + 2 * Field<F>::WORDS * i);
 }
 
 // synthetic point set for benches and large-size tests: P_i = (a*i + b) * G, a and b < 2^16, written in the internal
 // (Montgomery affine) form. Independent lanes: two small scalar multiples, one addition, one inversion each.
-__global__ __launch_bounds__(64) void k_synthetic_points(Affine g, uint32_t a, uint32_t b, size_t n, Affine *__restrict__ out) {
+template <class F>
+__global__ __launch_bounds__(64) void k_synthetic_points(AffineT<F> g, uint32_t a, uint32_t b, size_t n, AffineT<F> *__restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Jac G;
-  G.x = g.x; G.y = g.y; G.z = bls::fp_one();
+  const JacT<F> G{g.x, g.y, Field<F>::one()};
   // (a*i + b) G = i * (a G) + b G, with i < 2^32
-  Jac p = bls::jac_add(bls::jac_mul_small(bls::jac_mul_small(G, a), (uint32_t)i), bls::jac_mul_small(G, b));
-  const Fp zi = bls::fp_inv(p.z), zi2 = bls::fp_sqr(zi);
-  out[i].x = bls::fp_mul(p.x, zi2);
-  out[i].y = bls::fp_mul(p.y, bls::fp_mul(zi2, zi));
+  const JacT<F> p = bls::jac_add(bls::jac_mul_small(bls::jac_mul_small(G, a), (uint32_t)i), bls::jac_mul_small(G, b));
+  out[i] = bls::jac_to_affine(p);
 }
 
 // grid = (n/256, windows)
@@ -98,14 +99,15 @@ __global__ void k_scatter(const uint32_t *__restrict__ scalars, const uint8_t *_
 }
 
 // grid = (2^c / 128, windows): bucket (w, d) = sum of its points
-__global__ __launch_bounds__(128) void k_bucket_sum(const Affine *__restrict__ pts, const uint32_t *__restrict__ counts,
+template <class F>
+__global__ __launch_bounds__(128) void k_bucket_sum(const AffineT<F> *__restrict__ pts, const uint32_t *__restrict__ counts,
                                                     const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ sorted,
-                                                    size_t n, int c, Jac *__restrict__ buckets) {
+                                                    size_t n, int c, JacT<F> *__restrict__ buckets) {
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >> c) return;
   const int w = blockIdx.y;
   const size_t b = ((size_t)w << c) + d;
-  Jac acc = bls::jac_inf();
+  JacT<F> acc = bls::jac_inf<F>();
   if (d) {
     const uint32_t *idx = sorted + (size_t)w * n + offsets[b];
     const uint32_t cnt = counts[b];
@@ -124,21 +126,22 @@ __global__ void k_heavy_list(const uint32_t *__restrict__ counts, size_t total_b
   heavy[atomicAdd(n_heavy, 1u)] = (uint32_t)b;
 }
 // ... and each is summed by one workgroup: 256 strided partial sums, then a tree in LDS.
-__global__ __launch_bounds__(256) void k_heavy_sum(const Affine *__restrict__ pts, const uint32_t *__restrict__ counts,
+template <class F>
+__global__ __launch_bounds__(256) void k_heavy_sum(const AffineT<F> *__restrict__ pts, const uint32_t *__restrict__ counts,
                                                    const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ sorted,
                                                    size_t n, int c, const uint32_t *__restrict__ n_heavy,
-                                                   const uint32_t *__restrict__ heavy, Jac *__restrict__ buckets) {
-  __shared__ Jac part[256];
+                                                   const uint32_t *__restrict__ heavy, JacT<F> *__restrict__ buckets) {
+  __shared__ JacT<F> part[HEAVY_LANES<F>];
   if (blockIdx.x >= *n_heavy) return;
   const size_t b = heavy[blockIdx.x];
   const size_t w = b >> c;
   const uint32_t *idx = sorted + w * n + offsets[b];
   const uint32_t cnt = counts[b];
-  Jac acc = bls::jac_inf();
-  for (uint32_t t = threadIdx.x; t < cnt; t += 256) acc = bls::jac_add_mixed(acc, pts[idx[t]]);
+  JacT<F> acc = bls::jac_inf<F>();
+  for (uint32_t t = threadIdx.x; t < cnt; t += HEAVY_LANES<F>) acc = bls::jac_add_mixed(acc, pts[idx[t]]);
   part[threadIdx.x] = acc;
   __syncthreads();
-  for (int half = 128; half >= 1; half >>= 1) {
+  for (int half = HEAVY_LANES<F> / 2; half >= 1; half >>= 1) {
     if ((int)threadIdx.x < half) part[threadIdx.x] = bls::jac_add(part[threadIdx.x], part[threadIdx.x + half]);
     __syncthreads();
   }
@@ -146,33 +149,29 @@ __global__ __launch_bounds__(256) void k_heavy_sum(const Affine *__restrict__ pt
 }
 
 // grid = ((2^c / SEG) / 64, windows): out[w][seg] = sum_{d in run} d * B[w][d]
-__global__ __launch_bounds__(64) void k_segment_reduce(const Jac *__restrict__ buckets, int c, Jac *__restrict__ out) {
+template <class F>
+__global__ __launch_bounds__(64) void k_segment_reduce(const JacT<F> *__restrict__ buckets, int c, JacT<F> *__restrict__ out) {
   const uint32_t segs = (1u << c) / SEG;
   const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
   if (seg >= segs) return;
   const int w = blockIdx.y;
   const uint32_t s = seg * SEG;
-  const Jac *B = buckets + ((size_t)w << c);
-  Jac running = bls::jac_inf(), acc = bls::jac_inf();
+  const JacT<F> *B = buckets + ((size_t)w << c);
+  JacT<F> running = bls::jac_inf<F>(), acc = bls::jac_inf<F>();
   for (int d = (int)(s + SEG) - 1; d >= (int)s; d--) {
     running = bls::jac_add(running, B[d]);
     acc = bls::jac_add(acc, running);
   }
   // acc = sum (d - s + 1) B_d, running = T = sum B_d  ->  sum d B_d = acc + (s - 1) T
-  Jac off;
-  if (s == 0) {  // -T
-    off = running;
-    off.y = bls::fp_sub(bls::fp_zero(), off.y);
-  } else {
-    off = bls::jac_mul_small(running, s - 1);
-  }
+  const JacT<F> off = s == 0 ? bls::jac_neg(running) : bls::jac_mul_small(running, s - 1);
   out[(size_t)w * segs + seg] = bls::jac_add(acc, off);
 }
 // data[w][i] += data[w][i + half] for i < half   (grid = (half/64, windows))
-__global__ __launch_bounds__(64) void k_pair_reduce(Jac *__restrict__ data, uint32_t stride, uint32_t half) {
+template <class F>
+__global__ __launch_bounds__(64) void k_pair_reduce(JacT<F> *__restrict__ data, uint32_t stride, uint32_t half) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= half) return;
-  Jac *row = data + (size_t)blockIdx.y * stride;
+  JacT<F> *row = data + (size_t)blockIdx.y * stride;
   row[i] = bls::jac_add(row[i], row[i + half]);
 }
 

@@ -303,7 +303,7 @@ void cp_free(void *ptr);
  * city_rollup_core_worker/src/lib.rs:121; the arithmetic itself is gnark-crypto's, a Go dependency outside the tree).
  * Scalars: 4 little-endian u64 per scalar (any 256-bit integer). Points: affine x || y, 6 + 6 little-endian u64 of the
  * canonical (non-Montgomery) coordinates; points_inf: optional byte flags, non-zero = the point at infinity.
- * Result: affine canonical coordinates + infinity flag. First step of row A12 (G2 MSM, F_r NTTs and the witness
+ * Result: affine canonical coordinates + infinity flag. First kernels of row A12 (the F_r NTTs and the witness
  * solver are not built). */
 int cp_msm_bls12381_g1(cp_ctx *ctx, const uint64_t *scalars_host, const uint64_t *points_xy_host,
                        const uint8_t *points_inf_host, size_t n, uint64_t out_xy[12], int *out_is_infinity);
@@ -318,6 +318,16 @@ int cp_msm_bls12381_g1_synthetic_points_dev(cp_ctx *ctx, const uint64_t generato
                                             size_t n, void *points_mont_dev);
 int cp_msm_bls12381_g1_dev(cp_ctx *ctx, const uint64_t *scalars_dev, const void *points_mont_dev,
                            const uint8_t *points_inf_dev, size_t n, uint64_t out_xy[12], int *out_is_infinity);
+/* The same over G2 (the twist y^2 = x^3 + 4(1+u) over F_p^2 = F_p[u]/(u^2+1)): the B-query MSM of Groth16.
+ * A coordinate is c0 + c1*u, 6 + 6 little-endian u64; a point is x.c0, x.c1, y.c0, y.c1 = 24 u64. */
+#define CP_G2_AFFINE_BYTES 224
+int cp_msm_bls12381_g2(cp_ctx *ctx, const uint64_t *scalars_host, const uint64_t *points_xy_host,
+                       const uint8_t *points_inf_host, size_t n, uint64_t out_xy[24], int *out_is_infinity);
+int cp_msm_bls12381_g2_prepare_dev(cp_ctx *ctx, const uint64_t *points_xy_dev, size_t n, void *points_mont_dev);
+int cp_msm_bls12381_g2_synthetic_points_dev(cp_ctx *ctx, const uint64_t generator_xy[24], uint32_t a, uint32_t b,
+                                            size_t n, void *points_mont_dev);
+int cp_msm_bls12381_g2_dev(cp_ctx *ctx, const uint64_t *scalars_dev, const void *points_mont_dev,
+                           const uint8_t *points_inf_dev, size_t n, uint64_t out_xy[24], int *out_is_infinity);
 
 #ifdef __cplusplus
 }

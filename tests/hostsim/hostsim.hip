@@ -65,30 +65,43 @@ void hs_bls_fp_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *out) {
   }
   bls::fp_to_canonical(r, out);
 }
-static bls::Jac hs_load(const uint32_t *xy, int inf) {
-  if (inf) return bls::jac_inf();
-  bls::Jac p;
-  p.x = bls::fp_from_canonical(xy);
-  p.y = bls::fp_from_canonical(xy + 12);
-  p.z = bls::fp_one();
-  return p;
+// F_p^2: 24-word operands (c0, c1); op 0 mul, 1 sqr, 2 inv
+void hs_bls_fp2_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *out) {
+  using F2 = bls::Field<bls::Fp2>;
+  bls::Fp2 x = F2::from_canonical(a), y = F2::from_canonical(b), r;
+  switch (op) {
+    case 0: r = bls::fp2_mul(x, y); break;
+    case 1: r = bls::fp2_sqr(x); break;
+    default: r = bls::fp2_inv(x); break;
+  }
+  F2::to_canonical(r, out);
+}
 }
 // op 0: general add (both lifted to Jacobian, p scaled to a non-trivial z first), 1: mixed add, 2: double p, 3: p * k
-int hs_bls_g1_op(int op, const uint32_t *p_xy, int p_inf, const uint32_t *q_xy, int q_inf, uint32_t k, uint32_t *out_xy) {
-  bls::Jac p = hs_load(p_xy, p_inf), q = hs_load(q_xy, q_inf), r;
-  if (!p_inf) {  // give p a z != 1 so the projective formulas are exercised: (x z^2, y z^3, z), z = 3 (Montgomery)
-    bls::Fp z = bls::fp_add(bls::fp_one(), bls::fp_add(bls::fp_one(), bls::fp_one()));
-    bls::Fp z2 = bls::fp_sqr(z);
-    p.x = bls::fp_mul(p.x, z2);
-    p.y = bls::fp_mul(p.y, bls::fp_mul(z2, z));
-    p.z = z;
+template <class F>
+static int hs_group_op(int op, const uint32_t *p_xy, int p_inf, const uint32_t *q_xy, int q_inf, uint32_t k, uint32_t *out_xy) {
+  using Fd = bls::Field<F>;
+  bls::JacT<F> p = bls::jac_inf<F>(), q = bls::jac_inf<F>(), r;
+  bls::AffineT<F> qa = bls::affine_from_canonical<F>(q_xy);
+  if (!p_inf) {  // give p a z != 1 so the projective formulas are exercised: (x z^2, y z^3, z), z = 3
+    const bls::AffineT<F> pa = bls::affine_from_canonical<F>(p_xy);
+    const F z = bls::f_add(Fd::one(), bls::f_add(Fd::one(), Fd::one())), z2 = bls::f_sqr(z);
+    p = {bls::f_mul(pa.x, z2), bls::f_mul(pa.y, bls::f_mul(z2, z)), z};
   }
+  if (!q_inf) q = {qa.x, qa.y, Fd::one()};
   switch (op) {
     case 0: r = bls::jac_add(p, q); break;
-    case 1: { bls::Affine a{q.x, q.y}; r = q_inf ? p : bls::jac_add_mixed(p, a); break; }
+    case 1: r = q_inf ? p : bls::jac_add_mixed(p, qa); break;
     case 2: r = bls::jac_double(p); break;
     default: r = bls::jac_mul_small(p, k); break;
   }
   return bls::jac_to_affine_canonical(r, out_xy) ? 1 : 0;
+}
+extern "C" {
+int hs_bls_g1_op(int op, const uint32_t *p_xy, int p_inf, const uint32_t *q_xy, int q_inf, uint32_t k, uint32_t *out_xy) {
+  return hs_group_op<bls::Fp>(op, p_xy, p_inf, q_xy, q_inf, k, out_xy);
+}
+int hs_bls_g2_op(int op, const uint32_t *p_xy, int p_inf, const uint32_t *q_xy, int q_inf, uint32_t k, uint32_t *out_xy) {
+  return hs_group_op<bls::Fp2>(op, p_xy, p_inf, q_xy, q_inf, k, out_xy);
 }
 }

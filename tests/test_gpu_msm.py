@@ -123,3 +123,54 @@ def test_msm_skewed_scalars(prover):
     ds.free()
     P.free()
     assert got == O.bls_g1_mul(G, int(sum(int(v) * (5 * i + 2) for i, v in enumerate(vals)) % r))
+
+
+# ---- G2 ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 5, 200])
+def test_g2_msm_matches_oracle(prover, n):
+    import cityprover as cp
+    _, r, _ = O.bls_constants()
+    G2 = O.bls_g2_generator()
+    rng = np.random.default_rng(100 + n)
+    base_k = [int.from_bytes(rng.bytes(32), "little") % r for _ in range(min(n, 12))]
+    pts = [O.bls_g2_mul(G2, k) for k in base_k]
+    xy = np.array([O.bls_point2(P)[0] for P in pts], dtype=np.uint64)
+    idx = rng.integers(0, len(pts), n)
+    scal = [int.from_bytes(rng.bytes(32), "little") for _ in range(n)]
+    for i, e in enumerate([0, 1, r - 1, r, 2**256 - 1][:n]):
+        scal[i] = e
+    sc = np.array([limbs(k, 4) for k in scal], dtype=np.uint64)
+    O.lib().or_set_threads(8)
+    try:
+        want = O.bls_g2_msm(sc, xy[idx])
+    finally:
+        O.lib().or_set_threads(1)
+    assert cp.msm_g2(prover, sc, xy[idx]) == want
+    assert want == O.bls_g2_mul(G2, sum(k * base_k[j] for k, j in zip(scal, idx)) % r)
+
+
+def test_g2_msm_large_closed_form(prover):
+    import cityprover as cp
+    _, r, _ = O.bls_constants()
+    G2 = O.bls_g2_generator()
+    n = 1 << 14
+    P = cp.G2Points.synthetic(prover, G2, 3, 11, n)
+    rng = np.random.default_rng(21)
+    k = rng.integers(0, 2**64, (n, 4), dtype=np.uint64)
+    k[:, 3] >>= np.uint64(1)
+    k[:100] = 0
+    k[:100, 0] = 1          # a heavy bucket
+    ds = prover.to_device(k)
+    got = P.msm_dev(ds.ptr)
+    ds.free()
+    P.free()
+    ks = [sum(int(k[i, j]) << (64 * j) for j in range(4)) for i in range(n)]
+    assert got == O.bls_g2_mul(G2, sum(kk * (3 * i + 11) for i, kk in enumerate(ks)) % r)
+    g = np.array([O.bls_point2(G2)[0]], dtype=np.uint64)
+    neg = g.copy()
+    p = O.bls_constants()[0]
+    neg[0, 12:18] = limbs(p - G2[1][0], 6)
+    neg[0, 18:24] = limbs(p - G2[1][1], 6)
+    one = np.array([limbs(1, 4)], dtype=np.uint64)
+    assert cp.msm_g2(prover, np.repeat(one, 2, 0), np.concatenate([g, neg])) is None
+    assert cp.msm_g2(prover, np.repeat(one, 9, 0), np.repeat(g, 9, 0)) == O.bls_g2_mul(G2, 9)

@@ -176,3 +176,47 @@ def test_bls_group_law_matches_oracle(hs):
         for k in (0, 1, 2, 3, 255, 65535, 40000):
             assert run(3, A, None, k) == O.bls_g1_mul(A, k)
     assert run(2, None, None) is None and run(3, None, None, 7) is None
+
+
+def test_bls_fp2_and_g2_formulas(hs):
+    """The G2 instantiation of the templated group law (coordinates in F_p^2) against the oracle, on the host."""
+    p, r, _ = O.bls_constants()
+    G2 = O.bls_g2_generator()
+    rng = np.random.default_rng(6)
+
+    def w2(c):   # (c0, c1) -> 24 words
+        return (ctypes.c_uint32 * 24)(*(list(_w32(c[0])) + list(_w32(c[1]))))
+
+    out = (ctypes.c_uint32 * 24)()
+    for _ in range(20):
+        a = (int.from_bytes(rng.bytes(48), "little") % p, int.from_bytes(rng.bytes(48), "little") % p)
+        b = (int.from_bytes(rng.bytes(48), "little") % p, int.from_bytes(rng.bytes(48), "little") % p)
+        hs.hs_bls_fp2_op(0, w2(a), w2(b), out)
+        assert (_from_w32(out[:12]), _from_w32(out[12:])) == ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
+        hs.hs_bls_fp2_op(1, w2(a), w2(a), out)
+        assert (_from_w32(out[:12]), _from_w32(out[12:])) == ((a[0] * a[0] - a[1] * a[1]) % p, 2 * a[0] * a[1] % p)
+        hs.hs_bls_fp2_op(2, w2(a), w2(a), out)
+        inv = (_from_w32(out[:12]), _from_w32(out[12:]))
+        assert ((a[0] * inv[0] - a[1] * inv[1]) % p, (a[0] * inv[1] + a[1] * inv[0]) % p) == (1, 0)
+
+    def pt_words(P):
+        if P is None:
+            return (ctypes.c_uint32 * 48)()
+        (x0, x1), (y0, y1) = P
+        return (ctypes.c_uint32 * 48)(*(list(_w32(x0)) + list(_w32(x1)) + list(_w32(y0)) + list(_w32(y1))))
+
+    def run(op, P, Q, k=0):
+        o = (ctypes.c_uint32 * 48)()
+        inf = hs.hs_bls_g2_op(op, pt_words(P), 0 if P else 1, pt_words(Q), 0 if Q else 1, k, o)
+        return None if inf else ((_from_w32(o[0:12]), _from_w32(o[12:24])), (_from_w32(o[24:36]), _from_w32(o[36:48])))
+
+    pts = [O.bls_g2_mul(G2, int.from_bytes(rng.bytes(32), "little") % r) for _ in range(3)] + [G2]
+    neg = lambda P: (P[0], ((-P[1][0]) % p, (-P[1][1]) % p))
+    for A in pts:
+        for B in pts[:2]:
+            assert run(0, A, B) == run(1, A, B) == O.bls_g2_add(A, B)
+        assert run(0, A, A) == run(1, A, A) == run(2, A, None) == O.bls_g2_mul(A, 2)
+        assert run(0, A, neg(A)) is None and run(1, A, neg(A)) is None
+        assert run(0, A, None) == A and run(0, None, A) == A
+        for k in (0, 1, 5, 65535):
+            assert run(3, A, None, k) == O.bls_g2_mul(A, k)
