@@ -9,8 +9,14 @@
  *  city_rollup_circuit/src/block_circuits/ops/l2_transfer/circuit.rs:209-235)
  * and the primitives underneath it run on the GPU. Plain pointers and sizes only.
  *
+ * Groups of entry points: context / memory / events / profiling; primitives (NTT, LDE, Poseidon, Merkle,
+ * commitments); circuits (cp_circuit_load, cp_circuit_set_gates); proving (cp_prove, cp_prove_batch{,_host},
+ * cp_prove_batch_zk_host, cp_prove_tail*, cp_zs_partial_products_dev) and cp_verify; and, for the Groth16 wrap
+ * (SURVEY.md §8(a) A12), the BLS12-381 G1 / G2 multi-scalar multiplications (cp_msm_bls12381_*).
+ *
  * Conventions
- *  - every field element is a canonical Goldilocks u64 (little-endian on the wire), p = 2^64-2^32+1
+ *  - every plonky2 field element is a canonical Goldilocks u64 (little-endian on the wire), p = 2^64-2^32+1;
+ *    BLS12-381 coordinates and scalars are little-endian u64 limbs of the canonical value (6 resp. 4 limbs)
  *  - all functions return 0 on success, a negative cp_status otherwise, and NEVER abort or throw;
  *    the message is available from cp_last_error() (the Rust shim turns it into anyhow::bail!,
  *    matching the `anyhow::Result` convention of city_rollup_circuit/src/worker/traits.rs:16-43)
