@@ -293,3 +293,126 @@ void or_bls_g2_msm(const uint64_t *scalars, const uint64_t *points_xy, const uin
   for (int t = 0; t < nt; t++) acc = g2_add(acc, part[t]);
   g2_to_affine(acc, out_xy, out_inf);
 }
+
+/* ================================================================================================================
+ * Scalar field F_r (r = the group order above, 255 bits, 2-adicity 32, multiplicative generator 7) and its NTT: the
+ * transforms of Groth16's quotient computation. Elements cross the API as 4 little-endian u64 of the canonical value.
+ * omega_n = 7^((r-1)/n).
+ * ================================================================================================================ */
+typedef struct { uint64_t l[4]; } fr_t; /* Montgomery, R = 2^256 */
+static uint64_t FR_N0;
+static fr_t FR_R1, FR_R2;
+static int fr_ready = 0;
+
+static int fr_ge(const uint64_t a[4]) {
+  for (int i = 3; i >= 0; i--) { if (a[i] > R_ORDER[i]) return 1; if (a[i] < R_ORDER[i]) return 0; }
+  return 1;
+}
+static void fr_subm(uint64_t a[4]) {
+  u128 b = 0;
+  for (int i = 0; i < 4; i++) { u128 d = (u128)a[i] - R_ORDER[i] - (uint64_t)b; a[i] = (uint64_t)d; b = (d >> 64) & 1; }
+}
+static fr_t fr_add(fr_t a, fr_t b) {
+  fr_t r; u128 c = 0;
+  for (int i = 0; i < 4; i++) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+  if (c || fr_ge(r.l)) fr_subm(r.l);
+  return r;
+}
+static fr_t fr_sub(fr_t a, fr_t b) {
+  fr_t r; u128 br = 0;
+  for (int i = 0; i < 4; i++) { u128 d = (u128)a.l[i] - b.l[i] - (uint64_t)br; r.l[i] = (uint64_t)d; br = (d >> 64) & 1; }
+  if (br) { u128 c = 0; for (int i = 0; i < 4; i++) { c += (u128)r.l[i] + R_ORDER[i]; r.l[i] = (uint64_t)c; c >>= 64; } }
+  return r;
+}
+static fr_t fr_mul(fr_t a, fr_t b) {
+  uint64_t t[6] = {0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+    uint64_t m = t[0] * FR_N0;
+    c = ((u128)m * R_ORDER[0] + t[0]) >> 64;
+    for (int j = 1; j < 4; j++) { c += (u128)m * R_ORDER[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  fr_t r; memcpy(r.l, t, 32);
+  if (t[4] || fr_ge(r.l)) fr_subm(r.l);
+  return r;
+}
+static void fr_init(void) {
+  if (fr_ready) return;
+  uint64_t inv = 1;
+  for (int i = 0; i < 6; i++) inv *= 2 - R_ORDER[0] * inv;
+  FR_N0 = (uint64_t)0 - inv;
+  fr_t one = {{1, 0, 0, 0}}, v = one;
+  for (int i = 0; i < 512; i++) { v = fr_add(v, v); if (i == 255) FR_R1 = v; }
+  FR_R2 = v;
+  fr_ready = 1;
+}
+static fr_t fr_from(const uint64_t a[4]) { fr_t t; memcpy(t.l, a, 32); return fr_mul(t, FR_R2); }
+static void fr_to(fr_t a, uint64_t out[4]) { fr_t one = {{1, 0, 0, 0}}; fr_t r = fr_mul(a, one); memcpy(out, r.l, 32); }
+static fr_t fr_pow(fr_t a, const uint64_t e[4]) {
+  fr_t r = FR_R1;
+  for (int i = 255; i >= 0; i--) { r = fr_mul(r, r); if ((e[i / 64] >> (i % 64)) & 1) r = fr_mul(r, a); }
+  return r;
+}
+static fr_t fr_inv(fr_t a) { uint64_t e[4]; memcpy(e, R_ORDER, 32); e[0] -= 2; return fr_pow(a, e); }
+static fr_t fr_root(int log_n) { /* 7^((r-1) / 2^log_n) */
+  uint64_t e[4]; memcpy(e, R_ORDER, 32); e[0] -= 1;
+  for (int s = 0; s < log_n; s++) { for (int i = 0; i < 3; i++) e[i] = (e[i] >> 1) | (e[i + 1] << 63); e[3] >>= 1; }
+  const uint64_t seven[4] = {7, 0, 0, 0};
+  return fr_pow(fr_from(seven), e);
+}
+
+int or_fr_is_canonical(const uint64_t a[4]) { return !fr_ge(a); }
+void or_fr_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) { fr_init(); fr_to(fr_mul(fr_from(a), fr_from(b)), out); }
+void or_fr_root_of_unity(int log_n, uint64_t out[4]) { fr_init(); fr_to(fr_root(log_n), out); }
+/* O(n^2) definition: out[k] = sum_j in[j] * omega_n^(jk) */
+void or_fr_dft_naive(const uint64_t *in, uint64_t *out, int log_n) {
+  fr_init();
+  size_t n = (size_t)1 << log_n;
+  fr_t w = fr_root(log_n), wk = FR_R1;
+  for (size_t k = 0; k < n; k++) {
+    fr_t acc = {{0, 0, 0, 0}}, x = FR_R1;
+    for (size_t j = 0; j < n; j++) { acc = fr_add(acc, fr_mul(fr_from(in + 4 * j), x)); x = fr_mul(x, wk); }
+    fr_to(acc, out + 4 * k);
+    wk = fr_mul(wk, w);
+  }
+}
+/* in-place NTT, natural order in and out. inverse = 0: evaluations on shift*<omega_n> (shift NULL: the subgroup itself);
+ * inverse = 1: the exact inverse of that (including the 1/n and the shift^-i). */
+void or_fr_ntt(uint64_t *data, int log_n, int inverse, const uint64_t *shift) {
+  fr_init();
+  size_t n = (size_t)1 << log_n;
+  fr_t *a = (fr_t *)__builtin_malloc(n * sizeof(fr_t));
+  for (size_t i = 0; i < n; i++) a[i] = fr_from(data + 4 * i);
+  if (!inverse && shift) { fr_t s = fr_from(shift), p = FR_R1; for (size_t i = 0; i < n; i++) { a[i] = fr_mul(a[i], p); p = fr_mul(p, s); } }
+  /* bit reversal, then decimation-in-time butterflies */
+  for (size_t i = 0; i < n; i++) {
+    size_t j = 0;
+    for (int b = 0; b < log_n; b++) j |= ((i >> b) & 1) << (log_n - 1 - b);
+    if (i < j) { fr_t t = a[i]; a[i] = a[j]; a[j] = t; }
+  }
+  for (int s = 1; s <= log_n; s++) {
+    fr_t wm = fr_root(s);
+    if (inverse) wm = fr_inv(wm);
+    size_t m = (size_t)1 << s;
+    for (size_t k = 0; k < n; k += m) {
+      fr_t w = FR_R1;
+      for (size_t j = 0; j < m / 2; j++) {
+        fr_t t = fr_mul(w, a[k + j + m / 2]), u = a[k + j];
+        a[k + j] = fr_add(u, t);
+        a[k + j + m / 2] = fr_sub(u, t);
+        w = fr_mul(w, wm);
+      }
+    }
+  }
+  if (inverse) {
+    uint64_t nn[4] = {(uint64_t)n, 0, 0, 0};
+    fr_t ninv = fr_inv(fr_from(nn));
+    for (size_t i = 0; i < n; i++) a[i] = fr_mul(a[i], ninv);
+    if (shift) { fr_t si = fr_inv(fr_from(shift)), p = FR_R1; for (size_t i = 0; i < n; i++) { a[i] = fr_mul(a[i], p); p = fr_mul(p, si); } }
+  }
+  for (size_t i = 0; i < n; i++) fr_to(a[i], data + 4 * i);
+  __builtin_free(a);
+}

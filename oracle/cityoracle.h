@@ -207,6 +207,13 @@ void or_bls_g2_mul(const uint64_t xy[24], int inf, const uint64_t k[4], uint64_t
 void or_bls_g2_msm(const uint64_t *scalars, const uint64_t *points_xy, const uint8_t *points_inf, size_t n,
                    uint64_t out_xy[24], int *out_inf);
 
+/* scalar field F_r of BLS12-381 and its NTT (Groth16's quotient transforms); elements = 4 LE u64, canonical */
+int or_fr_is_canonical(const uint64_t a[4]);
+void or_fr_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
+void or_fr_root_of_unity(int log_n, uint64_t out[4]);
+void or_fr_dft_naive(const uint64_t *in, uint64_t *out, int log_n);
+void or_fr_ntt(uint64_t *data, int log_n, int inverse, const uint64_t *shift);
+
 /* number of worker threads the oracle uses for the batch entry points
  * (or_poseidon_permute_many, or_merkle_tree*, or_commit_batch); default 1 */
 void or_set_threads(int n);

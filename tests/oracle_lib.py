@@ -462,3 +462,26 @@ def bls_g2_msm(scalars, points_xy, points_inf=None):
     lib().or_bls_g2_msm(ptr(s), ptr(pxy), None if pi is None else pi.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
                         ctypes.c_size_t(n), ptr(out), ctypes.byref(oi))
     return _bls_out2(out, oi)
+
+
+# ---- F_r and its NTT ----
+def fr_ntt(values, inverse=False, shift=None):
+    """values: (n, 4) uint64 canonical F_r elements; returns the transformed copy"""
+    a = arr(values).copy()
+    log_n = int(a.shape[0]).bit_length() - 1
+    sh = None if shift is None else _limbs(shift, 4)
+    lib().or_fr_ntt(ptr(a), ctypes.c_int(log_n), ctypes.c_int(1 if inverse else 0), None if sh is None else ptr(sh))
+    return a
+
+
+def fr_dft_naive(values):
+    a = arr(values)
+    out = np.zeros_like(a)
+    lib().or_fr_dft_naive(ptr(a), ptr(out), ctypes.c_int(int(a.shape[0]).bit_length() - 1))
+    return out
+
+
+def fr_root_of_unity(log_n):
+    out = np.zeros(4, np.uint64)
+    lib().or_fr_root_of_unity(ctypes.c_int(log_n), ptr(out))
+    return _int(out)

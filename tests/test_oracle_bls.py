@@ -138,3 +138,33 @@ def test_g2_generator_and_group_law():
     scal = np.array([[(k >> (64 * j)) & (2**64 - 1) for j in range(4)] for k in ks], dtype=np.uint64)
     xy = np.array([O.bls_point2(P)[0] for P in pts], dtype=np.uint64)
     assert O.bls_g2_msm(scal, xy) == O.bls_g2_mul(G2, sum(k * (2 + i) for i, k in enumerate(ks)) % r)
+
+
+# ---- F_r NTT ---------------------------------------------------------------------------------------------------
+def fr_rand(rng, n, r):
+    vals = [int.from_bytes(rng.bytes(32), "little") % r for _ in range(n)]
+    return vals, np.array([[(v >> (64 * j)) & (2**64 - 1) for j in range(4)] for v in vals], dtype=np.uint64)
+
+
+def fr_ints(a):
+    return [sum(int(a[i, j]) << (64 * j) for j in range(4)) for i in range(a.shape[0])]
+
+
+def test_fr_roots_and_ntt_definition():
+    _, r, _ = O.bls_constants()
+    assert (r - 1) % (1 << 32) == 0
+    for k in (1, 2, 5, 32):
+        w = O.fr_root_of_unity(k)
+        assert w == pow(7, (r - 1) >> k, r) and pow(w, 1 << k, r) == 1 and pow(w, 1 << (k - 1), r) == r - 1
+    rng = np.random.default_rng(3)
+    for log_n in (0, 1, 3, 6):
+        n = 1 << log_n
+        vals, a = fr_rand(rng, n, r)
+        w = pow(7, (r - 1) >> log_n, r)
+        want = [sum(vals[j] * pow(w, j * k, r) for j in range(n)) % r for k in range(n)]
+        assert fr_ints(O.fr_ntt(a)) == want == fr_ints(O.fr_dft_naive(a))
+        assert (O.fr_ntt(O.fr_ntt(a), inverse=True) == a).all()
+        s = 7
+        cos = [sum(vals[j] * pow(s * pow(w, k, r), j, r) for j in range(n)) % r for k in range(n)]   # evaluations on s*<w>
+        assert fr_ints(O.fr_ntt(a, shift=s)) == cos
+        assert (O.fr_ntt(O.fr_ntt(a, shift=s), inverse=True, shift=s) == a).all()
