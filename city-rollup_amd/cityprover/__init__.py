@@ -705,3 +705,24 @@ class G2Points:
 
     def free(self):
         self.buf.free()
+
+
+# ---- NTT over the BLS12-381 scalar field ----
+ABI["cp_ntt_bls12381_fr"] = (ctypes.c_int, [_vp, _u64p, ctypes.c_int, ctypes.c_uint, _u64p])
+ABI["cp_ntt_bls12381_fr_dev"] = (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_uint, _u64p])
+
+
+def fr_ntt(prover, values, inverse=False, shift=None):
+    """values: (n, 4) uint64 canonical F_r elements -> transformed copy (natural order). shift: coset shift (int)."""
+    a = _as_u64(values).reshape(-1, 4).copy()
+    log_n = int(a.shape[0]).bit_length() - 1
+    flags = (NTT_INVERSE if inverse else 0) | (NTT_COSET if shift is not None else 0)
+    sh = None if shift is None else np.array([(int(shift) >> (64 * j)) & (2**64 - 1) for j in range(4)], dtype=np.uint64)
+    prover._check(prover.lib.cp_ntt_bls12381_fr(prover.ctx, _ptr(a), log_n, flags, None if sh is None else _ptr(sh)))
+    return a
+
+
+def fr_ntt_dev(prover, data_ptr, log_n, inverse=False, shift=None):
+    flags = (NTT_INVERSE if inverse else 0) | (NTT_COSET if shift is not None else 0)
+    sh = None if shift is None else np.array([(int(shift) >> (64 * j)) & (2**64 - 1) for j in range(4)], dtype=np.uint64)
+    prover._check(prover.lib.cp_ntt_bls12381_fr_dev(prover.ctx, data_ptr, log_n, flags, None if sh is None else _ptr(sh)))

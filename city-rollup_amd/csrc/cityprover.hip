@@ -47,6 +47,8 @@ struct cp_ctx {
   // pageable copies block inside the runtime and serialise the contexts of a process
   char *pin = nullptr;
   size_t pin_bytes = 0, pin_off = 0;
+  // BLS12-381 F_r twiddle tables (fr_ntt.inc), keyed by (log_n, inverse)
+  std::map<std::pair<int, int>, void *> fr_twiddles;
   // device staging buffer for wire matrices that arrive in host memory (cp_prove / cp_prove_batch_host)
   uint64_t *wires_stage = nullptr;
   size_t wires_stage_bytes = 0;
@@ -492,6 +494,7 @@ void cp_ctx_destroy(cp_ctx *ctx) {
   for (auto &ch : ctx->arena.chunks) hipFree(ch.first);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->wires_stage) hipFree(ctx->wires_stage);
+  for (auto &kv : ctx->fr_twiddles) hipFree(kv.second);
   if (ctx->pin) hipHostFree(ctx->pin);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -874,3 +877,5 @@ int cp_commit_dev(cp_ctx *ctx, const uint64_t *values, size_t k, int log_n, int 
 #include "verify.inc"
 #include "msm.h"
 #include "msm.inc"
+#include "fr_ntt.h"
+#include "fr_ntt.inc"

@@ -1,0 +1,68 @@
+// NTT over the BLS12-381 scalar field (the F_r transforms of the Groth16 quotient).
+// Decimation in frequency on a work array of Montgomery elements: natural order in, bit-reversed order out of the
+// butterflies; the load / store kernels convert from / to the canonical 4 x u64 form of the API, apply the coset
+// powers and 1/n, and undo the bit reversal. Stages with a butterfly distance of 512 elements or more run one
+// launch each over HBM; the last ten stages run on 1024-element tiles in LDS (40 KB).
+#pragma once
+#include "bls12_381_fr.h"
+
+namespace frntt {
+
+using blsfr::Fr;
+constexpr int LOG_TILE = 10;
+
+// out[i] = base^i for i < count (Montgomery); base given in Montgomery form
+__global__ void k_powers(Fr base, size_t count, Fr *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = blsfr::fr_pow_u64(base, i);
+}
+// work[i] = mont(data[i]) * (powers ? powers[i] : 1)
+__global__ void k_load(const uint32_t *__restrict__ data, size_t n, const Fr *__restrict__ powers, Fr *__restrict__ work) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr v = blsfr::fr_from_canonical(data + 8 * i);
+  if (powers) v = blsfr::fr_mul(v, powers[i]);
+  work[i] = v;
+}
+// one DIF stage over HBM: pairs (j, j + half) inside blocks of 2*half; twiddle omega_n^(j * n/(2 half)) = tw[j * step]
+__global__ void k_stage(Fr *__restrict__ work, size_t n, size_t half, size_t step, const Fr *__restrict__ tw) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n / 2) return;
+  const size_t j = t & (half - 1), lo = ((t - j) << 1) + j, hi = lo + half;
+  const Fr u = work[lo], v = work[hi];
+  work[lo] = blsfr::fr_add(u, v);
+  work[hi] = blsfr::fr_mul(blsfr::fr_sub(u, v), tw[j * step]);
+}
+// the last `stages` (<= LOG_TILE) DIF stages on contiguous tiles of 2^stages elements, in LDS
+__global__ __launch_bounds__(512) void k_tile(Fr *__restrict__ work, size_t n, int stages, size_t tw_step, const Fr *__restrict__ tw) {
+  __shared__ Fr tile[1 << LOG_TILE];
+  const size_t tsize = (size_t)1 << stages, base = (size_t)blockIdx.x * tsize;
+  for (size_t i = threadIdx.x; i < tsize; i += blockDim.x) tile[i] = work[base + i];
+  __syncthreads();
+  for (int s = stages - 1; s >= 0; s--) {
+    const size_t half = (size_t)1 << s;
+    // twiddle of the pair at offset j inside a block of 2*half: omega_{2 half}^j = omega_n^(j * n / (2 half))
+    const size_t step = tw_step << (stages - 1 - s);
+    for (size_t t = threadIdx.x; t < tsize / 2; t += blockDim.x) {
+      const size_t j = t & (half - 1), lo = ((t - j) << 1) + j, hi = lo + half;
+      const Fr u = tile[lo], v = tile[hi];
+      tile[lo] = blsfr::fr_add(u, v);
+      tile[hi] = blsfr::fr_mul(blsfr::fr_sub(u, v), tw[j * step]);
+    }
+    __syncthreads();
+  }
+  for (size_t i = threadIdx.x; i < tsize; i += blockDim.x) work[base + i] = tile[i];
+}
+// data[rev(p)] = canonical(work[p] * scale * (powers ? powers[rev(p)] : 1))
+__global__ void k_store(const Fr *__restrict__ work, size_t n, int log_n, Fr scale, int use_scale, const Fr *__restrict__ powers,
+                        uint32_t *__restrict__ data) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t i = log_n ? (size_t)(__brevll((unsigned long long)p) >> (64 - log_n)) : 0;
+  Fr v = work[p];
+  if (use_scale) v = blsfr::fr_mul(v, scale);
+  if (powers) v = blsfr::fr_mul(v, powers[i]);
+  blsfr::fr_to_canonical(v, data + 8 * i);
+}
+
+}  // namespace frntt

@@ -12,7 +12,8 @@
  * Groups of entry points: context / memory / events / profiling; primitives (NTT, LDE, Poseidon, Merkle,
  * commitments); circuits (cp_circuit_load, cp_circuit_set_gates); proving (cp_prove, cp_prove_batch{,_host},
  * cp_prove_batch_zk_host, cp_prove_tail*, cp_zs_partial_products_dev) and cp_verify; and, for the Groth16 wrap
- * (SURVEY.md §8(a) A12), the BLS12-381 G1 / G2 multi-scalar multiplications (cp_msm_bls12381_*).
+ * (SURVEY.md §8(a) A12), the BLS12-381 G1 / G2 multi-scalar multiplications (cp_msm_bls12381_*) and the scalar-field NTT
+ * (cp_ntt_bls12381_fr*).
  *
  * Conventions
  *  - every plonky2 field element is a canonical Goldilocks u64 (little-endian on the wire), p = 2^64-2^32+1;
@@ -309,8 +310,8 @@ void cp_free(void *ptr);
  * city_rollup_core_worker/src/lib.rs:121; the arithmetic itself is gnark-crypto's, a Go dependency outside the tree).
  * Scalars: 4 little-endian u64 per scalar (any 256-bit integer). Points: affine x || y, 6 + 6 little-endian u64 of the
  * canonical (non-Montgomery) coordinates; points_inf: optional byte flags, non-zero = the point at infinity.
- * Result: affine canonical coordinates + infinity flag. First kernels of row A12 (the F_r NTTs and the witness
- * solver are not built). */
+ * Result: affine canonical coordinates + infinity flag. First kernels of row A12 (the witness solver and the
+ * proof assembly are not built). */
 int cp_msm_bls12381_g1(cp_ctx *ctx, const uint64_t *scalars_host, const uint64_t *points_xy_host,
                        const uint8_t *points_inf_host, size_t n, uint64_t out_xy[12], int *out_is_infinity);
 /* Device-resident variant for a fixed point set (a proving key): convert once to the library's internal form
@@ -334,6 +335,13 @@ int cp_msm_bls12381_g2_synthetic_points_dev(cp_ctx *ctx, const uint64_t generato
                                             size_t n, void *points_mont_dev);
 int cp_msm_bls12381_g2_dev(cp_ctx *ctx, const uint64_t *scalars_dev, const void *points_mont_dev,
                            const uint8_t *points_inf_dev, size_t n, uint64_t out_xy[24], int *out_is_infinity);
+
+/* ---- NTT over the BLS12-381 scalar field F_r (the transforms of Groth16's quotient) ----
+ * Elements: 4 little-endian u64 of the canonical value (< r). In place, natural order in and out,
+ * omega_n = 7^((r-1)/n). flags: CP_NTT_INVERSE (exact inverse, 1/n included), CP_NTT_COSET with coset_shift
+ * (4 u64, non-zero): forward = evaluations on shift*<omega_n>, inverse = its inverse. log_n <= 28. */
+int cp_ntt_bls12381_fr(cp_ctx *ctx, uint64_t *data_host, int log_n, unsigned flags, const uint64_t *coset_shift);
+int cp_ntt_bls12381_fr_dev(cp_ctx *ctx, uint64_t *data_dev, int log_n, unsigned flags, const uint64_t *coset_shift);
 
 #ifdef __cplusplus
 }

@@ -105,3 +105,20 @@ int hs_bls_g2_op(int op, const uint32_t *p_xy, int p_inf, const uint32_t *q_xy, 
   return hs_group_op<bls::Fp2>(op, p_xy, p_inf, q_xy, q_inf, k, out_xy);
 }
 }
+
+// ---- BLS12-381 scalar field (csrc/bls12_381_fr.h) ----
+#include "../../city-rollup_amd/csrc/bls12_381_fr.h"
+extern "C" {
+// 8-word canonical operands; op 0 mul, 1 add, 2 sub, 3 inverse of a, 4 a^(b[0])
+void hs_bls_fr_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *out) {
+  blsfr::Fr x = blsfr::fr_from_canonical(a), y = blsfr::fr_from_canonical(b), r;
+  switch (op) {
+    case 0: r = blsfr::fr_mul(x, y); break;
+    case 1: r = blsfr::fr_add(x, y); break;
+    case 2: r = blsfr::fr_sub(x, y); break;
+    case 3: r = blsfr::fr_inv(x); break;
+    default: r = blsfr::fr_pow_u64(x, ((uint64_t)b[1] << 32) | b[0]); break;
+  }
+  blsfr::fr_to_canonical(r, out);
+}
+}

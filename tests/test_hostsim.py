@@ -220,3 +220,21 @@ def test_bls_fp2_and_g2_formulas(hs):
         assert run(0, A, None) == A and run(0, None, A) == A
         for k in (0, 1, 5, 65535):
             assert run(3, A, None, k) == O.bls_g2_mul(A, k)
+
+
+def test_bls_scalar_field_ops(hs):
+    _, r, _ = O.bls_constants()
+    rng = np.random.default_rng(12)
+    vals = [0, 1, 2, r - 1, r - 2, (1 << 254) + 99, 7] + [int.from_bytes(rng.bytes(32), "little") % r for _ in range(40)]
+    out = (ctypes.c_uint32 * 8)()
+    for i in range(len(vals) - 1):
+        a, b = vals[i], vals[i + 1]
+        for op, want in ((0, a * b % r), (1, (a + b) % r), (2, (a - b) % r)):
+            hs.hs_bls_fr_op(op, _w32(a, 8), _w32(b, 8), out)
+            assert _from_w32(out) == want, (op, hex(a), hex(b))
+    for a in vals[1:10]:
+        hs.hs_bls_fr_op(3, _w32(a, 8), _w32(0, 8), out)
+        assert _from_w32(out) * a % r == 1
+        e = int(rng.integers(0, 2**62))
+        hs.hs_bls_fr_op(4, _w32(a, 8), _w32(e, 8), out)
+        assert _from_w32(out) == pow(a, e, r)

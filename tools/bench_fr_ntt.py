@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""BLS12-381 scalar-field NTT timing (cp_ntt_bls12381_fr_dev: data resident in HBM in canonical form, in place,
+natural order in and out), with an inverse-of-forward round-trip check at every size."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "city-rollup_amd"))
+import numpy as np  # noqa: E402
+import cityprover as cp  # noqa: E402
+
+
+def run(prover, log_n, reps=5):
+    n = 1 << log_n
+    rng = np.random.default_rng(log_n)
+    a = rng.integers(0, 2**64, (n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 62) - 1)
+    d = prover.to_device(a)
+    cp.fr_ntt_dev(prover, d.ptr, log_n)
+    cp.fr_ntt_dev(prover, d.ptr, log_n, inverse=True)
+    assert (d.download().reshape(n, 4) == a).all(), "inverse(forward(x)) != x"
+    out = {"log_n": log_n}
+    for name, kw in (("forward", {}), ("inverse", {"inverse": True}), ("coset_forward", {"shift": 7})):
+        prover.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            cp.fr_ntt_dev(prover, d.ptr, log_n, **kw)
+        dt = (time.perf_counter() - t0) / reps
+        prof = prover.profile_end()
+        out[name + "_ms"] = dt * 1e3
+        if name == "forward":
+            out["kernels_ms"] = {k: round(v["total_ms"] / reps, 3) for k, v in prof.items() if k.startswith("fr_")}
+            out["algorithmic_GBs"] = 64.0 * n / dt / 1e9     # read + write the canonical array once
+    d.free()
+    return out
+
+
+if __name__ == "__main__":
+    sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [16, 20, 22, 24]
+    p = cp.Prover(0)
+    out = [run(p, s) for s in sizes]
+    p.close()
+    print(json.dumps(out))
