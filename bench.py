@@ -243,6 +243,20 @@ def main():
                           "wires -> proof bytes, witness generation excluded"}
         data = None
 
+    # Groth16-wrap kernels, side measurement on rank 0: G1 MSM and F_r NTT at 2^20, both with a
+    # correctness check inside (closed form resp. inverse round trip) — tools/bench_msm.py, tools/bench_fr_ntt.py
+    g16 = None
+    if rank == 0 and not args.no_qbench:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_msm
+        import bench_fr_ntt
+        m18 = bench_msm.run(prover, 18, reps=2)          # checked against (sum k_i (a i + b)) * G
+        m20 = bench_msm.run(prover, 20, reps=2)
+        f20 = bench_fr_ntt.run(prover, 20, reps=3)
+        g16 = {"msm_g1_2^18_ms": m18["ms"], "msm_g1_2^18_checked": m18["checked"], "msm_g1_2^20_ms": m20["ms"],
+               "msm_g1_2^20_Mpoints_per_s": m20["Mpoints_per_s"], "fr_ntt_2^20_forward_ms": f20["forward_ms"],
+               "fr_ntt_2^20_inverse_ms": f20["inverse_ms"]}
+
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
         ntts = k * world
@@ -325,6 +339,7 @@ def main():
             "merkle_levels_ms": lvl["total_ms"] / args.steps,
             "cpu_baseline": base,
             "qbench_proofs": qb,
+            "groth16_kernels": g16,
         }
         print(json.dumps(out))
     if data is not None:
