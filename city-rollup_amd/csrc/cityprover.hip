@@ -49,6 +49,8 @@ struct cp_ctx {
   size_t pin_bytes = 0, pin_off = 0;
   // BLS12-381 F_r twiddle tables (fr_ntt.inc), keyed by (log_n, inverse)
   std::map<std::pair<int, int>, void *> fr_twiddles;
+  void *fr_work = nullptr, *fr_pow = nullptr;  // grow-only work arrays of the F_r NTT
+  size_t fr_work_bytes = 0, fr_pow_bytes = 0;
   // device staging buffer for wire matrices that arrive in host memory (cp_prove / cp_prove_batch_host)
   uint64_t *wires_stage = nullptr;
   size_t wires_stage_bytes = 0;
@@ -495,6 +497,8 @@ void cp_ctx_destroy(cp_ctx *ctx) {
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->wires_stage) hipFree(ctx->wires_stage);
   for (auto &kv : ctx->fr_twiddles) hipFree(kv.second);
+  if (ctx->fr_work) hipFree(ctx->fr_work);
+  if (ctx->fr_pow) hipFree(ctx->fr_pow);
   if (ctx->pin) hipHostFree(ctx->pin);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;

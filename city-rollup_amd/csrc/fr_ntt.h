@@ -1,8 +1,8 @@
 // NTT over the BLS12-381 scalar field (the F_r transforms of the Groth16 quotient).
 // Decimation in frequency on a work array of Montgomery elements: natural order in, bit-reversed order out of the
 // butterflies; the load / store kernels convert from / to the canonical 4 x u64 form of the API, apply the coset
-// powers and 1/n, and undo the bit reversal. Stages with a butterfly distance of 512 elements or more run one
-// launch each over HBM; the last ten stages run on 1024-element tiles in LDS (40 KB).
+// powers and 1/n, and undo the bit reversal. Stages with a butterfly distance of 512 elements or more run over HBM,
+// two stages per launch (radix 4); the last ten stages run on 1024-element tiles in LDS (40 KB).
 #pragma once
 #include "bls12_381_fr.h"
 
@@ -32,6 +32,23 @@ __global__ void k_stage(Fr *__restrict__ work, size_t n, size_t half, size_t ste
   const Fr u = work[lo], v = work[hi];
   work[lo] = blsfr::fr_add(u, v);
   work[hi] = blsfr::fr_mul(blsfr::fr_sub(u, v), tw[j * step]);
+}
+// two consecutive DIF stages (distances half and half/2) in one pass over HBM: lane t owns the four elements
+// x, x + half/2, x + half, x + 3 half/2 of a block of 2*half
+__global__ void k_stage2(Fr *__restrict__ work, size_t n, size_t half, size_t step, const Fr *__restrict__ tw) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n / 4) return;
+  const size_t q = half >> 1, j = t & (q - 1), x = ((t - j) << 2) + j;
+  const Fr a = work[x], b = work[x + q], c = work[x + half], d = work[x + half + q];
+  // stage `half`: (a, c) with twiddle index j, (b, d) with j + q
+  const Fr a1 = blsfr::fr_add(a, c), c1 = blsfr::fr_mul(blsfr::fr_sub(a, c), tw[j * step]);
+  const Fr b1 = blsfr::fr_add(b, d), d1 = blsfr::fr_mul(blsfr::fr_sub(b, d), tw[(j + q) * step]);
+  // stage `half/2`: (a1, b1) and (c1, d1), both with twiddle index j at twice the step
+  const Fr w = tw[j * 2 * step];
+  work[x] = blsfr::fr_add(a1, b1);
+  work[x + q] = blsfr::fr_mul(blsfr::fr_sub(a1, b1), w);
+  work[x + half] = blsfr::fr_add(c1, d1);
+  work[x + half + q] = blsfr::fr_mul(blsfr::fr_sub(c1, d1), w);
 }
 // the last `stages` (<= LOG_TILE) DIF stages on contiguous tiles of 2^stages elements, in LDS
 __global__ __launch_bounds__(512) void k_tile(Fr *__restrict__ work, size_t n, int stages, size_t tw_step, const Fr *__restrict__ tw) {

@@ -20,6 +20,7 @@ def run(prover, log_n, reps=5):
     d = prover.to_device(a)
     cp.fr_ntt_dev(prover, d.ptr, log_n)
     cp.fr_ntt_dev(prover, d.ptr, log_n, inverse=True)
+    prover.sync()
     assert (d.download().reshape(n, 4) == a).all(), "inverse(forward(x)) != x"
     out = {"log_n": log_n}
     for name, kw in (("forward", {}), ("inverse", {"inverse": True}), ("coset_forward", {"shift": 7})):
@@ -27,6 +28,7 @@ def run(prover, log_n, reps=5):
         t0 = time.perf_counter()
         for _ in range(reps):
             cp.fr_ntt_dev(prover, d.ptr, log_n, **kw)
+        prover.sync()
         dt = (time.perf_counter() - t0) / reps
         prof = prover.profile_end()
         out[name + "_ms"] = dt * 1e3
