@@ -98,22 +98,62 @@ __global__ void k_scatter(const uint32_t *__restrict__ scalars, const uint8_t *_
   sorted[(size_t)w * n + pos] = (uint32_t)i;
 }
 
-// grid = (2^c / 128, windows): bucket (w, d) = sum of its points
+// Buckets in order of decreasing size, so that the 64 lanes of a wave run (nearly) the same number of additions:
+// with Poisson-distributed sizes a wave otherwise waits for its fullest bucket (~1.7x the mean at 16 points per bucket).
+// Counting sort on min(count, HEAVY + 1): k_size_hist (LDS histogram per workgroup) -> k_size_scan -> k_size_scatter.
+constexpr int SIZE_BINS = (int)HEAVY + 2;
+__global__ __launch_bounds__(256) void k_size_hist(const uint32_t *__restrict__ counts, size_t total, uint32_t *__restrict__ bins) {
+  __shared__ uint32_t h[SIZE_BINS];
+  for (int k = threadIdx.x; k < SIZE_BINS; k += 256) h[k] = 0;
+  __syncthreads();
+  const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (b < total) {
+    const uint32_t cnt = counts[b];
+    atomicAdd(&h[cnt > HEAVY ? HEAVY + 1 : cnt], 1u);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < SIZE_BINS; k += 256)
+    if (h[k]) atomicAdd(&bins[k], h[k]);
+}
+// cursor[k] = number of buckets in bins larger than k (descending order: the largest sizes come first)
+__global__ void k_size_scan(const uint32_t *__restrict__ bins, uint32_t *__restrict__ cursor) {
+  if (threadIdx.x || blockIdx.x) return;
+  uint32_t run = 0;
+  for (int k = SIZE_BINS - 1; k >= 0; k--) { cursor[k] = run; run += bins[k]; }
+}
+__global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict__ counts, size_t total, uint32_t *__restrict__ cursor,
+                                                      uint32_t *__restrict__ order) {
+  __shared__ uint32_t h[SIZE_BINS], base[SIZE_BINS];
+  for (int k = threadIdx.x; k < SIZE_BINS; k += 256) h[k] = 0;
+  __syncthreads();
+  const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t bin = 0, rank = 0;
+  if (b < total) {
+    const uint32_t cnt = counts[b];
+    bin = cnt > HEAVY ? HEAVY + 1 : cnt;
+    rank = atomicAdd(&h[bin], 1u);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < SIZE_BINS; k += 256) base[k] = h[k] ? atomicAdd(&cursor[k], h[k]) : 0;
+  __syncthreads();
+  if (b < total) order[base[bin] + rank] = (uint32_t)b;
+}
+
+// one lane per bucket, taken in `order`: bucket (w, d) = sum of its points
 template <class F>
 __global__ __launch_bounds__(128) void k_bucket_sum(const AffineT<F> *__restrict__ pts, const uint32_t *__restrict__ counts,
                                                     const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ sorted,
-                                                    size_t n, int c, JacT<F> *__restrict__ buckets) {
-  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >> c) return;
-  const int w = blockIdx.y;
-  const size_t b = ((size_t)w << c) + d;
+                                                    const uint32_t *__restrict__ order, size_t total, size_t n, int c,
+                                                    JacT<F> *__restrict__ buckets) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const size_t b = order[t];
+  const size_t w = b >> c;
   JacT<F> acc = bls::jac_inf<F>();
-  if (d) {
-    const uint32_t *idx = sorted + (size_t)w * n + offsets[b];
-    const uint32_t cnt = counts[b];
-    if (cnt > HEAVY) return;  // k_heavy_sum writes this one
-    for (uint32_t t = 0; t < cnt; t++) acc = bls::jac_add_mixed(acc, pts[idx[t]]);
-  }
+  const uint32_t cnt = counts[b];  // 0 for digit 0 (k_hist skips it)
+  if (cnt > HEAVY) return;         // k_heavy_sum writes this one
+  const uint32_t *idx = sorted + w * n + offsets[b];
+  for (uint32_t i = 0; i < cnt; i++) acc = bls::jac_add_mixed(acc, pts[idx[i]]);
   buckets[b] = acc;
 }
 
