@@ -51,6 +51,8 @@ struct cp_ctx {
   std::map<std::pair<int, int>, void *> fr_twiddles;
   void *fr_work = nullptr, *fr_pow = nullptr;  // grow-only work arrays of the F_r NTT
   size_t fr_work_bytes = 0, fr_pow_bytes = 0;
+  void *msm_ws = nullptr;  // grow-only workspace of the MSMs (counts, sorted indices, buckets)
+  size_t msm_ws_bytes = 0;
   // device staging buffer for wire matrices that arrive in host memory (cp_prove / cp_prove_batch_host)
   uint64_t *wires_stage = nullptr;
   size_t wires_stage_bytes = 0;
@@ -499,6 +501,7 @@ void cp_ctx_destroy(cp_ctx *ctx) {
   for (auto &kv : ctx->fr_twiddles) hipFree(kv.second);
   if (ctx->fr_work) hipFree(ctx->fr_work);
   if (ctx->fr_pow) hipFree(ctx->fr_pow);
+  if (ctx->msm_ws) hipFree(ctx->msm_ws);
   if (ctx->pin) hipHostFree(ctx->pin);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -1,12 +1,14 @@
 // Multi-scalar multiplication over BLS12-381 G1 and G2 (the MSMs of the Groth16 wrap proof; the
 // kernels are templates over the coordinate field F = Fp (G1) or Fp2 (G2)),
-// bucket method: sum_i k_i P_i = sum_w 2^(c w) sum_d d * B[w][d], B[w][d] = sum of the points whose w-th c-bit digit is d.
+// bucket method with SIGNED digits: k = sum_w 2^(c w) d_w, |d_w| <= 2^(c-1) (a digit above 2^(c-1) becomes d - 2^c and
+// carries into the next window), so sum_i k_i P_i = sum_w 2^(c w) sum_{d=1..2^(c-1)} d * B[w][d] with
+// B[w][d] = sum of +-P_i over the scalars whose w-th digit is +-d: half the buckets of the unsigned method.
 //
 //   k_points_to_mont   canonical affine points -> Montgomery form (once per point set: a proving key is fixed)
-//   k_hist / k_scan / k_scatter   counting sort of the point indices by digit, per window (atomics; the order inside
-//                      a bucket is arbitrary, the group law does not care)
+//   k_hist / k_scan / k_scatter   signed-digit recoding + counting sort of the point indices by |digit|, per window
+//                      (atomics; the order inside a bucket is arbitrary, the group law does not care)
 //   k_bucket_sum       one lane per (window, digit): mixed additions of its points into a Jacobian accumulator
-//   k_segment_reduce   one lane per (window, run of SEG buckets): sum_d d*B_d over the run by the running-sum trick plus
+//   k_segment_reduce   one lane per (window, run of seg_len buckets): sum_d d*B_d over the run by the running-sum trick plus
 //                      a small scalar multiple for the run's offset
 //   k_pair_reduce      tree reduction of the runs of a window
 // The 2^(c w) combination of the window sums and the final inversion run on the host (a few hundred point operations).
@@ -21,8 +23,8 @@ using bls::Field;
 using bls::JacT;
 
 constexpr int SCALAR_WORDS = 8;  // 256-bit scalars, little-endian 32-bit words
-constexpr int SEG = 8;           // buckets per k_segment_reduce lane (short runs: the reduction is latency-bound)
-constexpr uint32_t HEAVY = 128;  // buckets with more points than this are summed by a whole workgroup (k_heavy_sum)
+constexpr uint32_t HEAVY = 128;  // buckets with more than HEAVY << hs points are summed by a whole workgroup (k_heavy_sum);
+                                 // hs ("heavy shift") is chosen by the host so that this is well above the mean bucket size
 // lanes of that workgroup: the LDS tree holds one Jacobian point per lane (168 B for G1, 336 B for G2; 64 KB limit)
 template <class F> constexpr int HEAVY_LANES = sizeof(JacT<F>) <= 168 ? 256 : 128;
 
@@ -54,21 +56,30 @@ __global__ __launch_bounds__(64) void k_synthetic_points(AffineT<F> g, uint32_t 
   out[i] = bls::jac_to_affine(p);
 }
 
-// grid = (n/256, windows)
-__global__ void k_hist(const uint32_t *__restrict__ scalars, const uint8_t *__restrict__ inf, size_t n, int c,
-                       uint32_t *__restrict__ counts) {
+// signed digit of window w, given the carry from the window below; updates the carry
+__device__ __forceinline__ int signed_digit(const uint32_t *k, int w, int c, uint32_t &carry) {
+  const uint32_t raw = digit(k, w, c) + carry;
+  if (raw > (1u << (c - 1))) { carry = 1; return (int)raw - (1 << c); }
+  carry = 0;
+  return (int)raw;
+}
+// one lane per scalar, all its windows (the recoding carries from window to window)
+__global__ void k_hist(const uint32_t *__restrict__ scalars, const uint8_t *__restrict__ inf, size_t n, int c, int windows,
+                       size_t nbs, uint32_t *__restrict__ counts) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || (inf && inf[i])) return;
-  const int w = blockIdx.y;
-  const uint32_t d = digit(scalars + SCALAR_WORDS * i, w, c);
-  if (d) atomicAdd(&counts[((size_t)w << c) + d], 1u);
+  uint32_t carry = 0;
+  for (int w = 0; w < windows; w++) {
+    const int d = signed_digit(scalars + SCALAR_WORDS * i, w, c, carry);
+    if (d) atomicAdd(&counts[(size_t)w * nbs + (d < 0 ? -d : d)], 1u);
+  }
 }
-// one workgroup of 1024 lanes per window: exclusive scan of its 2^c counts -> offsets, cursor = offsets
-__global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ counts, int c, uint32_t *__restrict__ offsets,
+// one workgroup of 1024 lanes per window: exclusive scan of its nbs counts -> offsets, cursor = offsets
+__global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ counts, size_t nbs, uint32_t *__restrict__ offsets,
                                                uint32_t *__restrict__ cursor) {
   __shared__ uint32_t part[1024];
-  const size_t base = (size_t)blockIdx.x << c;
-  const uint32_t nb = 1u << c, per = (nb + 1023) / 1024;
+  const size_t base = (size_t)blockIdx.x * nbs;
+  const uint32_t nb = (uint32_t)nbs, per = (nb + 1023) / 1024;
   const uint32_t lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
   uint32_t s = 0;
   for (uint32_t d = lo; d < hi; d++) s += counts[base + d];
@@ -87,29 +98,41 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ coun
     run += counts[base + d];
   }
 }
-__global__ void k_scatter(const uint32_t *__restrict__ scalars, const uint8_t *__restrict__ inf, size_t n, int c,
-                          uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted) {
+// sorted[w][pos] = point index, bit 31 set when the point enters its bucket negated
+__global__ void k_scatter(const uint32_t *__restrict__ scalars, const uint8_t *__restrict__ inf, size_t n, int c, int windows,
+                          size_t nbs, uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || (inf && inf[i])) return;
-  const int w = blockIdx.y;
-  const uint32_t d = digit(scalars + SCALAR_WORDS * i, w, c);
-  if (!d) return;
-  const uint32_t pos = atomicAdd(&cursor[((size_t)w << c) + d], 1u);
-  sorted[(size_t)w * n + pos] = (uint32_t)i;
+  uint32_t carry = 0;
+  for (int w = 0; w < windows; w++) {
+    const int d = signed_digit(scalars + SCALAR_WORDS * i, w, c, carry);
+    if (!d) continue;
+    const uint32_t pos = atomicAdd(&cursor[(size_t)w * nbs + (d < 0 ? -d : d)], 1u);
+    sorted[(size_t)w * n + pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+  }
+}
+// the point a sorted entry stands for (negated when bit 31 is set)
+template <class F>
+__device__ __forceinline__ AffineT<F> entry_point(const AffineT<F> *__restrict__ pts, uint32_t e) {
+  AffineT<F> q = pts[e & 0x7fffffffu];
+  if (e >> 31) q.y = bls::f_sub(Field<F>::zero(), q.y);
+  return q;
 }
 
 // Buckets in order of decreasing size, so that the 64 lanes of a wave run (nearly) the same number of additions:
 // with Poisson-distributed sizes a wave otherwise waits for its fullest bucket (~1.7x the mean at 16 points per bucket).
-// Counting sort on min(count, HEAVY + 1): k_size_hist (LDS histogram per workgroup) -> k_size_scan -> k_size_scatter.
+// Counting sort on min(count >> hs, HEAVY + 1): k_size_hist (LDS histogram per workgroup) -> k_size_scan -> k_size_scatter.
 constexpr int SIZE_BINS = (int)HEAVY + 2;
-__global__ __launch_bounds__(256) void k_size_hist(const uint32_t *__restrict__ counts, size_t total, uint32_t *__restrict__ bins) {
+__device__ __forceinline__ uint32_t size_bin(uint32_t cnt, int hs) { return cnt > (HEAVY << hs) ? HEAVY + 1 : cnt >> hs; }
+__global__ __launch_bounds__(256) void k_size_hist(const uint32_t *__restrict__ counts, size_t total, int hs,
+                                                   uint32_t *__restrict__ bins) {
   __shared__ uint32_t h[SIZE_BINS];
   for (int k = threadIdx.x; k < SIZE_BINS; k += 256) h[k] = 0;
   __syncthreads();
   const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (b < total) {
     const uint32_t cnt = counts[b];
-    atomicAdd(&h[cnt > HEAVY ? HEAVY + 1 : cnt], 1u);
+    atomicAdd(&h[size_bin(cnt, hs)], 1u);
   }
   __syncthreads();
   for (int k = threadIdx.x; k < SIZE_BINS; k += 256)
@@ -121,8 +144,8 @@ __global__ void k_size_scan(const uint32_t *__restrict__ bins, uint32_t *__restr
   uint32_t run = 0;
   for (int k = SIZE_BINS - 1; k >= 0; k--) { cursor[k] = run; run += bins[k]; }
 }
-__global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict__ counts, size_t total, uint32_t *__restrict__ cursor,
-                                                      uint32_t *__restrict__ order) {
+__global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict__ counts, size_t total, int hs,
+                                                      uint32_t *__restrict__ cursor, uint32_t *__restrict__ order) {
   __shared__ uint32_t h[SIZE_BINS], base[SIZE_BINS];
   for (int k = threadIdx.x; k < SIZE_BINS; k += 256) h[k] = 0;
   __syncthreads();
@@ -130,7 +153,7 @@ __global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict
   uint32_t bin = 0, rank = 0;
   if (b < total) {
     const uint32_t cnt = counts[b];
-    bin = cnt > HEAVY ? HEAVY + 1 : cnt;
+    bin = size_bin(cnt, hs);
     rank = atomicAdd(&h[bin], 1u);
   }
   __syncthreads();
@@ -143,42 +166,42 @@ __global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict
 template <class F>
 __global__ __launch_bounds__(128) void k_bucket_sum(const AffineT<F> *__restrict__ pts, const uint32_t *__restrict__ counts,
                                                     const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ sorted,
-                                                    const uint32_t *__restrict__ order, size_t total, size_t n, int c,
+                                                    const uint32_t *__restrict__ order, size_t total, size_t n, size_t nbs, int hs,
                                                     JacT<F> *__restrict__ buckets) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const size_t b = order[t];
-  const size_t w = b >> c;
+  const size_t w = b / nbs;
   JacT<F> acc = bls::jac_inf<F>();
   const uint32_t cnt = counts[b];  // 0 for digit 0 (k_hist skips it)
-  if (cnt > HEAVY) return;         // k_heavy_sum writes this one
+  if (cnt > (HEAVY << hs)) return;  // k_heavy_sum writes this one
   const uint32_t *idx = sorted + w * n + offsets[b];
-  for (uint32_t i = 0; i < cnt; i++) acc = bls::jac_add_mixed(acc, pts[idx[i]]);
+  for (uint32_t i = 0; i < cnt; i++) acc = bls::jac_add_mixed(acc, entry_point(pts, idx[i]));
   buckets[b] = acc;
 }
 
 // Skewed scalars (few distinct digits in a window; witness vectors full of 0/1) put many points into one bucket; a
 // single lane would add them one after the other. Heavy buckets are listed here ...
-__global__ void k_heavy_list(const uint32_t *__restrict__ counts, size_t total_buckets, uint32_t *__restrict__ n_heavy,
+__global__ void k_heavy_list(const uint32_t *__restrict__ counts, size_t total_buckets, int hs, uint32_t *__restrict__ n_heavy,
                              uint32_t *__restrict__ heavy) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= total_buckets || counts[b] <= HEAVY) return;
+  if (b >= total_buckets || counts[b] <= (HEAVY << hs)) return;
   heavy[atomicAdd(n_heavy, 1u)] = (uint32_t)b;
 }
 // ... and each is summed by one workgroup: 256 strided partial sums, then a tree in LDS.
 template <class F>
 __global__ __launch_bounds__(256) void k_heavy_sum(const AffineT<F> *__restrict__ pts, const uint32_t *__restrict__ counts,
                                                    const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ sorted,
-                                                   size_t n, int c, const uint32_t *__restrict__ n_heavy,
+                                                   size_t n, size_t nbs, const uint32_t *__restrict__ n_heavy,
                                                    const uint32_t *__restrict__ heavy, JacT<F> *__restrict__ buckets) {
   __shared__ JacT<F> part[HEAVY_LANES<F>];
   if (blockIdx.x >= *n_heavy) return;
   const size_t b = heavy[blockIdx.x];
-  const size_t w = b >> c;
+  const size_t w = b / nbs;
   const uint32_t *idx = sorted + w * n + offsets[b];
   const uint32_t cnt = counts[b];
   JacT<F> acc = bls::jac_inf<F>();
-  for (uint32_t t = threadIdx.x; t < cnt; t += HEAVY_LANES<F>) acc = bls::jac_add_mixed(acc, pts[idx[t]]);
+  for (uint32_t t = threadIdx.x; t < cnt; t += HEAVY_LANES<F>) acc = bls::jac_add_mixed(acc, entry_point(pts, idx[t]));
   part[threadIdx.x] = acc;
   __syncthreads();
   for (int half = HEAVY_LANES<F> / 2; half >= 1; half >>= 1) {
@@ -188,17 +211,18 @@ __global__ __launch_bounds__(256) void k_heavy_sum(const AffineT<F> *__restrict_
   if (threadIdx.x == 0) buckets[b] = part[0];
 }
 
-// grid = ((2^c / SEG) / 64, windows): out[w][seg] = sum_{d in run} d * B[w][d]
+// grid = (segs / 64, windows), segs = nbs / seg_len: out[w][seg] = sum_{d in run} d * B[w][d]
 template <class F>
-__global__ __launch_bounds__(64) void k_segment_reduce(const JacT<F> *__restrict__ buckets, int c, JacT<F> *__restrict__ out) {
-  const uint32_t segs = (1u << c) / SEG;
+__global__ __launch_bounds__(64) void k_segment_reduce(const JacT<F> *__restrict__ buckets, size_t nbs, uint32_t seg_len,
+                                                       JacT<F> *__restrict__ out) {
+  const uint32_t segs = (uint32_t)(nbs / seg_len);
   const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
   if (seg >= segs) return;
   const int w = blockIdx.y;
-  const uint32_t s = seg * SEG;
-  const JacT<F> *B = buckets + ((size_t)w << c);
+  const uint32_t s = seg * seg_len;
+  const JacT<F> *B = buckets + (size_t)w * nbs;
   JacT<F> running = bls::jac_inf<F>(), acc = bls::jac_inf<F>();
-  for (int d = (int)(s + SEG) - 1; d >= (int)s; d--) {
+  for (int d = (int)(s + seg_len) - 1; d >= (int)s; d--) {
     running = bls::jac_add(running, B[d]);
     acc = bls::jac_add(acc, running);
   }
@@ -206,11 +230,11 @@ __global__ __launch_bounds__(64) void k_segment_reduce(const JacT<F> *__restrict
   const JacT<F> off = s == 0 ? bls::jac_neg(running) : bls::jac_mul_small(running, s - 1);
   out[(size_t)w * segs + seg] = bls::jac_add(acc, off);
 }
-// data[w][i] += data[w][i + half] for i < half   (grid = (half/64, windows))
+// data[w][i] += data[w][i + half] for i + half < m   (m items left, half = ceil(m / 2); grid = (half/64, windows))
 template <class F>
-__global__ __launch_bounds__(64) void k_pair_reduce(JacT<F> *__restrict__ data, uint32_t stride, uint32_t half) {
+__global__ __launch_bounds__(64) void k_pair_reduce(JacT<F> *__restrict__ data, uint32_t stride, uint32_t m, uint32_t half) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= half) return;
+  if (i + half >= m) return;
   JacT<F> *row = data + (size_t)blockIdx.y * stride;
   row[i] = bls::jac_add(row[i], row[i + half]);
 }

@@ -107,6 +107,35 @@ def test_msm_large_properties(prover):
     P.free()
 
 
+@pytest.mark.parametrize("log_n,c", [(9, 5), (10, 8), (13, 13), (16, 16)])
+def test_msm_signed_digit_boundaries(prover, log_n, c):
+    """The windows are recoded to signed digits (|d| <= 2^(c-1), carry into the next window): scalars whose c-bit digits
+    sit on the boundary (2^(c-1) - 1, 2^(c-1), 2^(c-1) + 1, 2^c - 1, 0) in every window, full 256-bit scalars
+    included — long carry chains up to the extra top window. Closed form: points (a i + b) G."""
+    import cityprover as cp
+    _, r, G = O.bls_constants()
+    n = 1 << log_n
+    half = 1 << (c - 1)
+    rng = np.random.default_rng(1000 + c)
+    choices = [0, 1, half - 1, half, half + 1, (1 << c) - 1, (1 << c) - 2]
+    windows = (256 + c - 1) // c
+    ks = []
+    for i in range(n):
+        digs = rng.choice(choices, windows)
+        if i % 7 == 0:
+            digs[:] = (1 << c) - 1          # 2^256 - 1 after truncation: carries through every window
+        if i % 7 == 1:
+            digs[:] = half
+        ks.append(sum(int(d) << (c * w) for w, d in enumerate(digs)) % (1 << 256))
+    k = np.array([limbs(v, 4) for v in ks], dtype=np.uint64)
+    P = cp.G1Points.synthetic(prover, G, 3, 1, n)
+    ds = prover.to_device(k)
+    got = P.msm_dev(ds.ptr)
+    ds.free()
+    P.free()
+    assert got == O.bls_g1_mul(G, sum(v * (3 * i + 1) for i, v in enumerate(ks)) % r)
+
+
 def test_msm_skewed_scalars(prover):
     """Witness-like scalars: half are 0 or 1, the rest tiny — one bucket receives a large share of the points (the
     workgroup path for heavy buckets), the upper windows are empty."""
