@@ -710,6 +710,8 @@ class G2Points:
 # ---- NTT over the BLS12-381 scalar field ----
 ABI["cp_ntt_bls12381_fr"] = (ctypes.c_int, [_vp, _u64p, ctypes.c_int, ctypes.c_uint, _u64p])
 ABI["cp_ntt_bls12381_fr_dev"] = (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_uint, _u64p])
+ABI["cp_groth16_quotient_bls12381_dev"] = (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int])
+ABI["cp_groth16_quotient_bls12381"] = (ctypes.c_int, [_vp, _u64p, _u64p, _u64p, ctypes.c_int])
 
 
 def fr_ntt(prover, values, inverse=False, shift=None):
@@ -726,3 +728,20 @@ def fr_ntt_dev(prover, data_ptr, log_n, inverse=False, shift=None):
     flags = (NTT_INVERSE if inverse else 0) | (NTT_COSET if shift is not None else 0)
     sh = None if shift is None else np.array([(int(shift) >> (64 * j)) & (2**64 - 1) for j in range(4)], dtype=np.uint64)
     prover._check(prover.lib.cp_ntt_bls12381_fr_dev(prover.ctx, data_ptr, log_n, flags, None if sh is None else _ptr(sh)))
+
+
+def groth16_quotient(prover, a, b, c):
+    """a, b, c: (n, 4) uint64 canonical F_r evaluations of (A w), (B w), (C w) on <omega_n> -> the n coefficients of
+    h = (a b - c) / (x^n - 1) (cp_groth16_quotient_bls12381)."""
+    a = _as_u64(a).reshape(-1, 4).copy()
+    b = np.ascontiguousarray(_as_u64(b).reshape(-1, 4))
+    c = np.ascontiguousarray(_as_u64(c).reshape(-1, 4))
+    if not (a.shape == b.shape == c.shape):
+        raise ValueError("a, b, c must have the same length")
+    log_n = int(a.shape[0]).bit_length() - 1
+    prover._check(prover.lib.cp_groth16_quotient_bls12381(prover.ctx, _ptr(a), _ptr(b), _ptr(c), log_n))
+    return a
+
+
+def groth16_quotient_dev(prover, a_ptr, b_ptr, c_ptr, log_n):
+    prover._check(prover.lib.cp_groth16_quotient_bls12381_dev(prover.ctx, a_ptr, b_ptr, c_ptr, log_n))

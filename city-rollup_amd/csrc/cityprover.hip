@@ -49,8 +49,14 @@ struct cp_ctx {
   size_t pin_bytes = 0, pin_off = 0;
   // BLS12-381 F_r twiddle tables (fr_ntt.inc), keyed by (log_n, inverse)
   std::map<std::pair<int, int>, void *> fr_twiddles;
-  void *fr_work = nullptr, *fr_pow = nullptr;  // grow-only work arrays of the F_r NTT
-  size_t fr_work_bytes = 0, fr_pow_bytes = 0;
+  void *fr_work = nullptr;  // grow-only work array of the F_r NTT
+  size_t fr_work_bytes = 0;
+  struct FrPowers {         // cached coset power table s^i, i < 2^log_n (Groth16 always asks for the same two)
+    void *tab = nullptr;
+    size_t bytes = 0;
+    int log_n = -1;
+    uint64_t shift[4] = {0, 0, 0, 0};
+  } fr_pow[2];              // [0]: forward (powers of the shift), [1]: inverse (powers of its inverse)
   void *msm_ws = nullptr;  // grow-only workspace of the MSMs (counts, sorted indices, buckets)
   size_t msm_ws_bytes = 0;
   // device staging buffer for wire matrices that arrive in host memory (cp_prove / cp_prove_batch_host)
@@ -500,7 +506,8 @@ void cp_ctx_destroy(cp_ctx *ctx) {
   if (ctx->wires_stage) hipFree(ctx->wires_stage);
   for (auto &kv : ctx->fr_twiddles) hipFree(kv.second);
   if (ctx->fr_work) hipFree(ctx->fr_work);
-  if (ctx->fr_pow) hipFree(ctx->fr_pow);
+  for (auto &t : ctx->fr_pow)
+    if (t.tab) hipFree(t.tab);
   if (ctx->msm_ws) hipFree(ctx->msm_ws);
   if (ctx->pin) hipHostFree(ctx->pin);
   if (ctx->stream) hipStreamDestroy(ctx->stream);

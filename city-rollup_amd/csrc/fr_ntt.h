@@ -82,4 +82,13 @@ __global__ void k_store(const Fr *__restrict__ work, size_t n, int log_n, Fr sca
   blsfr::fr_to_canonical(v, data + 8 * i);
 }
 
+// Groth16 quotient on the coset: a[i] = (a[i] * b[i] - c[i]) * den   (canonical words in and out)
+__global__ void k_quotient_pointwise(uint32_t *__restrict__ a, const uint32_t *__restrict__ b, const uint32_t *__restrict__ c, Fr den,
+                                     size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fr A = blsfr::fr_from_canonical(a + 8 * i), B = blsfr::fr_from_canonical(b + 8 * i), C = blsfr::fr_from_canonical(c + 8 * i);
+  blsfr::fr_to_canonical(blsfr::fr_mul(blsfr::fr_sub(blsfr::fr_mul(A, B), C), den), a + 8 * i);
+}
+
 }  // namespace frntt

@@ -343,6 +343,17 @@ int cp_msm_bls12381_g2_dev(cp_ctx *ctx, const uint64_t *scalars_dev, const void 
 int cp_ntt_bls12381_fr(cp_ctx *ctx, uint64_t *data_host, int log_n, unsigned flags, const uint64_t *coset_shift);
 int cp_ntt_bls12381_fr_dev(cp_ctx *ctx, uint64_t *data_dev, int log_n, unsigned flags, const uint64_t *coset_shift);
 
+/* Groth16 quotient polynomial over F_r (the H part of the proof's C element; inside gnark's `groth16.Prove`, which
+ * `gnark_plonky2_wrapper::wrap_plonky2_proof` runs: city_rollup_circuit/src/worker/toolbox/root.rs:296-304).
+ * a, b, c: n = 2^log_n evaluations of the R1CS products (A w), (B w), (C w) on <omega_n>, canonical, natural order.
+ * Computes h = (a(x) b(x) - c(x)) / (x^n - 1) through the coset 7<omega_n>:
+ *   a, b, c <- iNTT;  <- coset NTT;  a <- (a o b - c) / (7^n - 1);  a <- coset iNTT.
+ * h's n coefficients replace a; b and c are overwritten with intermediates. For a satisfied R1CS (a o b = c on the
+ * domain) h is the exact quotient, of degree <= n - 2. Parity unpinned by the reference (no vectors). */
+int cp_groth16_quotient_bls12381_dev(cp_ctx *ctx, uint64_t *a_dev, uint64_t *b_dev, uint64_t *c_dev, int log_n);
+int cp_groth16_quotient_bls12381(cp_ctx *ctx, uint64_t *a_host, const uint64_t *b_host, const uint64_t *c_host,
+                                 int log_n);
+
 #ifdef __cplusplus
 }
 #endif

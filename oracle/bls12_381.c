@@ -416,3 +416,20 @@ void or_fr_ntt(uint64_t *data, int log_n, int inverse, const uint64_t *shift) {
   for (size_t i = 0; i < n; i++) fr_to(a[i], data + 4 * i);
   __builtin_free(a);
 }
+
+/* Groth16 quotient, as gnark's computeH does it (UPSTREAM-MEMORY: gnark backend/groth16/bls12-381/prove.go is not in
+ * /root/reference; call site city_rollup_circuit/src/worker/toolbox/root.rs:296-304): a, b, c = evaluations of
+ * (A w), (B w), (C w) on <omega_n>; h = coset_iNTT((coset_NTT(iNTT a) o coset_NTT(iNTT b) - coset_NTT(iNTT c)) / (g^n - 1)),
+ * coset generator g = 7. h overwrites a; b and c are left transformed. Parity unpinned by the reference. */
+void or_groth16_quotient(uint64_t *a, uint64_t *b, uint64_t *c, int log_n) {
+  fr_init();
+  const size_t n = (size_t)1 << log_n;
+  const uint64_t g[4] = {7, 0, 0, 0};
+  uint64_t *v[3] = {a, b, c};
+  for (int k = 0; k < 3; k++) { or_fr_ntt(v[k], log_n, 1, NULL); or_fr_ntt(v[k], log_n, 0, g); }
+  uint64_t e[4] = {(uint64_t)n, 0, 0, 0};
+  fr_t den = fr_inv(fr_sub(fr_pow(fr_from(g), e), FR_R1));
+  for (size_t i = 0; i < n; i++)
+    fr_to(fr_mul(fr_sub(fr_mul(fr_from(a + 4 * i), fr_from(b + 4 * i)), fr_from(c + 4 * i)), den), a + 4 * i);
+  or_fr_ntt(a, log_n, 1, g);
+}

@@ -213,6 +213,8 @@ void or_fr_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 void or_fr_root_of_unity(int log_n, uint64_t out[4]);
 void or_fr_dft_naive(const uint64_t *in, uint64_t *out, int log_n);
 void or_fr_ntt(uint64_t *data, int log_n, int inverse, const uint64_t *shift);
+/* Groth16 quotient h = (a b - c) / (x^n - 1) from evaluations on <omega_n> (through the coset 7<omega_n>); h -> a */
+void or_groth16_quotient(uint64_t *a, uint64_t *b, uint64_t *c, int log_n);
 
 /* number of worker threads the oracle uses for the batch entry points
  * (or_poseidon_permute_many, or_merkle_tree*, or_commit_batch); default 1 */

@@ -474,6 +474,13 @@ def fr_ntt(values, inverse=False, shift=None):
     return a
 
 
+def groth16_quotient(a, b, c):
+    """h = (a b - c) / (x^n - 1) from (n, 4) evaluation arrays; returns h's coefficients"""
+    a, b, c = arr(a).copy(), arr(b).copy(), arr(c).copy()
+    lib().or_groth16_quotient(ptr(a), ptr(b), ptr(c), ctypes.c_int(int(a.shape[0]).bit_length() - 1))
+    return a
+
+
 def fr_dft_naive(values):
     a = arr(values)
     out = np.zeros_like(a)

@@ -168,3 +168,41 @@ def test_fr_roots_and_ntt_definition():
         cos = [sum(vals[j] * pow(s * pow(w, k, r), j, r) for j in range(n)) % r for k in range(n)]   # evaluations on s*<w>
         assert fr_ints(O.fr_ntt(a, shift=s)) == cos
         assert (O.fr_ntt(O.fr_ntt(a, shift=s), inverse=True, shift=s) == a).all()
+
+
+# ---- Groth16 quotient ------------------------------------------------------------------------------------------
+def to_limbs(vals):
+    return np.array([[(v >> (64 * j)) & (2**64 - 1) for j in range(4)] for v in vals], dtype=np.uint64)
+
+
+def interp_eval(evals, z, w, r):
+    """value at z of the polynomial of degree < n with the given evaluations on <w> (barycentric form)"""
+    n = len(evals)
+    zn = (pow(z, n, r) - 1) * pow(n, -1, r) % r
+    return zn * sum(e * pow(w, i, r) * pow(z - pow(w, i, r), -1, r) for i, e in enumerate(evals)) % r
+
+
+def test_groth16_quotient_identity():
+    """h = (a b - c) / (x^n - 1): for a satisfied R1CS (c = a o b on the domain) the division is exact, h has degree
+    <= n - 2 and a(z) b(z) - c(z) = h(z) (z^n - 1) at any z; for arbitrary c the output is the degree < n polynomial
+    that agrees with the quotient on the coset 7<w> (what the coset transform computes). Python integers throughout."""
+    _, r, _ = O.bls_constants()
+    rng = np.random.default_rng(17)
+    for log_n in (1, 3, 6):
+        n = 1 << log_n
+        w = pow(7, (r - 1) >> log_n, r)
+        av, a = fr_rand(rng, n, r)
+        bv, b = fr_rand(rng, n, r)
+        cv = [x * y % r for x, y in zip(av, bv)]
+        h = fr_ints(O.groth16_quotient(a, b, to_limbs(cv)))
+        assert h[n - 1] == 0
+        for z in (5, int.from_bytes(rng.bytes(31), "little")):
+            lhs = (interp_eval(av, z, w, r) * interp_eval(bv, z, w, r) - interp_eval(cv, z, w, r)) % r
+            assert lhs == sum(hk * pow(z, k, r) for k, hk in enumerate(h)) * (pow(z, n, r) - 1) % r
+        # unsatisfied: agreement on the coset only
+        cv2, c2 = fr_rand(rng, n, r)
+        h2 = fr_ints(O.groth16_quotient(a, b, c2))
+        for i in (0, n // 2, n - 1):
+            x = 7 * pow(w, i, r) % r
+            lhs = (interp_eval(av, x, w, r) * interp_eval(bv, x, w, r) - interp_eval(cv2, x, w, r)) % r
+            assert lhs == sum(hk * pow(x, k, r) for k, hk in enumerate(h2)) * (pow(7, n, r) - 1) % r
