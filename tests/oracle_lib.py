@@ -21,10 +21,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    so = os.path.join(ORACLE_DIR, "libcityoracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("cityoracle.c", "plonky2_tail.c", "plonky2_quotient.c", "cityoracle.h", "goldilocks.h")]
-    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        build()
+    so = os.environ.get("CITYORACLE_SO")      # e.g. a sanitizer build (make -C oracle sanitize)
+    if not so:
+        so = os.path.join(ORACLE_DIR, "libcityoracle.so")
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            build()
     L = ctypes.CDLL(so)
     u64, sz, i = ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int
     sigs = {
