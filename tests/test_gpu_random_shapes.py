@@ -1,6 +1,9 @@
 """Randomised shape sweep: whole proofs (cp_prove_batch) on circuits with random degree, wire counts, number of
 challenges, blow-up, cap height, FRI reduction schedule, query count and PoW bits must equal the oracle's bytes and
-pass cp_verify. Seeds are fixed, so a failure names a reproducible configuration."""
+pass cp_verify. Seeds are fixed, so a failure names a reproducible configuration.
+CITY_RANDOM_SHAPES / CITY_RANDOM_GATE_SETS widen the sweep for a soak run (defaults 24 / 8)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -38,7 +41,7 @@ def random_config(seed):
                 n_copies=int(rng.integers(0, 8)))
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CITY_RANDOM_SHAPES", "24"))))
 def test_random_shape(prover, seed):
     import cityprover as cp
     cfg = random_config(seed)
@@ -55,7 +58,7 @@ def test_random_shape(prover, seed):
     circ.close()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CITY_RANDOM_GATE_SETS", "8"))))
 def test_random_gate_subsets_in_one_batch(prover, seed):
     """Random subsets of the 21 gate types (plonky2 selector grouping recomputed per subset), three different circuits of
     one shape proved in ONE batch call."""
