@@ -136,6 +136,24 @@ def test_msm_signed_digit_boundaries(prover, log_n, c):
     assert got == O.bls_g1_mul(G, sum(v * (3 * i + 1) for i, v in enumerate(ks)) % r)
 
 
+@pytest.mark.parametrize("n", [511, 513, 1023, 1025, 4097, 8191, 8193, 65535, 65537, 100003])
+def test_msm_sizes_around_window_changes(prover, n):
+    """Point counts that are not powers of two, on both sides of every change of window width (c = 5 / 8 / 13 / 16),
+    full 256-bit scalars; closed form (sum k_i (a i + b)) G for points (a i + b) G."""
+    import cityprover as cp
+    _, r, G = O.bls_constants()
+    rng = np.random.default_rng(n)
+    k = rng.integers(0, 2**64, (n, 4), dtype=np.uint64)
+    k[: n // 2, 3] >>= np.uint64(1)                      # half below 2^255, half anywhere below 2^256
+    P = cp.G1Points.synthetic(prover, G, 11, 5, n)
+    ds = prover.to_device(k)
+    got = P.msm_dev(ds.ptr)
+    ds.free()
+    P.free()
+    ks = [sum(int(k[i, j]) << (64 * j) for j in range(4)) for i in range(n)]
+    assert got == O.bls_g1_mul(G, sum(v * (11 * i + 5) for i, v in enumerate(ks)) % r)
+
+
 def test_msm_skewed_scalars(prover):
     """Witness-like scalars: half are 0 or 1, the rest tiny — one bucket receives a large share of the points (the
     workgroup path for heavy buckets), the upper windows are empty."""
