@@ -13,7 +13,7 @@
 //   UninterleaveToU32 city_common_circuit/src/u32/gates/uninterleave_to_u32.rs:82-130 (67 per op, deg 2)
 //   UninterleaveToB32 city_common_circuit/src/u32/gates/uninterleave_to_b32.rs:82-131 (67 per op, deg 2)
 // Remaining upstream gates of the city-common gate set (pad_circuit.rs:31-55), restated from plonky2 0.2.2:
-// ArithmeticExtension, MulExtension, BaseSum<B>, RandomAccess, Reducing, ReducingExtension, PoseidonMds,
+// ArithmeticExtension, MulExtension, BaseSum<B>, RandomAccess, Reducing, ReducingExtension, PoseidonMds, Exponentiation,
 // CosetInterpolation. Extension-valued wires are pairs of wires forming an element of the extension ALGEBRA
 // (F[X]/(X^2-7) over F = base field for the prover, F = F_p^2 for the verifier): `Alg<F>` below.
 // Each `eval` calls emit(k, value) for constraint k in the order the reference pushes them.
@@ -41,7 +41,8 @@ enum {
   REDUCING_EXT = 18,    // param = num_coeffs
   POSEIDON_MDS = 19,
   COSET_INTERPOLATION = 20,  // param = subgroup_bits, param2 = degree
-  N_TYPES = 21
+  EXPONENTIATION = 21,  // param = num_power_bits
+  N_TYPES = 22
 };
 
 constexpr int MAX_RANDOM_ACCESS_BITS = 4;
@@ -84,6 +85,7 @@ GL_HD int num_constraints(const Gate &g) {
     case REDUCING: case REDUCING_EXT: return 2 * g.param;
     case POSEIDON_MDS: return 24;
     case COSET_INTERPOLATION: return 2 * (2 + 2 * (((1 << g.param) - 2) / (g.param2 - 1)));
+    case EXPONENTIATION: return g.param + 1;
     default: return 0;
   }
 }
@@ -119,6 +121,7 @@ GL_HD int num_wires(const Gate &g) {
     case REDUCING_EXT: return 6 + 2 * g.param + 2 * (g.param - 1);
     case POSEIDON_MDS: return 48;
     case COSET_INTERPOLATION: return 1 + 2 * (1 << g.param) + 4 + 4 * (((1 << g.param) - 2) / (g.param2 - 1)) + 2;
+    case EXPONENTIATION: return 2 + 2 * g.param;
     default: return 0;
   }
 }
@@ -493,6 +496,19 @@ GL_HD void eval_t(const Gate &g, WF W, CF C, PF PI, EF emit) {
       emit(c++, d.b);
       break;
     }
+    case EXPONENTIATION: {  // plonky2 ExponentiationGate (gates/exponentiation.rs, UPSTREAM-MEMORY): wire 0 = base,
+      // 1..n = power bits (little-endian), n+1 = output, n+2.. = intermediate values; square-and-multiply from the top bit
+      const int n = g.param;
+      const F base = W(0), one = O::from(1);
+      for (int i = 0; i < n; i++) {
+        const F prev = i == 0 ? one : O::mul(W(2 + n + i - 1), W(2 + n + i - 1));
+        const F bit = W(1 + (n - 1 - i));
+        const F mul_by = O::add(O::mul(bit, base), O::sub(one, bit));
+        emit(i, O::sub(O::mul(prev, mul_by), W(2 + n + i)));
+      }
+      emit(n, O::sub(W(1 + n), W(2 + n + n - 1)));
+      break;
+    }
     default: break;
   }
 }
@@ -506,7 +522,7 @@ GL_HD void eval(const Gate &g, WF W, CF C, PF PI, EF emit) {
     CITY_GATE_CASE(U32_SUBTRACTION) CITY_GATE_CASE(U32_INTERLEAVE) CITY_GATE_CASE(UNINTERLEAVE_TO_U32)
     CITY_GATE_CASE(UNINTERLEAVE_TO_B32) CITY_GATE_CASE(ARITHMETIC_EXT) CITY_GATE_CASE(MUL_EXT) CITY_GATE_CASE(BASE_SUM)
     CITY_GATE_CASE(RANDOM_ACCESS) CITY_GATE_CASE(REDUCING) CITY_GATE_CASE(REDUCING_EXT) CITY_GATE_CASE(POSEIDON_MDS)
-    CITY_GATE_CASE(COSET_INTERPOLATION)
+    CITY_GATE_CASE(COSET_INTERPOLATION) CITY_GATE_CASE(EXPONENTIATION)
 #undef CITY_GATE_CASE
     default: break;
   }

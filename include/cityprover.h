@@ -256,7 +256,9 @@ enum {
   CP_GATE_REDUCING = 17,       /* ReducingGate              param = num_coeffs */
   CP_GATE_REDUCING_EXT = 18,   /* ReducingExtensionGate     param = num_coeffs */
   CP_GATE_POSEIDON_MDS = 19,   /* PoseidonMdsGate */
-  CP_GATE_COSET_INTERPOLATION = 20 /* CosetInterpolationGate param = subgroup_bits (<= 5), param2 = degree */
+  CP_GATE_COSET_INTERPOLATION = 20, /* CosetInterpolationGate param = subgroup_bits (<= 5), param2 = degree */
+  /* not in the city-common set; completes plonky2 0.2.2's standard gates except the lookup pair: */
+  CP_GATE_EXPONENTIATION = 21  /* ExponentiationGate        param = num_power_bits */
 };
 typedef struct cp_gate {
   int type;           /* CP_GATE_* */

@@ -141,7 +141,7 @@ enum { OR_GATE_NOOP = 0, OR_GATE_CONSTANT = 1, OR_GATE_PUBLIC_INPUT = 2, OR_GATE
        OR_GATE_U32_ADD_MANY = 8, OR_GATE_U32_SUBTRACTION = 9, OR_GATE_U32_INTERLEAVE = 10, OR_GATE_UNINTERLEAVE_TO_U32 = 11,
        OR_GATE_UNINTERLEAVE_TO_B32 = 12, OR_GATE_ARITHMETIC_EXT = 13, OR_GATE_MUL_EXT = 14, OR_GATE_BASE_SUM = 15,
        OR_GATE_RANDOM_ACCESS = 16, OR_GATE_REDUCING = 17, OR_GATE_REDUCING_EXT = 18, OR_GATE_POSEIDON_MDS = 19,
-       OR_GATE_COSET_INTERPOLATION = 20 };
+       OR_GATE_COSET_INTERPOLATION = 20, OR_GATE_EXPONENTIATION = 21 };
 typedef struct {
   int type;           /* OR_GATE_* */
   int selector_index; /* which selector polynomial (constants column) carries this gate's group */

@@ -10,7 +10,7 @@
  *       UninterleaveToB32Gate city_common_circuit/src/u32/gates/uninterleave_to_b32.rs:82-131
  *   - the remaining upstream gates of the city-common gate set (city_common_circuit/src/builder/pad_circuit.rs:31-55),
  *     restated from plonky2 0.2.2 (un-vendored, QEDProtocol/plonky2-hwa @ 6a8ca008): ArithmeticExtensionGate,
- *     MulExtensionGate, BaseSumGate<B>, RandomAccessGate, ReducingGate, ReducingExtensionGate, PoseidonMdsGate,
+ *     MulExtensionGate, BaseSumGate<B>, RandomAccessGate, ReducingGate, ReducingExtensionGate, PoseidonMdsGate, ExponentiationGate,
  *     CosetInterpolationGate. PARITY UNPINNED for these eight (no reference data can check them; see
  *     plonky2_quotient.c header) — validated by prove -> verify round trips on satisfying witnesses and by rejection
  *     of corrupted ones.
@@ -258,6 +258,22 @@ static void coset_interpolation(const or_gate *g, const gl2_t *w, cvec *out) {
   push_alg(out, alg_sub(alg_get(w, start_evaluation_value), st.eval));
 }
 
+/* ---- ExponentiationGate { num_power_bits } (plonky2 0.2.2 gates/exponentiation.rs, UPSTREAM-MEMORY):
+ * wire_base = 0, wire_power_bit(i) = 1 + i, wire_output = 1 + n, wire_intermediate_value(i) = 2 + n + i ---- */
+static void exponentiation(const or_gate *g, const gl2_t *w, cvec *out) {
+  const int num_power_bits = g->param;
+  const gl2_t base = w[0], one = gl2_from_base(1);
+  for (int i = 0; i < num_power_bits; i++) {
+    gl2_t prev_intermediate_value = i == 0 ? one : gl2_mul(w[2 + num_power_bits + i - 1], w[2 + num_power_bits + i - 1]);
+    /* power_bits is in LE order, but we accumulate in BE order */
+    gl2_t cur_bit = w[1 + (num_power_bits - i - 1)];
+    gl2_t not_cur_bit = gl2_sub(one, cur_bit);
+    gl2_t computed_intermediate_value = gl2_mul(prev_intermediate_value, gl2_add(gl2_mul(cur_bit, base), not_cur_bit));
+    push(out, gl2_sub(computed_intermediate_value, w[2 + num_power_bits + i]));
+  }
+  push(out, gl2_sub(w[1 + num_power_bits], w[2 + num_power_bits + num_power_bits - 1]));
+}
+
 int or_extra_gate_num_constraints(const or_gate *g) {
   switch (g->type) {
     case OR_GATE_U32_ADD_MANY: return g->param * (3 + 18);   /* add_many_u32.rs:266-268 */
@@ -272,6 +288,7 @@ int or_extra_gate_num_constraints(const or_gate *g) {
     case OR_GATE_REDUCING:
     case OR_GATE_REDUCING_EXT: return 2 * g->param;
     case OR_GATE_POSEIDON_MDS: return 24;
+    case OR_GATE_EXPONENTIATION: return g->param >= 1 ? g->param + 1 : -1;
     case OR_GATE_COSET_INTERPOLATION:
       if (g->param < 1 || g->param > 5 || g->param2 < 2) return -1;
       return (2 + 2 * (((1 << g->param) - 2) / (g->param2 - 1))) * 2;
@@ -295,6 +312,7 @@ int or_extra_gate_eval(const or_gate *g, const gl2_t *consts, const gl2_t *w, gl
     case OR_GATE_REDUCING_EXT: reducing(g, w, &c, 1); break;
     case OR_GATE_POSEIDON_MDS: poseidon_mds(w, &c); break;
     case OR_GATE_COSET_INTERPOLATION: coset_interpolation(g, w, &c); break;
+    case OR_GATE_EXPONENTIATION: exponentiation(g, w, &c); break;
     default: return -1;
   }
   return c.n;

@@ -355,6 +355,7 @@ GATE_COMPARISON, GATE_U32_ARITHMETIC, GATE_U32_RANGE_CHECK = 5, 6, 7
 GATE_U32_ADD_MANY, GATE_U32_SUBTRACTION, GATE_U32_INTERLEAVE, GATE_UNINTERLEAVE_TO_U32, GATE_UNINTERLEAVE_TO_B32 = 8, 9, 10, 11, 12
 (GATE_ARITHMETIC_EXT, GATE_MUL_EXT, GATE_BASE_SUM, GATE_RANDOM_ACCESS, GATE_REDUCING, GATE_REDUCING_EXT, GATE_POSEIDON_MDS,
  GATE_COSET_INTERPOLATION) = 13, 14, 15, 16, 17, 18, 19, 20
+GATE_EXPONENTIATION = 21
 
 
 # ---- BLS12-381 G1 (oracle/bls12_381.c) ---------------------------------------------------------------------

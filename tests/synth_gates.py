@@ -13,7 +13,7 @@ from synth_circuit import (P, UNUSED, OracleBackend, comparison_row, u32_arithme
 
 (NOOP, CONSTANT, PUBLIC_INPUT, ARITHMETIC, POSEIDON, COMPARISON, U32_ARITHMETIC, U32_RANGE_CHECK, U32_ADD_MANY,
  U32_SUBTRACTION, U32_INTERLEAVE, UNINTERLEAVE_TO_U32, UNINTERLEAVE_TO_B32, ARITHMETIC_EXT, MUL_EXT, BASE_SUM,
- RANDOM_ACCESS, REDUCING, REDUCING_EXT, POSEIDON_MDS, COSET_INTERPOLATION) = range(21)
+ RANDOM_ACCESS, REDUCING, REDUCING_EXT, POSEIDON_MDS, COSET_INTERPOLATION, EXPONENTIATION) = range(22)
 
 # (type, param, param2, param3) with the parameters `new_from_config(standard_recursion_config)` gives (135 wires, 80 routed)
 CITY_COMMON = [  # city_common_circuit/src/builder/pad_circuit.rs:31-55 (+ Noop, PublicInput, which every circuit has)
@@ -23,7 +23,8 @@ CITY_COMMON = [  # city_common_circuit/src/builder/pad_circuit.rs:31-55 (+ Noop,
 U32_GATES = [  # city_common_circuit/src/u32/gates/*.rs, num_ops from each gate's new_from_config at 135/80 wires
     (U32_ARITHMETIC, 3, 0, 0), (U32_RANGE_CHECK, 7, 0, 0), (U32_ADD_MANY, 5, 3, 0), (U32_SUBTRACTION, 6, 0, 0),
     (U32_INTERLEAVE, 3, 0, 0), (UNINTERLEAVE_TO_U32, 2, 0, 0), (UNINTERLEAVE_TO_B32, 2, 0, 0)]
-ALL_GATES = CITY_COMMON + U32_GATES
+OTHER_UPSTREAM = [(EXPONENTIATION, 66, 0, 0)]  # ExponentiationGate::new_from_config: min(80 - 2, (135 - 2) / 2) power bits
+ALL_GATES = CITY_COMMON + U32_GATES + OTHER_UPSTREAM
 
 _ID = {NOOP: "NoopGate", CONSTANT: "ConstantGate", PUBLIC_INPUT: "PublicInputGate", ARITHMETIC: "ArithmeticGate",
        POSEIDON: "PoseidonGate", COMPARISON: "ComparisonGate", U32_ARITHMETIC: "U32ArithmeticGate",
@@ -31,7 +32,8 @@ _ID = {NOOP: "NoopGate", CONSTANT: "ConstantGate", PUBLIC_INPUT: "PublicInputGat
        U32_INTERLEAVE: "U32InterleaveGate", UNINTERLEAVE_TO_U32: "UninterleaveToU32Gate",
        UNINTERLEAVE_TO_B32: "UninterleaveToB32Gate", ARITHMETIC_EXT: "ArithmeticExtensionGate", MUL_EXT: "MulExtensionGate",
        BASE_SUM: "BaseSumGate", RANDOM_ACCESS: "RandomAccessGate", REDUCING: "ReducingGate",
-       REDUCING_EXT: "ReducingExtensionGate", POSEIDON_MDS: "PoseidonMdsGate", COSET_INTERPOLATION: "CosetInterpolationGate"}
+       REDUCING_EXT: "ReducingExtensionGate", POSEIDON_MDS: "PoseidonMdsGate", COSET_INTERPOLATION: "CosetInterpolationGate",
+       EXPONENTIATION: "ExponentiationGate"}
 
 
 def gate_degree(g):
@@ -39,7 +41,7 @@ def gate_degree(g):
     return {NOOP: 0, CONSTANT: 1, PUBLIC_INPUT: 1, POSEIDON_MDS: 1, BASE_SUM: b, REDUCING: 2, REDUCING_EXT: 2,
             U32_INTERLEAVE: 2, UNINTERLEAVE_TO_U32: 2, UNINTERLEAVE_TO_B32: 2, ARITHMETIC: 3, ARITHMETIC_EXT: 3, MUL_EXT: 3,
             COMPARISON: 1 << (-(-a // b) if b else 0), U32_ARITHMETIC: 4, U32_RANGE_CHECK: 4, U32_ADD_MANY: 4,
-            U32_SUBTRACTION: 4, RANDOM_ACCESS: a + 1, COSET_INTERPOLATION: b, POSEIDON: 7}[t]
+            U32_SUBTRACTION: 4, RANDOM_ACCESS: a + 1, COSET_INTERPOLATION: b, POSEIDON: 7, EXPONENTIATION: 4}[t]
 
 
 def gate_num_wires(g):
@@ -52,7 +54,7 @@ def gate_num_wires(g):
             U32_ADD_MANY: a * (b + 21), U32_SUBTRACTION: 21 * a, U32_INTERLEAVE: 34 * a, UNINTERLEAVE_TO_U32: 67 * a,
             UNINTERLEAVE_TO_B32: 67 * a, ARITHMETIC_EXT: 8 * a, MUL_EXT: 6 * a, BASE_SUM: 1 + a,
             RANDOM_ACCESS: b * (2 + (1 << a)) + c + a * b, REDUCING: 6 + a + 2 * (a - 1), REDUCING_EXT: 6 + 2 * a + 2 * (a - 1),
-            POSEIDON_MDS: 48}[t]
+            POSEIDON_MDS: 48, EXPONENTIATION: 2 + 2 * a}[t]
 
 
 def selector_groups(gates, max_degree):
@@ -128,6 +130,19 @@ def mul_ext_row(rng, num_ops, c0):
 def base_sum_row(rng, num_limbs, base):
     limbs = [int(v) for v in rng.integers(0, base, num_limbs)]
     return [sum(l * base ** i for i, l in enumerate(limbs)) % P] + limbs
+
+
+def exponentiation_row(rng, num_power_bits):
+    """ExponentiationGenerator: intermediate_values[i] = prev^2 * (base if bit else 1), bits taken from the top"""
+    base = _felt(rng)
+    bits = [int(v) for v in rng.integers(0, 2, num_power_bits)]
+    inter, cur = [], 1
+    for i in range(num_power_bits):
+        cur = cur * cur % P
+        if bits[num_power_bits - 1 - i]:
+            cur = cur * base % P
+        inter.append(cur)
+    return [base] + bits + [inter[-1]] + inter
 
 
 def random_access_row(rng, bits, copies, extra, consts):
@@ -325,6 +340,8 @@ def build_gate_set(gate_set=CITY_COMMON, db=7, num_routed=80, num_wires=135, chu
             row = poseidon_mds_row(rng)
         elif t == COSET_INTERPOLATION:
             row = coset_interpolation_row(rng, a, b)
+        elif t == EXPONENTIATION:
+            row = exponentiation_row(rng, a)
         elif t == COMPARISON:
             x, y = int(rng.integers(0, 2**a)), int(rng.integers(0, 2**a))
             row = comparison_row(x, x if rng.random() < 0.2 else y, a, b)

@@ -66,7 +66,8 @@ def test_set_gates_parameter_validation(prover):
                 (cp.GATE_REDUCING, 0, 0, 1, 44, 0, 0),            # 136 wires
                 (cp.GATE_U32_ADD_MANY, 0, 0, 1, 5, 0, 0),         # no addends
                 (cp.GATE_UNINTERLEAVE_TO_U32, 0, 0, 1, 3, 0, 0),  # 201 wires
-                (21, 0, 0, 1, 0, 0, 0)]:                          # unknown type
+                (cp.GATE_EXPONENTIATION, 0, 0, 1, 67, 0, 0),      # 136 wires
+                (22, 0, 0, 1, 0, 0, 0)]:                          # unknown type
         with pytest.raises(cp.CityProverError):
             cp.set_gates(circ, [bad], 1)
     circ.close()

@@ -60,7 +60,7 @@ def test_random_shape(prover, seed):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("CITY_RANDOM_GATE_SETS", "8"))))
 def test_random_gate_subsets_in_one_batch(prover, seed):
-    """Random subsets of the 21 gate types (plonky2 selector grouping recomputed per subset), three different circuits of
+    """Random subsets of the 22 gate types (plonky2 selector grouping recomputed per subset), three different circuits of
     one shape proved in ONE batch call."""
     import cityprover as cp
     import synth_gates as SG

@@ -29,14 +29,15 @@ def test_selector_grouping_matches_plonky2_rule():
     rec = [g for g in gates if g[0] != SG.COMPARISON]
     assert len(SG.selector_groups(rec, 9)) == 3
     allg = sorted(SG.ALL_GATES, key=lambda g: (SG.gate_degree(g), SG._ID[g[0]]))
-    assert SG.selector_groups(allg, 9) == [(0, 7), (7, 13), (13, 18), (18, 20), (20, 21)]
+    assert SG.selector_groups(allg, 9) == [(0, 7), (7, 13), (13, 18), (18, 21), (21, 22)]
 
 
 def test_constraint_counts():
     want = {SG.COMPARISON: 88, SG.RANDOM_ACCESS: 26, SG.POSEIDON: 123, SG.POSEIDON_MDS: 24, SG.REDUCING: 86,
             SG.REDUCING_EXT: 64, SG.ARITHMETIC: 20, SG.ARITHMETIC_EXT: 20, SG.MUL_EXT: 26, SG.BASE_SUM: 64,
             SG.COSET_INTERPOLATION: 12, SG.U32_ARITHMETIC: 108, SG.U32_RANGE_CHECK: 119, SG.U32_ADD_MANY: 105,
-            SG.U32_SUBTRACTION: 114, SG.U32_INTERLEAVE: 102, SG.UNINTERLEAVE_TO_U32: 134, SG.UNINTERLEAVE_TO_B32: 134}
+            SG.U32_SUBTRACTION: 114, SG.U32_INTERLEAVE: 102, SG.UNINTERLEAVE_TO_U32: 134, SG.UNINTERLEAVE_TO_B32: 134,
+            SG.EXPONENTIATION: 67}
     for g in SG.ALL_GATES:
         if g[0] in want:
             og = O.make_gates([(g[0], 0, 0, 1, g[1], g[2], g[3])], 1, [1])
