@@ -189,27 +189,59 @@ __global__ __launch_bounds__(256) void k_leaf_hash_fri(const uint64_t *__restric
   d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
 }
 
-// Proof of work: candidates start .. start+count-1 for every proof still searching; records the smallest
-// witness whose response has `pow_bits` leading zero bits. st[proof] = sponge state with the pending
-// inputs already written, pos[proof] = slot the witness goes to.   grid = (count/256, B)
+// Proof of work (plonky2 `fri_proof_of_work`: the witness is hashed after the transcript's pending inputs; this
+// build, like the oracle, returns the SMALLEST witness whose response has `pow_bits` leading zero bits, which makes the
+// proof bytes deterministic). st[proof] = sponge state with the pending inputs already written, pos[proof] = slot the
+// witness goes to.
+// Persistent workgroups over a work queue: the candidates of a proof are handed out in ranges of 256, in increasing
+// order (next_range[proof], atomicAdd); a workgroup keeps taking ranges of "its" proof until a witness below the next
+// range is known (best[proof], atomicMin), then moves on to a proof that is still searching, and exits when none is.
+// So the chip stays full until the last proof is done, and the work beyond each proof's first witness is only what
+// was in flight when it was found. Ranges complete out of order, but a range is handed out only after all smaller
+// ones, and every range taken is finished: the minimum over all found witnesses is the smallest one.
+// Exit: next_range only grows and is bounded by count / 256, so every workgroup runs out of work.
 struct PowState { uint64_t s[12]; int pos; int pad; };
 __global__ __launch_bounds__(256) void k_pow_grind(const PowState *__restrict__ st, uint64_t start, uint64_t count,
-                                                   int pow_bits, const unsigned long long *__restrict__ done,
-                                                   unsigned long long *__restrict__ best) {
-  const size_t proof = blockIdx.y;
-  if (done[proof] != ~0ull) return;  // found in an earlier chunk
-  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= count) return;
-  uint64_t cand = start + i;
-  uint64_t s[poseidon::W];
-  const int pos = st[proof].pos;
+                                                   int pow_bits, unsigned n_proofs, const unsigned long long *__restrict__ done,
+                                                   unsigned long long *__restrict__ best, unsigned *__restrict__ next_range) {
+  __shared__ int s_proof;
+  __shared__ unsigned s_range;
+  const unsigned ranges = (unsigned)(count >> 8);
+  unsigned home = blockIdx.x % n_proofs;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      int found = -1;
+      unsigned r = 0;
+      for (unsigned k = 0; k < n_proofs && found < 0; k++) {
+        const unsigned q = home + k < n_proofs ? home + k : home + k - n_proofs;
+        if (done[q] != ~0ull) continue;  // found by an earlier launch, or supplied by the caller
+        const unsigned peek = __hip_atomic_load(next_range + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (peek >= ranges) continue;
+        if (__hip_atomic_load(best + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < start + ((uint64_t)peek << 8)) continue;
+        r = atomicAdd(next_range + q, 1u);
+        if (r >= ranges) continue;
+        found = (int)q;  // taken: it is computed even if a smaller witness has appeared meanwhile (harmless)
+      }
+      s_proof = found;
+      s_range = r;
+    }
+    __syncthreads();
+    const int q = s_proof;
+    const unsigned r = s_range;
+    __syncthreads();
+    if (q < 0) return;
+    home = (unsigned)q;
+    const uint64_t cand = start + ((uint64_t)r << 8) + threadIdx.x;
+    uint64_t s[poseidon::W];
+    const int pos = st[q].pos;
 #pragma unroll
-  for (int k = 0; k < poseidon::W; k++) s[k] = st[proof].s[k];
+    for (int k = 0; k < poseidon::W; k++) s[k] = st[q].s[k];
 #pragma unroll
-  for (int k = 0; k < 8; k++)
-    if (k == pos) s[k] = cand;
-  poseidon::permute(s);
-  if (pow_bits <= 0 || (s[7] >> (64 - pow_bits)) == 0) atomicMin(best + proof, (unsigned long long)cand);
+    for (int k = 0; k < 8; k++)
+      if (k == pos) s[k] = cand;
+    poseidon::permute(s);
+    if (pow_bits <= 0 || (s[7] >> (64 - pow_bits)) == 0) atomicMin(best + q, (unsigned long long)cand);
+  }
 }
 
 // Query gathering: one workgroup per (query round, proof); writes the bincode words of a FriQueryRound.
