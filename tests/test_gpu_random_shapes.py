@@ -1,7 +1,7 @@
 """Randomised shape sweep: whole proofs (cp_prove_batch) on circuits with random degree, wire counts, number of
 challenges, blow-up, cap height, FRI reduction schedule, query count and PoW bits must equal the oracle's bytes and
 pass cp_verify. Seeds are fixed, so a failure names a reproducible configuration.
-CITY_RANDOM_SHAPES / CITY_RANDOM_GATE_SETS widen the sweep for a soak run (defaults 24 / 8)."""
+CITY_RANDOM_SHAPES / CITY_RANDOM_ZK / CITY_RANDOM_GATE_SETS widen the sweep for a soak run (defaults 24 / 8 / 8)."""
 import os
 
 import numpy as np
@@ -52,6 +52,27 @@ def test_random_shape(prover, seed):
     cp.set_gates(circ, c["gate_list"], c["num_selectors"])
     got = cp.prove(circ, c["wires"], c["public_inputs"])
     want, _ = O.prove_full(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], c["wires"])
+    assert got == want, cfg
+    cp.verify(circ, got)
+    assert O.verify_full(c["shape"], c["gates"], digest, circ.cs_cap(), got) == 0, cfg
+    circ.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CITY_RANDOM_ZK", "8"))))
+def test_random_shape_zero_knowledge(prover, seed):
+    """The same sweep in zero-knowledge mode (FRI hiding: 4 salt elements on every wires / Z / quotient leaf)."""
+    import cityprover as cp
+    cfg = random_config(7000 + seed)
+    c = build(**cfg)
+    c["shape"].zero_knowledge = 1
+    N = 1 << (cfg["db"] + cfg["rate_bits"])
+    salts = np.random.default_rng(seed).integers(0, O.P, (3, O.SALT_SIZE, N), dtype=np.uint64)
+    sh = cp_shape_of(cp, c["shape"])
+    digest = [seed, 9, 9, 9]
+    circ = cp.Circuit(prover, sh, digest, c["cs_values"])
+    cp.set_gates(circ, c["gate_list"], c["num_selectors"])
+    got = cp.prove_batch_zk(prover, [circ], [c["public_inputs"]], [c["wires"]], [salts])[0]
+    want, _ = O.prove_full_zk(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], c["wires"], salts)
     assert got == want, cfg
     cp.verify(circ, got)
     assert O.verify_full(c["shape"], c["gates"], digest, circ.cs_cap(), got) == 0, cfg
