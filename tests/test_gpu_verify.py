@@ -81,3 +81,36 @@ def test_verify_accepts_and_rejects(prover, db, R, W, arity):
     for b in (dw, dw2):
         b.free()
     circ.close(); other.close()
+
+
+def test_verify_survives_malformed_bytes(prover):
+    """cp_verify on mutated proofs — flipped bits, truncations, overwritten 8-byte words (length prefixes among them:
+    huge and near-2^64 values), trailing bytes: every one is refused with an error code, none crashes or hangs (the ABI
+    never aborts, include/cityprover.h). The oracle's parser sees the same mutations under ASan in DESIGN.md §3."""
+    import cityprover as cp
+    c = build(db=5, num_routed=16, num_wires=20, chunk=8, rate_bits=3, arity_bits=(2,), seed=3)
+    circ = load(prover, c, [1, 2, 3, 4])
+    proof = cp.prove(circ, c["wires"], c["public_inputs"])
+    cp.verify(circ, proof)
+    rng = np.random.default_rng(1)
+    n = len(proof)
+    for it in range(1500):
+        b = bytearray(proof)
+        kind = it % 5
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, n))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            b = b[: int(rng.integers(0, n))]
+        elif kind == 2:
+            pos = int(rng.integers(0, n - 8)) & ~7
+            b[pos:pos + 8] = int(rng.integers(0, 2**63)).to_bytes(8, "little")
+        elif kind == 3:
+            b += bytes(rng.integers(0, 256, int(rng.integers(1, 64)), dtype=np.uint8))
+        else:
+            pos = int(rng.integers(0, n - 8)) & ~7
+            b[pos:pos + 8] = (2**64 - 1 - int(rng.integers(0, 4))).to_bytes(8, "little")
+        with pytest.raises(cp.CityProverError):
+            cp.verify(circ, bytes(b))
+    cp.verify(circ, proof)        # the context is still usable
+    circ.close()
