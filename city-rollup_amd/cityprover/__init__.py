@@ -26,6 +26,7 @@ ABI = {
     "cp_device_count": (ctypes.c_int, []),
     "cp_ctx_create": (_vp, [ctypes.c_int]),
     "cp_ctx_destroy": (None, [_vp]),
+    "cp_ctx_set_lanes": (ctypes.c_int, [_vp, ctypes.c_int]),
     "cp_last_error": (ctypes.c_char_p, [_vp]),
     "cp_dev_alloc": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "cp_dev_free": (ctypes.c_int, [_vp, _vp]),
@@ -158,6 +159,10 @@ class Prover:
     # ---- memory / timing -----------------------------------------------------------------
     def alloc(self, n_elems):
         return DeviceBuffer(self, n_elems)
+
+    def set_lanes(self, lanes):
+        """internal pipelining of cp_prove_batch_host for a single-threaded caller (cp_ctx_set_lanes)"""
+        self._check(self.lib.cp_ctx_set_lanes(self.ctx, int(lanes)))
 
     def to_device(self, arr):
         arr = _as_u64(arr)

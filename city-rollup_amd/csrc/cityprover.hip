@@ -36,6 +36,11 @@ struct cp_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
   std::string error;
+  // cp_ctx_set_lanes: child contexts (own stream, arena, staging) among which ONE cp_prove_batch_host call is split, so
+  // that a single-threaded caller gets the overlap of host phases and small kernels that several contexts give
+  cp_ctx *parent = nullptr;
+  std::vector<cp_ctx *> lanes;
+  int n_lanes = 1;
   std::map<uint64_t, PowTable> pow_tables;  // keyed by base
   struct PreKey { int log_n, rate_bits; uint64_t shift; bool operator<(const PreKey &o) const {
     return std::tie(log_n, rate_bits, shift) < std::tie(o.log_n, o.rate_bits, o.shift); } };
@@ -495,6 +500,8 @@ cp_ctx *cp_ctx_create(int device) {
 
 void cp_ctx_destroy(cp_ctx *ctx) {
   if (!ctx) return;
+  for (cp_ctx *lane : ctx->lanes) cp_ctx_destroy(lane);
+  ctx->lanes.clear();
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   prof_flush(ctx);
@@ -512,6 +519,20 @@ void cp_ctx_destroy(cp_ctx *ctx) {
   if (ctx->pin) hipHostFree(ctx->pin);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+int cp_ctx_set_lanes(cp_ctx *ctx, int lanes) {
+  CHECK_CTX(ctx);
+  if (ctx->parent) return set_error(ctx, CP_ERR_INVALID_ARG, "a lane has no lanes of its own");
+  if (lanes < 1 || lanes > 8) return set_error(ctx, CP_ERR_INVALID_ARG, "lanes must be 1..8 (got %d)", lanes);
+  while ((int)ctx->lanes.size() < lanes) {
+    cp_ctx *lane = cp_ctx_create(ctx->device);
+    if (!lane) return set_error(ctx, CP_ERR_HIP, "lane context: %s", cp_last_error(nullptr));
+    lane->parent = ctx;
+    ctx->lanes.push_back(lane);
+  }
+  ctx->n_lanes = lanes;
+  return CP_OK;
 }
 
 int cp_dev_alloc(cp_ctx *ctx, size_t bytes, void **out) {

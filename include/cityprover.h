@@ -61,6 +61,13 @@ int cp_device_count(void);
  * when no GPU is present: there is no CPU fallback in this library. */
 cp_ctx *cp_ctx_create(int device);
 void cp_ctx_destroy(cp_ctx *ctx);
+/* Internal pipelining for single-threaded callers (the reference's worker loop is one thread per process,
+ * city_rollup_core_worker/src/lib.rs:131-145): with lanes > 1, cp_prove_batch_host / cp_prove_batch_zk_host split a
+ * batch of >= 4 * lanes proofs among `lanes` internal contexts (own stream, workspace and staging; the circuits stay
+ * shared) driven by short-lived threads, so the host phases of one part overlap the kernels of the others. Same proof
+ * bytes; ~20 % more proofs/s than lanes = 1 for one caller at B = 32. Callers that already run
+ * several contexts from several threads should leave it at 1 (the default). lanes: 1..8. */
+int cp_ctx_set_lanes(cp_ctx *ctx, int lanes);
 /* last error message of `ctx`, or of the calling thread when ctx == NULL. Never NULL. */
 const char *cp_last_error(cp_ctx *ctx);
 

@@ -259,3 +259,36 @@ def test_zero_knowledge_circuits(prover):
     pc.close()
     for c in circs:
         c.close()
+
+
+def test_internal_lanes_give_the_same_bytes(prover):
+    """cp_ctx_set_lanes: one cp_prove_batch_host call split among internal contexts returns the bytes of the unsplit call
+    (plain and zero-knowledge entry points); a failing part fails the whole call and leaves no outputs behind."""
+    import cityprover as cp
+    p2 = cp.Prover(0)
+    try:
+        cases = [build(db=6, num_routed=16, num_wires=20, chunk=8, rate_bits=3, arity_bits=(2, 2), seed=300 + i) for i in range(3)]
+        sh = cp_shape_of(cp, cases[0]["shape"])
+        circs = []
+        for i, c in enumerate(cases):
+            circ = cp.Circuit(p2, sh, [i, 5, 5, 5], c["cs_values"])
+            cp.set_gates(circ, c["gate_list"], c["num_selectors"])
+            circs.append(circ)
+        pick = [i % 3 for i in range(13)]
+        args = ([circs[i] for i in pick], [cases[i]["public_inputs"] for i in pick], [cases[i]["wires"] for i in pick])
+        want = cp.prove_batch(p2, *args)
+        for lanes in (2, 3):
+            p2.set_lanes(lanes)
+            assert cp.prove_batch(p2, *args) == want
+        bad = list(args[1])
+        bad[12] = np.full_like(np.asarray(bad[12], np.uint64), 2**64 - 1)      # not canonical: the last part fails
+        with pytest.raises(cp.CityProverError, match="canonical"):
+            cp.prove_batch(p2, args[0], bad, args[2])
+        p2.set_lanes(1)
+        assert cp.prove_batch(p2, *args) == want
+        with pytest.raises(cp.CityProverError):
+            p2.set_lanes(9)
+        for c in circs:
+            c.close()
+    finally:
+        p2.close()

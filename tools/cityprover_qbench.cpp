@@ -10,6 +10,7 @@
 //   --mode throughput : every worker proves --iters batches of --batch independent proofs (common start, wall clock
 //                       until the last worker finishes)
 //   --mode dag        : --blocks example blocks in flight, proof-level dependencies honoured
+//   --lanes L         : cp_ctx_set_lanes(L) on every worker context (internal pipelining of one call; default 1)
 // Before timing, each distinct circuit is proved once and the bytes are compared with the oracle's, then cp_verify'd.
 // Build: g++ -O2 -std=c++17 -Iinclude tools/cityprover_qbench.cpp -Lcity-rollup_amd -lcityprover_hip
 //            -Wl,-rpath,'$ORIGIN/../city-rollup_amd' -lpthread -o tools/cityprover_qbench
@@ -214,7 +215,7 @@ struct Dag {
 
 int main(int argc, char **argv) {
   std::string path = "tools/qbench_case.bin", mode = "throughput";
-  int contexts = 3, batch = 32, iters = 8, blocks = 32, device = 0;
+  int contexts = 3, batch = 32, iters = 8, blocks = 32, device = 0, lanes = 1;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     auto val = [&]() -> const char * { if (i + 1 >= argc) die("missing value for " + a); return argv[++i]; };
@@ -225,6 +226,7 @@ int main(int argc, char **argv) {
     else if (a == "--iters") iters = atoi(val());
     else if (a == "--blocks") blocks = atoi(val());
     else if (a == "--device") device = atoi(val());
+    else if (a == "--lanes") lanes = atoi(val());
     else die("unknown argument " + a);
   }
   if (contexts < 1 || batch < 1 || iters < 1 || blocks < 1) die("bad argument value");
@@ -232,7 +234,10 @@ int main(int argc, char **argv) {
   const Case cs = load_case(path.c_str());
   const uint32_t n_circ = (uint32_t)cs.circuits.size();
   std::vector<Worker> workers(contexts);
-  for (auto &w : workers) w.open(cs, device);
+  for (auto &w : workers) {
+    w.open(cs, device);
+    w.check(cp_ctx_set_lanes(w.ctx, lanes), "cp_ctx_set_lanes");  // > 1: one call is pipelined inside the library
+  }
 
   // parity gate: every circuit once, bytes against the oracle's, then the library's verifier
   {
@@ -293,11 +298,11 @@ int main(int argc, char **argv) {
   }
   const double dt = t1 - t0;
   const size_t per_block = cs.dag.size();
-  printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"%s\", \"contexts\": %d, \"max_batch\": %d, \"proofs\": %zu, "
+  printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"%s\", \"contexts\": %d, \"lanes_per_context\": %d, \"max_batch\": %d, \"proofs\": %zu, "
          "\"wall_s\": %.6f, \"proofs_per_s\": %.2f, \"blocks_per_s\": %.3f, \"mean_batch\": %.2f, \"proofs_per_block\": %zu, "
          "\"blocks_in_flight\": %d, \"proof_bytes\": %zu, \"parity\": \"proof bytes == oracle bytes for all %u circuits; cp_verify ok\", "
          "\"wires\": \"host (page-locked), PCIe-inclusive\"}\n",
-         mode.c_str(), contexts, batch, (size_t)proofs, dt, proofs / dt, proofs / dt / (double)per_block,
+         mode.c_str(), contexts, lanes, batch, (size_t)proofs, dt, proofs / dt, proofs / dt / (double)per_block,
          (double)proofs / (double)batches, per_block, mode == "dag" ? blocks : 0, cs.circuits[0].expected_proof.size(), n_circ);
   for (auto &w : workers) w.close();
   return 0;
