@@ -74,6 +74,63 @@ __global__ void k_hist(const uint32_t *__restrict__ scalars, const uint8_t *__re
     if (d) atomicAdd(&counts[(size_t)w * nbs + (d < 0 ? -d : d)], 1u);
   }
 }
+// ---- the same counting sort for large point sets (n >= 2^21), with the counters privatised in LDS -------------------
+// k_hist / k_scatter issue one global atomic per (scalar, window): 0.57 G of them at 2^25 points, a quarter of the MSM
+// (and on witness-like scalars they pile onto a few counters). Here a workgroup owns a tile of >= 2^17 scalars of ONE
+// window and keeps that window's <= 32784 counters in LDS (128 KB of the 160 KB): LDS atomics per scalar, one global
+// atomic per non-empty counter and tile. The signed digits are computed once (the recoding carries through the
+// windows) into digits[w][i]; 0 = no contribution (zero digit, or a point at infinity).
+constexpr int TILE_NBS = 32784;  // 2^15 + 1 bucket indices padded to a multiple of 16 (c = 16, the widest window used)
+__global__ void k_digits(const uint32_t *__restrict__ scalars, const uint8_t *__restrict__ inf, size_t n, int c, int windows,
+                         int32_t *__restrict__ digits) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool skip = inf && inf[i];
+  uint32_t carry = 0;
+  for (int w = 0; w < windows; w++) {
+    const int d = signed_digit(scalars + SCALAR_WORDS * i, w, c, carry);
+    digits[(size_t)w * n + i] = skip ? 0 : d;
+  }
+}
+// grid = (tiles, windows)
+__global__ __launch_bounds__(1024) void k_hist_tiled(const int32_t *__restrict__ digits, size_t n, size_t tile, size_t nbs,
+                                                     uint32_t *__restrict__ counts) {
+  __shared__ uint32_t h[TILE_NBS];
+  const size_t w = blockIdx.y, lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
+  for (size_t b = threadIdx.x; b < nbs; b += 1024) h[b] = 0;
+  __syncthreads();
+  for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    const int d = digits[w * n + i];
+    if (d) atomicAdd(&h[d < 0 ? -d : d], 1u);
+  }
+  __syncthreads();
+  for (size_t b = threadIdx.x; b < nbs; b += 1024)
+    if (h[b]) atomicAdd(&counts[w * nbs + b], h[b]);
+}
+__global__ __launch_bounds__(1024) void k_scatter_tiled(const int32_t *__restrict__ digits, size_t n, size_t tile, size_t nbs,
+                                                        uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted) {
+  __shared__ uint32_t h[TILE_NBS];
+  const size_t w = blockIdx.y, lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
+  for (size_t b = threadIdx.x; b < nbs; b += 1024) h[b] = 0;
+  __syncthreads();
+  for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    const int d = digits[w * n + i];
+    if (d) atomicAdd(&h[d < 0 ? -d : d], 1u);
+  }
+  __syncthreads();
+  for (size_t b = threadIdx.x; b < nbs; b += 1024) {  // reserve this tile's slots of every bucket: h[b] <- first slot
+    const uint32_t cnt = h[b];
+    if (cnt) h[b] = atomicAdd(&cursor[w * nbs + b], cnt);
+  }
+  __syncthreads();
+  for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    const int d = digits[w * n + i];
+    if (!d) continue;
+    const uint32_t pos = atomicAdd(&h[d < 0 ? -d : d], 1u);
+    sorted[w * n + pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+  }
+}
+
 // one workgroup of 1024 lanes per window: exclusive scan of its nbs counts -> offsets, cursor = offsets
 __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ counts, size_t nbs, uint32_t *__restrict__ offsets,
                                                uint32_t *__restrict__ cursor) {

@@ -154,6 +154,29 @@ def test_msm_sizes_around_window_changes(prover, n):
     assert got == O.bls_g1_mul(G, sum(v * (11 * i + 5) for i, v in enumerate(ks)) % r)
 
 
+def test_msm_large_point_set_tiled_sort(prover):
+    """n >= 2^21 takes the LDS-privatised digit sort (tiles of scalars per window): 2^21 + 777 points, a third of the
+    scalars witness-like (0 / 1 / small), the rest full 256-bit; closed form as above."""
+    import cityprover as cp
+    _, r, G = O.bls_constants()
+    n = (1 << 21) + 777
+    rng = np.random.default_rng(21)
+    k = rng.integers(0, 2**64, (n, 4), dtype=np.uint64)
+    small = rng.random(n) < 0.33
+    k[small, 1:] = 0
+    k[small, 0] = rng.choice(np.array([0, 1, 1, 2, 65535, 65536], dtype=np.uint64), int(small.sum()))
+    P = cp.G1Points.synthetic(prover, G, 3, 7, n)
+    ds = prover.to_device(k)
+    got = P.msm_dev(ds.ptr)
+    ds.free()
+    P.free()
+    idx = np.arange(n, dtype=object) * 3 + 7
+    total = 0
+    for j in range(4):
+        total += int((k[:, j].astype(object) * idx).sum()) << (64 * j)
+    assert got == O.bls_g1_mul(G, total % r)
+
+
 def test_msm_skewed_scalars(prover):
     """Witness-like scalars: half are 0 or 1, the rest tiny — one bucket receives a large share of the points (the
     workgroup path for heavy buckets), the upper windows are empty."""
