@@ -74,9 +74,9 @@ __global__ void k_hist(const uint32_t *__restrict__ scalars, const uint8_t *__re
     if (d) atomicAdd(&counts[(size_t)w * nbs + (d < 0 ? -d : d)], 1u);
   }
 }
-// ---- the same counting sort for large point sets (n >= 2^21), with the counters privatised in LDS -------------------
+// ---- the same counting sort for n >= 2^18 points, with the counters privatised in LDS ------------------------------
 // k_hist / k_scatter issue one global atomic per (scalar, window): 0.57 G of them at 2^25 points, a quarter of the MSM
-// (and on witness-like scalars they pile onto a few counters). Here a workgroup owns a tile of >= 2^17 scalars of ONE
+// (and on witness-like scalars they pile onto a few counters). Here a workgroup owns a tile of scalars of ONE
 // window and keeps that window's <= 32784 counters in LDS (128 KB of the 160 KB): LDS atomics per scalar, one global
 // atomic per non-empty counter and tile. The signed digits are computed once (the recoding carries through the
 // windows) into digits[w][i]; 0 = no contribution (zero digit, or a point at infinity).

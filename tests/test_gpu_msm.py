@@ -136,10 +136,11 @@ def test_msm_signed_digit_boundaries(prover, log_n, c):
     assert got == O.bls_g1_mul(G, sum(v * (3 * i + 1) for i, v in enumerate(ks)) % r)
 
 
-@pytest.mark.parametrize("n", [511, 513, 1023, 1025, 4097, 8191, 8193, 65535, 65537, 100003])
+@pytest.mark.parametrize("n", [511, 513, 1023, 1025, 4097, 8191, 8193, 65535, 65537, 100003, 262143, 262144, 300007])
 def test_msm_sizes_around_window_changes(prover, n):
     """Point counts that are not powers of two, on both sides of every change of window width (c = 5 / 8 / 13 / 16),
-    full 256-bit scalars; closed form (sum k_i (a i + b)) G for points (a i + b) G."""
+    and of the switch to the LDS-privatised digit sort (n >= 2^18); full 256-bit scalars; closed form
+    (sum k_i (a i + b)) G for points (a i + b) G."""
     import cityprover as cp
     _, r, G = O.bls_constants()
     rng = np.random.default_rng(n)
@@ -155,7 +156,7 @@ def test_msm_sizes_around_window_changes(prover, n):
 
 
 def test_msm_large_point_set_tiled_sort(prover):
-    """n >= 2^21 takes the LDS-privatised digit sort (tiles of scalars per window): 2^21 + 777 points, a third of the
+    """The LDS-privatised digit sort (tiles of scalars per window) with many tiles: 2^21 + 777 points, a third of the
     scalars witness-like (0 / 1 / small), the rest full 256-bit; closed form as above."""
     import cityprover as cp
     _, r, G = O.bls_constants()
