@@ -257,6 +257,40 @@ template <class F> GL_HD JacT<F> jac_add(const JacT<F> &p, const JacT<F> &q) {
   r.z = f_mul(f_mul(p.z, q.z), h);
   return r;
 }
+// Bucket accumulators use extended Jacobian ("XYZZ") coordinates: x = X/ZZ, y = Y/ZZZ with ZZ^3 = ZZZ^2; zz = 0:
+// infinity. Adding an affine point costs 8 products + 2 squarings ("madd-2008-s") against 8 + 3 for the Jacobian
+// mixed addition, and the result goes back to Jacobian with two products: (X ZZ, Y ZZZ, ZZ).
+template <class F> struct XyzzT { F x, y, zz, zzz; };
+template <class F> GL_HD XyzzT<F> xyzz_inf() { return {Field<F>::one(), Field<F>::one(), Field<F>::zero(), Field<F>::zero()}; }
+template <class F> GL_HD XyzzT<F> xyzz_add_mixed(const XyzzT<F> &p, const AffineT<F> &q) {  // q not infinity
+  if (f_is_zero(p.zz)) return {q.x, q.y, Field<F>::one(), Field<F>::one()};
+  const F u2 = f_mul(q.x, p.zz), s2 = f_mul(q.y, p.zzz);
+  if (f_eq(p.x, u2)) {
+    if (!f_eq(p.y, s2)) return xyzz_inf<F>();
+    // doubling of the affine point ("mdbl-2008-s-1", a = 0)
+    const F u = f_dbl(q.y), v = f_sqr(u), w = f_mul(u, v), s = f_mul(q.x, v);
+    const F xx = f_sqr(q.x), m = f_add(f_dbl(xx), xx);
+    XyzzT<F> r;
+    r.x = f_sub(f_sqr(m), f_dbl(s));
+    r.y = f_sub(f_mul(m, f_sub(s, r.x)), f_mul(w, q.y));
+    r.zz = v;
+    r.zzz = w;
+    return r;
+  }
+  const F pp_ = f_sub(u2, p.x), rr = f_sub(s2, p.y);
+  const F pp = f_sqr(pp_), ppp = f_mul(pp_, pp), qq = f_mul(p.x, pp);
+  XyzzT<F> r;
+  r.x = f_sub(f_sub(f_sqr(rr), ppp), f_dbl(qq));
+  r.y = f_sub(f_mul(rr, f_sub(qq, r.x)), f_mul(p.y, ppp));
+  r.zz = f_mul(p.zz, pp);
+  r.zzz = f_mul(p.zzz, ppp);
+  return r;
+}
+template <class F> GL_HD JacT<F> xyzz_to_jac(const XyzzT<F> &p) {
+  if (f_is_zero(p.zz)) return jac_inf<F>();
+  return {f_mul(p.x, p.zz), f_mul(p.y, p.zzz), p.zz};
+}
+
 template <class F> GL_HD JacT<F> jac_neg(const JacT<F> &p) { return {p.x, f_sub(Field<F>::zero(), p.y), p.z}; }
 // k * p for a small scalar (window-reduction offsets), double-and-add from the top bit
 template <class F> GL_HD JacT<F> jac_mul_small(const JacT<F> &p, uint32_t k) {

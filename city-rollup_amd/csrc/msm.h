@@ -7,7 +7,8 @@
 //   k_points_to_mont   canonical affine points -> Montgomery form (once per point set: a proving key is fixed)
 //   k_hist / k_scan / k_scatter   signed-digit recoding + counting sort of the point indices by |digit|, per window
 //                      (atomics; the order inside a bucket is arbitrary, the group law does not care)
-//   k_bucket_sum       one lane per (window, digit): mixed additions of its points into a Jacobian accumulator
+//   k_bucket_sum       one lane per (window, digit): mixed additions of its points into an XYZZ accumulator (10 field
+//                      products each instead of 11), stored as a Jacobian point
 //   k_segment_reduce   one lane per (window, run of seg_len buckets): sum_d d*B_d over the run by the running-sum trick plus
 //                      a small scalar multiple for the run's offset
 //   k_pair_reduce      tree reduction of the runs of a window
@@ -229,12 +230,12 @@ __global__ __launch_bounds__(128) void k_bucket_sum(const AffineT<F> *__restrict
   if (t >= total) return;
   const size_t b = order[t];
   const size_t w = b / nbs;
-  JacT<F> acc = bls::jac_inf<F>();
+  bls::XyzzT<F> acc = bls::xyzz_inf<F>();
   const uint32_t cnt = counts[b];  // 0 for digit 0 (k_hist skips it)
   if (cnt > (HEAVY << hs)) return;  // k_heavy_sum writes this one
   const uint32_t *idx = sorted + w * n + offsets[b];
-  for (uint32_t i = 0; i < cnt; i++) acc = bls::jac_add_mixed(acc, entry_point(pts, idx[i]));
-  buckets[b] = acc;
+  for (uint32_t i = 0; i < cnt; i++) acc = bls::xyzz_add_mixed(acc, entry_point(pts, idx[i]));
+  buckets[b] = bls::xyzz_to_jac(acc);
 }
 
 // Skewed scalars (few distinct digits in a window; witness vectors full of 0/1) put many points into one bucket; a
@@ -257,9 +258,9 @@ __global__ __launch_bounds__(256) void k_heavy_sum(const AffineT<F> *__restrict_
   const size_t w = b / nbs;
   const uint32_t *idx = sorted + w * n + offsets[b];
   const uint32_t cnt = counts[b];
-  JacT<F> acc = bls::jac_inf<F>();
-  for (uint32_t t = threadIdx.x; t < cnt; t += HEAVY_LANES<F>) acc = bls::jac_add_mixed(acc, entry_point(pts, idx[t]));
-  part[threadIdx.x] = acc;
+  bls::XyzzT<F> acc = bls::xyzz_inf<F>();
+  for (uint32_t t = threadIdx.x; t < cnt; t += HEAVY_LANES<F>) acc = bls::xyzz_add_mixed(acc, entry_point(pts, idx[t]));
+  part[threadIdx.x] = bls::xyzz_to_jac(acc);
   __syncthreads();
   for (int half = HEAVY_LANES<F> / 2; half >= 1; half >>= 1) {
     if ((int)threadIdx.x < half) part[threadIdx.x] = bls::jac_add(part[threadIdx.x], part[threadIdx.x + half]);
