@@ -106,7 +106,41 @@ __host__ __device__ __attribute__((noinline)) inline Fp fp_mul(Fp a, Fp b) {  //
   fp_cond_sub_p(r);
   return r;
 }
-GL_HD Fp fp_sqr(const Fp &a) { return fp_mul(a, a); }
+// Montgomery square: the same column scan with every cross product a_i a_j (i < j) computed once and doubled —
+// 105 + 196 multiply-adds instead of 196 + 196. Not inlined, for the same reason.
+__host__ __device__ __attribute__((noinline)) inline Fp fp_sqr_mont(Fp a) {
+  uint32_t m[NL];
+  Fp r;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+    uint64_t x = 0;  // cross products of the column: at most 7 x 2^56
+#pragma unroll
+    for (int i = 0; 2 * i < k; i++) x += (uint64_t)a.l[i] * a.l[k - i];
+    acc += x << 1;
+    if (k % 2 == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * BLS_P[k - i];
+    m[k] = ((uint32_t)acc * BLS_N0) & LM;
+    acc += (uint64_t)m[k] * BLS_P[0];
+    acc >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL; k++) {
+    uint64_t x = 0;
+#pragma unroll
+    for (int i = k - NL + 1; 2 * i < k; i++) x += (uint64_t)a.l[i] * a.l[k - i];
+    acc += x << 1;
+    if (k % 2 == 0 && k / 2 < NL) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)m[i] * BLS_P[k - i];
+    if (k - NL < NL) r.l[k - NL] = (uint32_t)acc & LM;
+    acc >>= LB;
+  }
+  fp_cond_sub_p(r);
+  return r;
+}
+GL_HD Fp fp_sqr(const Fp &a) { return fp_sqr_mont(a); }
 
 // 12 little-endian 32-bit words of a canonical value (< p)  <->  Montgomery limbs
 GL_HD Fp fp_from_canonical(const uint32_t *w) {

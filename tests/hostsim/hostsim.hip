@@ -54,13 +54,14 @@ void hs_round16(uint64_t *x, int inverse) {
 // ---- BLS12-381 (csrc/bls12_381.h) ----
 #include "../../city-rollup_amd/csrc/bls12_381.h"
 extern "C" {
-// canonical 12-word operands -> canonical (a*b mod p, a+b, a-b by op 0/1/2; 3: a^-1)
+// canonical 12-word operands -> canonical (a*b mod p, a+b, a-b by op 0/1/2; 3: a^-1; 4: a^2 by the dedicated square)
 void hs_bls_fp_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *out) {
   bls::Fp x = bls::fp_from_canonical(a), y = bls::fp_from_canonical(b), r;
   switch (op) {
     case 0: r = bls::fp_mul(x, y); break;
     case 1: r = bls::fp_add(x, y); break;
     case 2: r = bls::fp_sub(x, y); break;
+    case 4: r = bls::fp_sqr_mont(x); break;
     default: r = bls::fp_inv(x); break;
   }
   bls::fp_to_canonical(r, out);

@@ -151,6 +151,9 @@ def test_bls_field_ops_match_python_integers(hs):
     for a in vals[1:12]:
         hs.hs_bls_fp_op(3, _w32(a), _w32(0), out)
         assert _from_w32(out) * a % p == 1
+    for a in vals:      # the dedicated Montgomery square (doubled cross products)
+        hs.hs_bls_fp_op(4, _w32(a), _w32(0), out)
+        assert _from_w32(out) == a * a % p, hex(a)
 
 
 def test_bls_group_law_matches_oracle(hs):
