@@ -238,35 +238,63 @@ __global__ __launch_bounds__(128) void k_bucket_sum(const AffineT<F> *__restrict
   buckets[b] = bls::xyzz_to_jac(acc);
 }
 
-// Skewed scalars (few distinct digits in a window; witness vectors full of 0/1) put many points into one bucket; a
-// single lane would add them one after the other. Heavy buckets are listed here ...
-__global__ void k_heavy_list(const uint32_t *__restrict__ counts, size_t total_buckets, int hs, uint32_t *__restrict__ n_heavy,
-                             uint32_t *__restrict__ heavy) {
+// Skewed scalars (few distinct digits in a window; witness vectors full of 0 / 1: gnark witnesses are mostly bits) put
+// a large share of the points into one bucket; a single lane would add them one after the other, and a single
+// workgroup still leaves 255 CUs idle while it adds a million points. Heavy buckets are therefore cut into chunks of
+// HEAVY_CHUNK points: k_heavy_list lists the buckets and their chunks, k_heavy_sum sums one chunk per workgroup
+// (strided partial sums, then a tree in LDS), k_heavy_combine adds a bucket's chunk sums.
+constexpr uint32_t HEAVY_CHUNK = 8192;
+struct HeavyBucket { uint32_t bucket, first_chunk, n_chunks; };
+struct HeavyChunk { uint32_t bucket, first, count; };  // points [first, first + count) of the bucket's sorted range
+// head[0] = number of heavy buckets, head[1] = number of chunks (both zeroed by the host)
+__global__ void k_heavy_list(const uint32_t *__restrict__ counts, size_t total_buckets, int hs, uint32_t *__restrict__ head,
+                             HeavyBucket *__restrict__ heavy, HeavyChunk *__restrict__ chunks) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= total_buckets || counts[b] <= (HEAVY << hs)) return;
-  heavy[atomicAdd(n_heavy, 1u)] = (uint32_t)b;
-}
-// ... and each is summed by one workgroup: 256 strided partial sums, then a tree in LDS.
-template <class F>
-__global__ __launch_bounds__(256) void k_heavy_sum(const AffineT<F> *__restrict__ pts, const uint32_t *__restrict__ counts,
-                                                   const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ sorted,
-                                                   size_t n, size_t nbs, const uint32_t *__restrict__ n_heavy,
-                                                   const uint32_t *__restrict__ heavy, JacT<F> *__restrict__ buckets) {
-  __shared__ JacT<F> part[HEAVY_LANES<F>];
-  if (blockIdx.x >= *n_heavy) return;
-  const size_t b = heavy[blockIdx.x];
-  const size_t w = b / nbs;
-  const uint32_t *idx = sorted + w * n + offsets[b];
+  if (b >= total_buckets) return;
   const uint32_t cnt = counts[b];
+  if (cnt <= (HEAVY << hs)) return;
+  const uint32_t nch = (cnt + HEAVY_CHUNK - 1) / HEAVY_CHUNK, base = atomicAdd(head + 1, nch);
+  heavy[atomicAdd(head, 1u)] = {(uint32_t)b, base, nch};
+  for (uint32_t j = 0; j < nch; j++) {
+    const uint32_t first = j * HEAVY_CHUNK;
+    chunks[base + j] = {(uint32_t)b, first, cnt - first < HEAVY_CHUNK ? cnt - first : HEAVY_CHUNK};
+  }
+}
+template <class F>
+__global__ __launch_bounds__(256) void k_heavy_sum(const AffineT<F> *__restrict__ pts, const uint32_t *__restrict__ offsets,
+                                                   const uint32_t *__restrict__ sorted, size_t n, size_t nbs,
+                                                   const uint32_t *__restrict__ head, const HeavyChunk *__restrict__ chunks,
+                                                   JacT<F> *__restrict__ partial) {
+  __shared__ JacT<F> part[HEAVY_LANES<F>];
+  if (blockIdx.x >= head[1]) return;
+  const HeavyChunk ch = chunks[blockIdx.x];
+  const size_t w = ch.bucket / nbs;
+  const uint32_t *idx = sorted + w * n + offsets[ch.bucket] + ch.first;
   bls::XyzzT<F> acc = bls::xyzz_inf<F>();
-  for (uint32_t t = threadIdx.x; t < cnt; t += HEAVY_LANES<F>) acc = bls::xyzz_add_mixed(acc, entry_point(pts, idx[t]));
+  for (uint32_t t = threadIdx.x; t < ch.count; t += HEAVY_LANES<F>) acc = bls::xyzz_add_mixed(acc, entry_point(pts, idx[t]));
   part[threadIdx.x] = bls::xyzz_to_jac(acc);
   __syncthreads();
   for (int half = HEAVY_LANES<F> / 2; half >= 1; half >>= 1) {
     if ((int)threadIdx.x < half) part[threadIdx.x] = bls::jac_add(part[threadIdx.x], part[threadIdx.x + half]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) buckets[b] = part[0];
+  if (threadIdx.x == 0) partial[blockIdx.x] = part[0];
+}
+template <class F>
+__global__ __launch_bounds__(256) void k_heavy_combine(const uint32_t *__restrict__ head, const HeavyBucket *__restrict__ heavy,
+                                                       const JacT<F> *__restrict__ partial, JacT<F> *__restrict__ buckets) {
+  __shared__ JacT<F> part[HEAVY_LANES<F>];
+  if (blockIdx.x >= head[0]) return;
+  const HeavyBucket hb = heavy[blockIdx.x];
+  JacT<F> acc = bls::jac_inf<F>();
+  for (uint32_t t = threadIdx.x; t < hb.n_chunks; t += HEAVY_LANES<F>) acc = bls::jac_add(acc, partial[hb.first_chunk + t]);
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int half = HEAVY_LANES<F> / 2; half >= 1; half >>= 1) {
+    if ((int)threadIdx.x < half) part[threadIdx.x] = bls::jac_add(part[threadIdx.x], part[threadIdx.x + half]);  // idle lanes hold infinity
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) buckets[hb.bucket] = part[0];
 }
 
 // grid = (segs / 64, windows), segs = nbs / seg_len: out[w][seg] = sum_{d in run} d * B[w][d]
