@@ -1,5 +1,14 @@
-import sys, time, json
-sys.path.insert(0, '/root/repo/city-rollup_amd'); sys.path.insert(0, '/root/repo/tools')
+#!/usr/bin/env python3
+"""G1 MSM with witness-like scalars: 70 % of them in {0, 1} (gnark witnesses are mostly bits), the rest uniform — the
+ones all land in one bucket of window 0, which exercises the chunked heavy-bucket path (msm.h: k_heavy_*)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "city-rollup_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import cityprover as cp
 from bench_msm import G, R
