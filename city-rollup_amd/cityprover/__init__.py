@@ -692,6 +692,15 @@ def msm_g2(prover, scalars, points_xy, points_inf=None):
 class G2Points:
     """A fixed G2 point set resident on the device in the library's internal form."""
 
+    def __init__(self, prover, points_xy):
+        p = _as_u64(points_xy).reshape(-1, 24)
+        self.prover, self.n = prover, p.shape[0]
+        raw = prover.to_device(p)
+        self.buf = prover.alloc(self.n * G2_AFFINE_BYTES // 8)
+        prover._check(prover.lib.cp_msm_bls12381_g2_prepare_dev(prover.ctx, raw.ptr, self.n, self.buf.ptr))
+        prover.sync()
+        raw.free()
+
     @classmethod
     def synthetic(cls, prover, generator, a, b, n):
         self = cls.__new__(cls)
@@ -751,3 +760,26 @@ def groth16_quotient(prover, a, b, c):
 
 def groth16_quotient_dev(prover, a_ptr, b_ptr, c_ptr, log_n):
     prover._check(prover.lib.cp_groth16_quotient_bls12381_dev(prover.ctx, a_ptr, b_ptr, c_ptr, log_n))
+
+
+class Groth16Pk(ctypes.Structure):
+    _fields_ = [("n_wires", ctypes.c_size_t), ("n_private", ctypes.c_size_t), ("log_domain", ctypes.c_int),
+                ("a_g1", _vp), ("b_g1", _vp), ("b_g2", _vp), ("k_g1", _vp), ("z_g1", _vp), ("a_inf", _vp), ("b_inf", _vp),
+                ("alpha_g1", ctypes.c_uint64 * 12), ("beta_g1", ctypes.c_uint64 * 12), ("delta_g1", ctypes.c_uint64 * 12),
+                ("beta_g2", ctypes.c_uint64 * 24), ("delta_g2", ctypes.c_uint64 * 24)]
+
+
+ABI["cp_groth16_prove_bls12381"] = (ctypes.c_int, [_vp, ctypes.POINTER(Groth16Pk), _vp, _vp, _vp, _vp, _u64p, _u64p,
+                                                   _u64p, _u64p, _u64p])
+
+
+def groth16_prove(prover, pk, witness_ptr, a_ptr, b_ptr, c_ptr, r, s):
+    """cp_groth16_prove_bls12381: pk = Groth16Pk; device pointers; r, s ints. Returns (A, B, C) as coordinate tuples of ints:
+    A, C = (x, y); B = ((x0, x1), (y0, y1))."""
+    lim = lambda v: np.array([(int(v) >> (64 * j)) & (2**64 - 1) for j in range(4)], dtype=np.uint64)
+    oa, ob, oc = np.zeros(12, np.uint64), np.zeros(24, np.uint64), np.zeros(12, np.uint64)
+    rr, ss = lim(r), lim(s)
+    prover._check(prover.lib.cp_groth16_prove_bls12381(prover.ctx, ctypes.byref(pk), witness_ptr, a_ptr, b_ptr, c_ptr, _ptr(rr), _ptr(ss),
+                                                       _ptr(oa), _ptr(ob), _ptr(oc)))
+    val = lambda a: sum(int(v) << (64 * j) for j, v in enumerate(a))
+    return ((val(oa[:6]), val(oa[6:])), ((val(ob[:6]), val(ob[6:12])), (val(ob[12:18]), val(ob[18:]))), (val(oc[:6]), val(oc[6:])))

@@ -7,7 +7,7 @@ PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG, "csrc")
 SO = os.path.join(PKG, "libcityprover_hip.so")
 SOURCES = ["cityprover.hip"]
-HEADERS = ["gl.h", "poseidon.h", "poseidon_tables.h", "merkle.h", "ntt.h", "ntt16.h", "fri.h", "zs.h", "quotient.h", "gates.h", "prover_tail.inc", "verify.inc", "bls12_381.h", "bls12_381_tables.h", "msm.h", "msm.inc", "bls12_381_fr.h", "fr_ntt.h", "fr_ntt.inc"]
+HEADERS = ["gl.h", "poseidon.h", "poseidon_tables.h", "merkle.h", "ntt.h", "ntt16.h", "fri.h", "zs.h", "quotient.h", "gates.h", "prover_tail.inc", "verify.inc", "bls12_381.h", "bls12_381_tables.h", "msm.h", "msm.inc", "bls12_381_fr.h", "fr_ntt.h", "fr_ntt.inc", "groth16.inc"]
 
 
 def stale():

@@ -914,3 +914,4 @@ int cp_commit_dev(cp_ctx *ctx, const uint64_t *values, size_t k, int log_n, int 
 #include "msm.inc"
 #include "fr_ntt.h"
 #include "fr_ntt.inc"
+#include "groth16.inc"

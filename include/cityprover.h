@@ -363,6 +363,33 @@ int cp_groth16_quotient_bls12381_dev(cp_ctx *ctx, uint64_t *a_dev, uint64_t *b_d
 int cp_groth16_quotient_bls12381(cp_ctx *ctx, uint64_t *a_host, const uint64_t *b_host, const uint64_t *c_host,
                                  int log_n);
 
+/* ---- Groth16 proof assembly (gnark's groth16.Prove after the witness solver) ----
+ * The proving key as device-resident point sets in the library's internal form (cp_msm_bls12381_g1/g2_prepare_dev),
+ * wires ordered public first (the constant-one wire included), then private:
+ *   a_g1[i], b_g1[i], b_g2[i], i < n_wires       the A / B query ([u_i(tau)]_1, [v_i(tau)]_1, [v_i(tau)]_2)
+ *   a_inf / b_inf                                 optional device byte flags: 1 = that entry is the point at infinity
+ *   k_g1[i], i < n_private                        [(beta u_i + alpha v_i + w_i)(tau) / delta]_1 of the private wires
+ *   z_g1[j], j < 2^log_domain - 1                 [tau^j (tau^n - 1) / delta]_1
+ * and alpha, beta, delta as canonical affine coordinates. */
+typedef struct cp_groth16_pk {
+  size_t n_wires, n_private;
+  int log_domain;
+  const void *a_g1, *b_g1, *b_g2, *k_g1, *z_g1;
+  const uint8_t *a_inf, *b_inf;
+  uint64_t alpha_g1[12], beta_g1[12], delta_g1[12];
+  uint64_t beta_g2[24], delta_g2[24];
+} cp_groth16_pk;
+/* witness_dev: n_wires x 4 u64 (canonical scalars). a/b/c_evals_dev: 2^log_domain evaluations of A w, B w, C w on the
+ * domain (canonical; overwritten - see cp_groth16_quotient_bls12381_dev). r, s: the prover's blinding scalars, supplied
+ * by the caller (the RNG stays on the host side; runs are reproducible). Outputs: affine canonical A (G1), B (G2), C (G1):
+ *   A = alpha + sum w_i A_i + r delta,  B = beta + sum w_i B_i + s delta,
+ *   C = sum_private w_i K_i + sum h_j Z_j + s A + r B1 - r s delta.
+ * Five MSMs + the quotient on the device, the remaining point operations on the host. Parity unpinned by the reference
+ * (no proving key or vectors in the tree): tests check against the trapdoor of a setup they generate. */
+int cp_groth16_prove_bls12381(cp_ctx *ctx, const cp_groth16_pk *pk, const uint64_t *witness_dev, uint64_t *a_evals_dev,
+                              uint64_t *b_evals_dev, uint64_t *c_evals_dev, const uint64_t r[4], const uint64_t s[4],
+                              uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12]);
+
 #ifdef __cplusplus
 }
 #endif
