@@ -104,3 +104,25 @@ def test_groth16_proof_matches_the_trapdoor(prover, log_n, n_pub, n_in):
         d.free()
     for s in sets:
         s.free()
+
+
+def test_groth16_prove_rejects_bad_arguments(prover):
+    import cityprover as cp
+    _, r, G1 = O.bls_constants()
+    pk = cp.Groth16Pk()
+    pk.n_wires, pk.n_private, pk.log_domain = 4, 2, 2
+    d = prover.to_device(np.zeros((4, 4), np.uint64))
+    with pytest.raises(cp.CityProverError, match="NULL point set"):
+        cp.groth16_prove(prover, pk, d.ptr, d.ptr, d.ptr, d.ptr, 1, 1)
+    pts = cp.G1Points.synthetic(prover, G1, 1, 1, 4)
+    g2 = cp.G2Points.synthetic(prover, O.bls_g2_generator(), 1, 1, 4)
+    pk.a_g1 = pk.b_g1 = pk.k_g1 = pk.z_g1 = pts.buf.ptr
+    pk.b_g2 = g2.buf.ptr
+    with pytest.raises(cp.CityProverError, match="canonical"):
+        cp.groth16_prove(prover, pk, d.ptr, d.ptr, d.ptr, d.ptr, r, 1)          # r is not below the group order
+    with pytest.raises(cp.CityProverError, match="not on the curve"):
+        cp.groth16_prove(prover, pk, d.ptr, d.ptr, d.ptr, d.ptr, 1, 1)          # alpha = (0, 0)
+    pk.log_domain = 40
+    with pytest.raises(cp.CityProverError, match="log_domain"):
+        cp.groth16_prove(prover, pk, d.ptr, d.ptr, d.ptr, d.ptr, 1, 1)
+    d.free(); pts.free(); g2.free()
