@@ -254,10 +254,13 @@ def main():
         m20 = bench_msm.run(prover, 20, reps=2)
         g2 = bench_msm.run_g2(prover, 18, reps=2)
         f20 = bench_fr_ntt.run(prover, 20, reps=3)
+        import bench_groth16
+        pr20 = bench_groth16.run(prover, 20, reps=2)      # whole proof assembly: five MSMs + quotient + host part
         g16 = {"msm_g1_2^18_ms": m18["ms"], "msm_g1_2^18_checked": m18["checked"], "msm_g1_2^20_ms": m20["ms"],
                "msm_g1_2^20_Mpoints_per_s": m20["Mpoints_per_s"], "msm_g2_2^18_ms": g2["ms"],
                "msm_g2_2^18_checked": g2["checked"], "fr_ntt_2^20_forward_ms": f20["forward_ms"],
-               "fr_ntt_2^20_inverse_ms": f20["inverse_ms"], "groth16_quotient_2^20_ms": f20["groth16_quotient_ms"]}
+               "fr_ntt_2^20_inverse_ms": f20["inverse_ms"], "groth16_quotient_2^20_ms": f20["groth16_quotient_ms"],
+               "groth16_prove_2^20_ms": pr20["prove_ms"]}
 
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
