@@ -292,3 +292,28 @@ def test_internal_lanes_give_the_same_bytes(prover):
             c.close()
     finally:
         p2.close()
+
+
+def test_internal_lanes_zero_knowledge(prover):
+    """The split path of cp_prove_batch_zk_host (salts travel with their part of the batch): same bytes as unsplit."""
+    import cityprover as cp
+    from test_oracle_full import zk_case
+    p2 = cp.Prover(0)
+    try:
+        cases = [zk_case(seed=170 + i, db=6) for i in range(3)]
+        sh = cp_shape_of(cp, cases[0]["shape"])
+        circs = []
+        for i, c in enumerate(cases):
+            circ = cp.Circuit(p2, sh, [i, 8, 8, 8], c["cs_values"])
+            cp.set_gates(circ, c["gate_list"], 1)
+            circs.append(circ)
+        pick = [i % 3 for i in range(9)]
+        args = ([circs[i] for i in pick], [cases[i]["public_inputs"] for i in pick], [cases[i]["wires"] for i in pick],
+                [cases[i]["salts"] for i in pick])
+        want = cp.prove_batch_zk(p2, *args)
+        p2.set_lanes(2)
+        assert cp.prove_batch_zk(p2, *args) == want
+        for c in circs:
+            c.close()
+    finally:
+        p2.close()
