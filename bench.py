@@ -86,7 +86,7 @@ def cpu_port_proof(prover, cores):
     import bench_prove
     import cityprover as cp
     c = bench_prove.cases_for(prover, 4, bench_prove.POSEIDON_FRACTION)[0]
-    sh = cp.standard_recursion_shape(num_constants=c["num_constants"])
+    sh = cp.standard_recursion_shape(num_constants=c["num_constants"], num_public_inputs=len(c["public_inputs"]))
     osh = O.standard_shape(num_constants=c["num_constants"])
     og = O.make_gates(c["gate_list"], c["num_selectors"], c["k_is"])
     digest = [0, 1, 2, 3]
@@ -119,6 +119,27 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-qbench", action="store_true", help="skip the proofs/s side measurement")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: this process starts N ranks of itself (one per GPU) before anything
+    # here touches the GPU, passes rank 0's JSON line through and fails when any rank fails. Under torchrun
+    # (WORLD_SIZE set) the flag must agree with the launcher.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        codes = [pr.wait() for pr in procs]
+        if any(codes):
+            sys.exit("bench.py: rank exit codes %s" % codes)
+        return
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
 
     import cityprover as cp
     from cityprover import dist as D

@@ -24,6 +24,7 @@ _vp = ctypes.c_void_p
 ABI = {
     "cp_abi_version": (ctypes.c_int, []),
     "cp_device_count": (ctypes.c_int, []),
+    "cp_fault_inject": (ctypes.c_int, [ctypes.c_int, ctypes.c_long]),
     "cp_ctx_create": (_vp, [ctypes.c_int]),
     "cp_ctx_destroy": (None, [_vp]),
     "cp_ctx_set_lanes": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -338,7 +339,8 @@ class Shape(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "degree_bits", "num_constants", "num_routed_wires", "num_wires", "num_challenges",
         "num_partial_products", "quotient_degree_factor", "rate_bits", "cap_height", "pow_bits",
-        "num_query_rounds", "n_arity")] + [("arity_bits", ctypes.c_int * 8), ("zero_knowledge", ctypes.c_int)]
+        "num_query_rounds", "n_arity")] + [("arity_bits", ctypes.c_int * 8), ("zero_knowledge", ctypes.c_int),
+                                            ("num_public_inputs", ctypes.c_int)]
 
 
 SALT_SIZE = 4
@@ -349,7 +351,7 @@ def standard_recursion_shape(**over):
     circuits use (SURVEY.md §5 'Config / flags', Appendix A)."""
     d = dict(degree_bits=12, num_constants=5, num_routed_wires=80, num_wires=135, num_challenges=2,
              num_partial_products=9, quotient_degree_factor=8, rate_bits=3, cap_height=4, pow_bits=16,
-             num_query_rounds=28, arity_bits=(4, 4), zero_knowledge=0)
+             num_query_rounds=28, arity_bits=(4, 4), zero_knowledge=0, num_public_inputs=0)
     d.update(over)
     ab = d.pop("arity_bits")
     s = Shape(**d, n_arity=len(ab))
@@ -783,3 +785,84 @@ def groth16_prove(prover, pk, witness_ptr, a_ptr, b_ptr, c_ptr, r, s):
                                                        _ptr(oa), _ptr(ob), _ptr(oc)))
     val = lambda a: sum(int(v) << (64 * j) for j, v in enumerate(a))
     return ((val(oa[:6]), val(oa[6:])), ((val(ob[:6]), val(ob[6:12])), (val(ob[12:18]), val(ob[18:]))), (val(oc[:6]), val(oc[6:])))
+
+
+# ---- circuit files (N1) and the stored Groth16 proof form ----
+ABI["cp_circuit_load_file"] = (_vp, [_vp, ctypes.c_char_p])
+ABI["cp_circuit_save_file"] = (ctypes.c_int, [_vp, ctypes.c_char_p])
+ABI["cp_circuit_file_info"] = (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Shape), _u64p, ctypes.POINTER(ctypes.c_size_t),
+                                              ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint)])
+ABI["cp_circuit_set_public_input_targets"] = (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t])
+ABI["cp_circuit_public_inputs_from_wires"] = (ctypes.c_int, [_vp, _u64p, _u64p])
+ABI["cp_circuit_shape"] = (ctypes.c_int, [_vp, ctypes.POINTER(Shape), _u64p])
+ABI["cp_groth16_proof_pack_city"] = (ctypes.c_int, [_u64p, _u64p, _u64p, _u8p])
+ABI["cp_groth16_proof_unpack_city"] = (ctypes.c_int, [_u8p, _u64p, _u64p, _u64p])
+
+
+def circuit_file_info(path):
+    """cp_circuit_file_info: parse + validate a .cpcirc file on the host (no GPU). Returns a dict; raises on a bad file."""
+    lib = load_library()
+    sh, dg = Shape(), np.zeros(4, np.uint64)
+    ng, ns, fl = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_uint()
+    rc = lib.cp_circuit_file_info(os.fsencode(path), ctypes.byref(sh), _ptr(dg), ctypes.byref(ng), ctypes.byref(ns), ctypes.byref(fl))
+    if rc != 0:
+        raise CityProverError(f"[{rc}] " + lib.cp_last_error(None).decode())
+    return dict(shape=sh, digest=[int(x) for x in dg], n_gates=ng.value, num_selectors=ns.value, flags=fl.value)
+
+
+def load_circuit_file(prover, path):
+    """cp_circuit_load_file -> Circuit"""
+    h = prover.lib.cp_circuit_load_file(prover.ctx, os.fsencode(path))
+    if not h:
+        raise CityProverError(prover.lib.cp_last_error(prover.ctx).decode())
+    c = Circuit.__new__(Circuit)
+    c.prover, c.handle, c.shape = prover, h, Shape()
+    prover._check(prover.lib.cp_circuit_shape(h, ctypes.byref(c.shape), None))
+    return c
+
+
+def save_circuit_file(circuit, path):
+    circuit.prover._check(circuit.prover.lib.cp_circuit_save_file(circuit.handle, os.fsencode(path)))
+
+
+def set_public_input_targets(circuit, row_wire_pairs):
+    t = np.ascontiguousarray(np.asarray(row_wire_pairs, dtype=np.uint32).reshape(-1, 2))
+    circuit.prover._check(circuit.prover.lib.cp_circuit_set_public_input_targets(
+        circuit.handle, t.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), t.shape[0]))
+
+
+def public_inputs_from_wires(circuit, wires):
+    w = _as_u64(wires)
+    out = np.zeros(circuit.shape.num_public_inputs, np.uint64)
+    circuit.prover._check(circuit.prover.lib.cp_circuit_public_inputs_from_wires(circuit.handle, _ptr(w), _ptr(out) if out.size else None))
+    return out
+
+
+def _limbs6(v):
+    return [(int(v) >> (64 * i)) & (2**64 - 1) for i in range(6)]
+
+
+def groth16_pack_city(A, B, C):
+    """(A, B, C) as groth16_prove returns them -> the 192 bytes of CityGroth16ProofData (pi_a | pi_b_a0 | pi_b_a1 | pi_c)."""
+    lib = load_library()
+    a = np.array(_limbs6(A[0]) + _limbs6(A[1]), dtype=np.uint64)
+    b = np.array(_limbs6(B[0][0]) + _limbs6(B[0][1]) + _limbs6(B[1][0]) + _limbs6(B[1][1]), dtype=np.uint64)
+    c = np.array(_limbs6(C[0]) + _limbs6(C[1]), dtype=np.uint64)
+    out = np.zeros(192, np.uint8)
+    rc = lib.cp_groth16_proof_pack_city(_ptr(a), _ptr(b), _ptr(c), out.ctypes.data_as(_u8p))
+    if rc != 0:
+        raise CityProverError(f"[{rc}] " + lib.cp_last_error(None).decode())
+    return out.tobytes()
+
+
+def groth16_unpack_city(data):
+    lib = load_library()
+    buf = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+    if buf.size != 192:
+        raise ValueError("CityGroth16ProofData is 192 bytes")
+    a, b, c = np.zeros(12, np.uint64), np.zeros(24, np.uint64), np.zeros(12, np.uint64)
+    rc = lib.cp_groth16_proof_unpack_city(buf.ctypes.data_as(_u8p), _ptr(a), _ptr(b), _ptr(c))
+    if rc != 0:
+        raise CityProverError(f"[{rc}] " + lib.cp_last_error(None).decode())
+    val = lambda x: sum(int(v) << (64 * j) for j, v in enumerate(x))
+    return ((val(a[:6]), val(a[6:])), ((val(b[:6]), val(b[6:12])), (val(b[12:18]), val(b[18:]))), (val(c[:6]), val(c[6:])))

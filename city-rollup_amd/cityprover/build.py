@@ -1,22 +1,43 @@
-"""Build libcityprover_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libcityprover_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU). The library is several
+translation units (csrc/*.hip) compiled in parallel and linked into one shared object."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG, "csrc")
 SO = os.path.join(PKG, "libcityprover_hip.so")
-SOURCES = ["cityprover.hip"]
-HEADERS = ["gl.h", "poseidon.h", "poseidon_tables.h", "merkle.h", "ntt.h", "ntt16.h", "fri.h", "zs.h", "quotient.h", "gates.h", "prover_tail.inc", "verify.inc", "bls12_381.h", "bls12_381_tables.h", "msm.h", "msm.inc", "bls12_381_fr.h", "fr_ntt.h", "fr_ntt.inc", "groth16.inc"]
+OBJ = os.path.join(PKG, "build")
+# translation unit -> the headers it includes (core.h and its own includes are shared by all)
+COMMON = ["core.h", "gl.h", "host_util.h"]
+UNITS = {
+    "cityprover.hip": ["poseidon.h", "poseidon_tables.h", "merkle.h", "ntt.h", "ntt16.h", "fri.h", "zs.h", "quotient.h", "gates.h",
+                       "prover_tail.inc", "verify.inc", "circuit_file.inc"],
+    "bls.hip": ["bls12_381.h", "bls12_381_tables.h", "msm.h", "msm.inc", "bls12_381_fr.h", "fr_ntt.h", "fr_ntt.inc", "groth16.inc",
+                "groth16_pack.inc"],
+}
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-function"]
+
+
+def _mtime(path):
+    return os.path.getmtime(path) if os.path.exists(path) else 0.0
+
+
+def _unit_stale(unit):
+    obj = os.path.join(OBJ, unit + ".o")
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [os.path.join(CSRC, f) for f in [unit] + COMMON + UNITS[unit]]
+    deps.append(os.path.join(os.path.dirname(PKG), "include", "cityprover.h"))
+    return any(_mtime(d) > t for d in deps)
 
 
 def stale():
     if not os.path.exists(SO):
         return True
-    t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    deps.append(os.path.join(os.path.dirname(PKG), "include", "cityprover.h"))
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return any(_unit_stale(u) or _mtime(os.path.join(OBJ, u + ".o")) > os.path.getmtime(SO) for u in UNITS)
 
 
 def build(force=False, verbose=False):
@@ -25,9 +46,25 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    tmp = "%s.%d.tmp" % (SO, os.getpid())   # several ranks may build at once: private name, atomic rename
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ, exist_ok=True)
+    pid = os.getpid()   # several ranks may build at once: private names, atomic renames
+
+    def compile_unit(unit):
+        obj = os.path.join(OBJ, unit + ".o")
+        if not force and not _unit_stale(unit):
+            return obj
+        tmp = "%s.%d.tmp" % (obj, pid)
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, unit), "-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, obj)
+        return obj
+
+    with ThreadPoolExecutor(len(UNITS)) as ex:
+        objs = list(ex.map(compile_unit, UNITS))
+    tmp = "%s.%d.tmp" % (SO, pid)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

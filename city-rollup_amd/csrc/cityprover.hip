@@ -1,228 +1,12 @@
 // libcityprover_hip.so — C ABI (include/cityprover.h) over the gfx950 kernels.
 // No CPU fallback: every compute entry point needs a live HIP device and fails loudly without one.
-#include <hip/hip_runtime.h>
-
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <chrono>
-#include <map>
-#include <mutex>
-#include <new>
-#include <string>
-#include <thread>
-#include <tuple>
-#include <vector>
-
-#include "../../include/cityprover.h"
-#include "gl.h"
+#include "core.h"
 #include "merkle.h"
 #include "ntt.h"
 #include "ntt16.h"
 #include "poseidon.h"
 
 namespace {
-
-thread_local std::string g_tls_error = "";
-
-struct PowTable {
-  uint64_t *dev = nullptr;  // 3 x 2048
-};
-
-}  // namespace
-
-struct cp_ctx {
-  int device = -1;
-  hipStream_t stream = nullptr;
-  std::string error;
-  // cp_ctx_set_lanes: child contexts (own stream, arena, staging) among which ONE cp_prove_batch_host call is split, so
-  // that a single-threaded caller gets the overlap of host phases and small kernels that several contexts give
-  cp_ctx *parent = nullptr;
-  std::vector<cp_ctx *> lanes;
-  int n_lanes = 1;
-  std::map<uint64_t, PowTable> pow_tables;  // keyed by base
-  struct PreKey { int log_n, rate_bits; uint64_t shift; bool operator<(const PreKey &o) const {
-    return std::tie(log_n, rate_bits, shift) < std::tie(o.log_n, o.rate_bits, o.shift); } };
-  std::map<PreKey, uint64_t *> prescale_tables;  // LDE pre-scale tables [2^rate_bits][n]
-  // scratch buffer reused by natural-order NTT epilogues / merkle host paths
-  void *scratch = nullptr;
-  size_t scratch_bytes = 0;
-  // page-locked host staging for the small transfers of a proving call (caps, challenges, openings, query words):
-  // pageable copies block inside the runtime and serialise the contexts of a process
-  char *pin = nullptr;
-  size_t pin_bytes = 0, pin_off = 0;
-  // BLS12-381 F_r twiddle tables (fr_ntt.inc), keyed by (log_n, inverse)
-  std::map<std::pair<int, int>, void *> fr_twiddles;
-  void *fr_work = nullptr;  // grow-only work array of the F_r NTT
-  size_t fr_work_bytes = 0;
-  struct FrPowers {         // cached coset power table s^i, i < 2^log_n (Groth16 always asks for the same two)
-    void *tab = nullptr;
-    size_t bytes = 0;
-    int log_n = -1;
-    uint64_t shift[4] = {0, 0, 0, 0};
-  } fr_pow[2];              // [0]: forward (powers of the shift), [1]: inverse (powers of its inverse)
-  void *msm_ws = nullptr;  // grow-only workspace of the MSMs (counts, sorted indices, buckets)
-  size_t msm_ws_bytes = 0;
-  // device staging buffer for wire matrices that arrive in host memory (cp_prove / cp_prove_batch_host)
-  uint64_t *wires_stage = nullptr;
-  size_t wires_stage_bytes = 0;
-  // per-proof workspace arena (prover_tail.inc): chunks survive between proofs
-  struct Arena {
-    std::vector<std::pair<char *, size_t>> chunks;
-    size_t cur = 0, off = 0, used = 0;
-  } arena;
-  // optional per-kernel hipEvent timing (cp_profile_begin / cp_profile_end)
-  bool profiling = false;
-  struct ProfRec { const char *name; hipEvent_t e0, e1; };
-  std::vector<ProfRec> prof_recs;
-  std::vector<hipEvent_t> prof_pool;
-  std::map<std::string, std::pair<uint64_t, double>> prof_acc;  // name -> (launches, total ms)
-  // host-side phase clock (profiling only): wall time per phase of a proving call and the part of it spent
-  // blocked on the stream, reported as "host:<phase>" / "wait:<phase>"
-  const char *phase_name = nullptr;
-  double phase_t0 = 0, phase_wait = 0;
-};
-
-namespace {
-
-int set_error(cp_ctx *ctx, int code, const char *fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  g_tls_error = buf;
-  if (ctx) ctx->error = buf;
-  return code;
-}
-
-#define HIP_TRY(ctx, expr)                                                                  \
-  do {                                                                                      \
-    hipError_t e__ = (expr);                                                                \
-    if (e__ != hipSuccess)                                                                  \
-      return set_error(ctx, e__ == hipErrorOutOfMemory ? CP_ERR_OOM : CP_ERR_HIP,           \
-                       "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,    \
-                       __LINE__);                                                           \
-  } while (0)
-
-#define CP_TRY(expr)              \
-  do {                            \
-    int rc__ = (expr);            \
-    if (rc__ != CP_OK) return rc__; \
-  } while (0)
-
-#define CHECK_CTX(ctx)                                                          \
-  do {                                                                          \
-    if (!(ctx)) return set_error(nullptr, CP_ERR_INVALID_ARG, "ctx is NULL");   \
-    hipError_t e__ = hipSetDevice((ctx)->device);                               \
-    if (e__ != hipSuccess)                                                      \
-      return set_error(ctx, CP_ERR_HIP, "hipSetDevice(%d): %s", (ctx)->device,  \
-                       hipGetErrorString(e__));                                 \
-  } while (0)
-
-int ensure_scratch(cp_ctx *ctx, size_t bytes) {
-  if (ctx->scratch_bytes >= bytes) return CP_OK;
-  if (ctx->scratch) {
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipFree(ctx->scratch));
-    ctx->scratch = nullptr;
-    ctx->scratch_bytes = 0;
-  }
-  HIP_TRY(ctx, hipMalloc(&ctx->scratch, bytes));
-  ctx->scratch_bytes = bytes;
-  return CP_OK;
-}
-
-hipEvent_t prof_event(cp_ctx *ctx) {
-  if (!ctx->prof_pool.empty()) {
-    hipEvent_t e = ctx->prof_pool.back();
-    ctx->prof_pool.pop_back();
-    return e;
-  }
-  hipEvent_t e = nullptr;
-  (void)hipEventCreate(&e);
-  return e;
-}
-void prof_flush(cp_ctx *ctx) {
-  for (auto &r : ctx->prof_recs) {
-    float ms = 0.f;
-    if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
-      auto &acc = ctx->prof_acc[r.name];
-      acc.first += 1;
-      acc.second += ms;
-    }
-    ctx->prof_pool.push_back(r.e0);
-    ctx->prof_pool.push_back(r.e1);
-  }
-  ctx->prof_recs.clear();
-}
-
-// Per-proof host work of a batch (the Fiat-Shamir transcripts are independent across proofs): run body(p) for
-// p < n on a few short-lived threads. The body must not touch the HIP API or the context.
-template <class Body>
-void host_for(size_t n, Body body) {
-  unsigned hw = std::thread::hardware_concurrency();
-  size_t T = n / 4;  // at least four proofs per thread
-  if (T > 8) T = 8;
-  if (hw && T > hw) T = hw;
-  if (T <= 1) {
-    for (size_t p = 0; p < n; p++) body(p);
-    return;
-  }
-  std::vector<std::thread> ths;
-  ths.reserve(T - 1);
-  for (size_t t = 1; t < T; t++)
-    ths.emplace_back([=, &body] { for (size_t p = t; p < n; p += T) body(p); });
-  for (size_t p = 0; p < n; p += T) body(p);
-  for (auto &th : ths) th.join();
-}
-
-double host_now_ms() {
-  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-// closes the running host phase (if any) and opens `name` (nullptr: none)
-void host_phase(cp_ctx *ctx, const char *name) {
-  if (!ctx->profiling) { ctx->phase_name = nullptr; return; }
-  const double t = host_now_ms();
-  if (ctx->phase_name) {
-    auto &a = ctx->prof_acc[std::string("host:") + ctx->phase_name];
-    a.first += 1;
-    a.second += t - ctx->phase_t0;
-    auto &w = ctx->prof_acc[std::string("wait:") + ctx->phase_name];
-    w.first += 1;
-    w.second += ctx->phase_wait;
-  }
-  ctx->phase_name = name;
-  ctx->phase_t0 = t;
-  ctx->phase_wait = 0;
-}
-// hipStreamSynchronize on the context stream, accounted to the running host phase
-hipError_t sync_stream(cp_ctx *ctx) {
-  if (!ctx->profiling) return hipStreamSynchronize(ctx->stream);
-  const double t = host_now_ms();
-  hipError_t e = hipStreamSynchronize(ctx->stream);
-  ctx->phase_wait += host_now_ms() - t;
-  return e;
-}
-
-// Launch `kernel` on the context stream; when profiling is on, bracket it with HIP events.
-#define LAUNCH(ctx, name, kernel, grid, block, ...)                                      \
-  do {                                                                                   \
-    cp_ctx::ProfRec pr__{name, nullptr, nullptr};                                        \
-    if ((ctx)->profiling) {                                                              \
-      if ((ctx)->prof_recs.size() >= 8192) prof_flush(ctx);                              \
-      pr__.e0 = prof_event(ctx);                                                         \
-      pr__.e1 = prof_event(ctx);                                                         \
-      (void)hipEventRecord(pr__.e0, (ctx)->stream);                                      \
-    }                                                                                    \
-    hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);              \
-    if ((ctx)->profiling) {                                                              \
-      (void)hipEventRecord(pr__.e1, (ctx)->stream);                                      \
-      (ctx)->prof_recs.push_back(pr__);                                                  \
-    }                                                                                    \
-    HIP_TRY(ctx, hipGetLastError());                                                     \
-  } while (0)
 
 // 3-level power table of `base`, cached per ctx
 int get_pow_table(cp_ctx *ctx, uint64_t base, const uint64_t **out) {
@@ -283,7 +67,6 @@ int upload_constants(cp_ctx *ctx) {
   return CP_OK;
 }
 
-inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
 
 // ---- NTT driver ---------------------------------------------------------------------------
 
@@ -454,6 +237,12 @@ extern "C" {
 
 int cp_abi_version(void) { return CP_ABI_VERSION; }
 
+int cp_fault_inject(int kind, long after) {
+  if (kind != CP_FAULT_THREAD && kind != CP_FAULT_ALLOC) return set_error(nullptr, CP_ERR_INVALID_ARG, "unknown fault kind %d", kind);
+  hostu::fault_counter(kind).store(after < 0 ? -1 : after);
+  return CP_OK;
+}
+
 int cp_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -462,7 +251,7 @@ int cp_device_count(void) {
 
 const char *cp_last_error(cp_ctx *ctx) { return ctx ? ctx->error.c_str() : g_tls_error.c_str(); }
 
-cp_ctx *cp_ctx_create(int device) {
+cp_ctx *cp_ctx_create(int device) try {
   int n = cp_device_count();
   if (n <= 0) {
     set_error(nullptr, CP_ERR_NO_DEVICE,
@@ -496,6 +285,9 @@ cp_ctx *cp_ctx_create(int device) {
     return nullptr;
   }
   return ctx;
+} catch (...) {
+  exception_status(nullptr);
+  return nullptr;
 }
 
 void cp_ctx_destroy(cp_ctx *ctx) {
@@ -508,6 +300,7 @@ void cp_ctx_destroy(cp_ctx *ctx) {
   for (auto e : ctx->prof_pool) hipEventDestroy(e);
   for (auto &kv : ctx->pow_tables) hipFree(kv.second.dev);
   for (auto &kv : ctx->prescale_tables) hipFree(kv.second);
+  for (auto &kv : ctx->l0_tables) hipFree(kv.second);
   for (auto &ch : ctx->arena.chunks) hipFree(ch.first);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->wires_stage) hipFree(ctx->wires_stage);
@@ -521,7 +314,7 @@ void cp_ctx_destroy(cp_ctx *ctx) {
   delete ctx;
 }
 
-int cp_ctx_set_lanes(cp_ctx *ctx, int lanes) {
+int cp_ctx_set_lanes(cp_ctx *ctx, int lanes) try {
   CHECK_CTX(ctx);
   if (ctx->parent) return set_error(ctx, CP_ERR_INVALID_ARG, "a lane has no lanes of its own");
   if (lanes < 1 || lanes > 8) return set_error(ctx, CP_ERR_INVALID_ARG, "lanes must be 1..8 (got %d)", lanes);
@@ -533,101 +326,101 @@ int cp_ctx_set_lanes(cp_ctx *ctx, int lanes) {
   }
   ctx->n_lanes = lanes;
   return CP_OK;
-}
+} CP_CATCH(ctx)
 
-int cp_dev_alloc(cp_ctx *ctx, size_t bytes, void **out) {
+int cp_dev_alloc(cp_ctx *ctx, size_t bytes, void **out) try {
   CHECK_CTX(ctx);
   if (!out) return set_error(ctx, CP_ERR_INVALID_ARG, "out is NULL");
   *out = nullptr;
   if (bytes == 0) return CP_OK;
   HIP_TRY(ctx, hipMalloc(out, bytes));
   return CP_OK;
-}
-int cp_dev_free(cp_ctx *ctx, void *ptr) {
+} CP_CATCH(ctx)
+int cp_dev_free(cp_ctx *ctx, void *ptr) try {
   CHECK_CTX(ctx);
   if (!ptr) return CP_OK;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipFree(ptr));
   return CP_OK;
-}
-int cp_host_alloc(cp_ctx *ctx, size_t bytes, void **out) {
+} CP_CATCH(ctx)
+int cp_host_alloc(cp_ctx *ctx, size_t bytes, void **out) try {
   CHECK_CTX(ctx);
   if (!out) return set_error(ctx, CP_ERR_INVALID_ARG, "out is NULL");
   *out = nullptr;
   if (bytes == 0) return CP_OK;
   if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) { *out = nullptr; return set_error(ctx, CP_ERR_OOM, "hipHostMalloc of %zu bytes failed", bytes); }
   return CP_OK;
-}
-int cp_host_free(cp_ctx *ctx, void *ptr) {
+} CP_CATCH(ctx)
+int cp_host_free(cp_ctx *ctx, void *ptr) try {
   CHECK_CTX(ctx);
   if (!ptr) return CP_OK;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipHostFree(ptr));
   return CP_OK;
-}
-int cp_h2d(cp_ctx *ctx, void *dst, const void *src, size_t bytes) {
+} CP_CATCH(ctx)
+int cp_h2d(cp_ctx *ctx, void *dst, const void *src, size_t bytes) try {
   CHECK_CTX(ctx);
   if (bytes == 0) return CP_OK;
   if (!dst || !src) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
   HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return CP_OK;
-}
-int cp_d2h(cp_ctx *ctx, void *dst, const void *src, size_t bytes) {
+} CP_CATCH(ctx)
+int cp_d2h(cp_ctx *ctx, void *dst, const void *src, size_t bytes) try {
   CHECK_CTX(ctx);
   if (bytes == 0) return CP_OK;
   if (!dst || !src) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
   HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return CP_OK;
-}
-int cp_d2d(cp_ctx *ctx, void *dst, const void *src, size_t bytes) {
+} CP_CATCH(ctx)
+int cp_d2d(cp_ctx *ctx, void *dst, const void *src, size_t bytes) try {
   CHECK_CTX(ctx);
   if (bytes == 0) return CP_OK;
   if (!dst || !src) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
   HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return CP_OK;
-}
-int cp_sync(cp_ctx *ctx) {
+} CP_CATCH(ctx)
+int cp_sync(cp_ctx *ctx) try {
   CHECK_CTX(ctx);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return CP_OK;
-}
-int cp_event_create(cp_ctx *ctx, void **event_out) {
+} CP_CATCH(ctx)
+int cp_event_create(cp_ctx *ctx, void **event_out) try {
   CHECK_CTX(ctx);
   if (!event_out) return set_error(ctx, CP_ERR_INVALID_ARG, "event_out is NULL");
   hipEvent_t ev;
   HIP_TRY(ctx, hipEventCreate(&ev));
   *event_out = (void *)ev;
   return CP_OK;
-}
-int cp_event_destroy(cp_ctx *ctx, void *event) {
+} CP_CATCH(ctx)
+int cp_event_destroy(cp_ctx *ctx, void *event) try {
   CHECK_CTX(ctx);
   if (event) HIP_TRY(ctx, hipEventDestroy((hipEvent_t)event));
   return CP_OK;
-}
-int cp_event_record(cp_ctx *ctx, void *event) {
+} CP_CATCH(ctx)
+int cp_event_record(cp_ctx *ctx, void *event) try {
   CHECK_CTX(ctx);
   if (!event) return set_error(ctx, CP_ERR_INVALID_ARG, "event is NULL");
   HIP_TRY(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
   return CP_OK;
-}
-int cp_event_elapsed_ms(cp_ctx *ctx, void *start, void *stop, float *ms_out) {
+} CP_CATCH(ctx)
+int cp_event_elapsed_ms(cp_ctx *ctx, void *start, void *stop, float *ms_out) try {
   CHECK_CTX(ctx);
   if (!start || !stop || !ms_out) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL argument");
   HIP_TRY(ctx, hipEventSynchronize((hipEvent_t)stop));
   HIP_TRY(ctx, hipEventElapsedTime(ms_out, (hipEvent_t)start, (hipEvent_t)stop));
   return CP_OK;
-}
+} CP_CATCH(ctx)
 
-int cp_profile_begin(cp_ctx *ctx) {
+int cp_profile_begin(cp_ctx *ctx) try {
   CHECK_CTX(ctx);
   prof_flush(ctx);
   ctx->prof_acc.clear();
   ctx->profiling = true;
   return CP_OK;
-}
-int cp_profile_end(cp_ctx *ctx, char *json_out, size_t cap) {
+} CP_CATCH(ctx)
+int cp_profile_end(cp_ctx *ctx, char *json_out, size_t cap) try {
   CHECK_CTX(ctx);
   ctx->profiling = false;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -647,12 +440,12 @@ int cp_profile_end(cp_ctx *ctx, char *json_out, size_t cap) {
     memcpy(json_out, js.c_str(), js.size() + 1);
   }
   return CP_OK;
-}
+} CP_CATCH(ctx)
 
 // ---- NTT ------------------------------------------------------------------------------------
 
 int cp_ntt_dev(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stride, unsigned flags,
-               uint64_t coset_shift) {
+               uint64_t coset_shift) try {
   CHECK_CTX(ctx);
   if (batch == 0) return CP_OK;
   if (!data) return set_error(ctx, CP_ERR_INVALID_ARG, "data is NULL");
@@ -700,10 +493,10 @@ int cp_ntt_dev(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stri
     return set_error(ctx, CP_ERR_UNSUPPORTED, "inverse coset NTT with bit-reversed output is not supported");
   }
   return CP_OK;
-}
+} CP_CATCH(ctx)
 
 int cp_ntt(cp_ctx *ctx, uint64_t *data_host, int log_n, size_t batch, unsigned flags,
-           uint64_t coset_shift) {
+           uint64_t coset_shift) try {
   CHECK_CTX(ctx);
   if (batch == 0) return CP_OK;
   if (!data_host) return set_error(ctx, CP_ERR_INVALID_ARG, "data is NULL");
@@ -717,10 +510,10 @@ int cp_ntt(cp_ctx *ctx, uint64_t *data_host, int log_n, size_t batch, unsigned f
   hipStreamSynchronize(ctx->stream);
   hipFree(d);
   return rc;
-}
+} CP_CATCH(ctx)
 
 int cp_lde_dev(cp_ctx *ctx, const uint64_t *coeffs, size_t in_stride, int log_n, int rate_bits,
-               size_t batch, uint64_t coset_shift, unsigned flags, uint64_t *out, size_t out_stride) {
+               size_t batch, uint64_t coset_shift, unsigned flags, uint64_t *out, size_t out_stride) try {
   CHECK_CTX(ctx);
   if (batch == 0) return CP_OK;
   if (!coeffs || !out) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
@@ -751,20 +544,20 @@ int cp_lde_dev(cp_ctx *ctx, const uint64_t *coeffs, size_t in_stride, int log_n,
   LAUNCH(ctx, "lde_pad_copy", ntt::k_pad_copy, grid, dim3(256), coeffs, out, in_stride, out_stride, n, N);
   return cp_ntt_dev(ctx, out, log_n + rate_bits, batch, out_stride,
                     (flags & CP_NTT_BITREV_OUT) | CP_NTT_COSET, coset_shift);
-}
+} CP_CATCH(ctx)
 
 // ---- Poseidon -------------------------------------------------------------------------------
 
-int cp_poseidon_permute_dev(cp_ctx *ctx, uint64_t *states, size_t count) {
+int cp_poseidon_permute_dev(cp_ctx *ctx, uint64_t *states, size_t count) try {
   CHECK_CTX(ctx);
   if (count == 0) return CP_OK;
   if (!states) return set_error(ctx, CP_ERR_INVALID_ARG, "states is NULL");
   LAUNCH(ctx, "poseidon_permute", merkle::k_permute, dim3(blocks_for(count, merkle::THREADS)),
          dim3(merkle::THREADS), states, count);
   return CP_OK;
-}
+} CP_CATCH(ctx)
 
-int cp_poseidon_permute(cp_ctx *ctx, uint64_t *states_host, size_t count) {
+int cp_poseidon_permute(cp_ctx *ctx, uint64_t *states_host, size_t count) try {
   CHECK_CTX(ctx);
   if (count == 0) return CP_OK;
   if (!states_host) return set_error(ctx, CP_ERR_INVALID_ARG, "states is NULL");
@@ -773,10 +566,10 @@ int cp_poseidon_permute(cp_ctx *ctx, uint64_t *states_host, size_t count) {
   CP_TRY(cp_h2d(ctx, ctx->scratch, states_host, bytes));
   CP_TRY(cp_poseidon_permute_dev(ctx, (uint64_t *)ctx->scratch, count));
   return cp_d2h(ctx, states_host, ctx->scratch, bytes);
-}
+} CP_CATCH(ctx)
 
 int cp_hash_no_pad(cp_ctx *ctx, const uint64_t *in_host, size_t count, size_t len,
-                   uint64_t *digests_host) {
+                   uint64_t *digests_host) try {
   CHECK_CTX(ctx);
   if (count == 0) return CP_OK;
   if (!digests_host || (!in_host && len)) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
@@ -789,10 +582,10 @@ int cp_hash_no_pad(cp_ctx *ctx, const uint64_t *in_host, size_t count, size_t le
   LAUNCH(ctx, "leaf_hash_rows", merkle::k_leaf_hash_rows, dim3(blocks_for(count, merkle::THREADS)),
          dim3(merkle::THREADS), din, count, (int)len, dout, 1);
   return cp_d2h(ctx, digests_host, dout, out_bytes);
-}
+} CP_CATCH(ctx)
 
 int cp_two_to_one(cp_ctx *ctx, const uint64_t *left_host, const uint64_t *right_host, size_t count,
-                  uint64_t *out_host) {
+                  uint64_t *out_host) try {
   CHECK_CTX(ctx);
   if (count == 0) return CP_OK;
   if (!left_host || !right_host || !out_host) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
@@ -804,12 +597,12 @@ int cp_two_to_one(cp_ctx *ctx, const uint64_t *left_host, const uint64_t *right_
   LAUNCH(ctx, "two_to_one", merkle::k_two_to_one, dim3(blocks_for(count, merkle::THREADS)),
          dim3(merkle::THREADS), l, r, count, o);
   return cp_d2h(ctx, out_host, o, b);
-}
+} CP_CATCH(ctx)
 
 // ---- Merkle ---------------------------------------------------------------------------------
 
 int cp_merkle_cols_dev(cp_ctx *ctx, const uint64_t *cols, size_t n_leaves, size_t leaf_len,
-                       size_t col_stride, int cap_height, uint64_t *digests_dev, uint64_t *cap_dev) {
+                       size_t col_stride, int cap_height, uint64_t *digests_dev, uint64_t *cap_dev) try {
   CHECK_CTX(ctx);
   if (!cols || !cap_dev) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
   if (!valid_merkle_shape(n_leaves, cap_height))
@@ -820,10 +613,10 @@ int cp_merkle_cols_dev(cp_ctx *ctx, const uint64_t *cols, size_t n_leaves, size_
   size_t cap_n = (size_t)1 << cap_height;
   return merkle_cols_batch(ctx, cols, n_leaves, leaf_len, col_stride, 1, 0, cap_height,
                            (digests_dev && n_leaves > cap_n) ? digests_dev : nullptr, cap_dev);
-}
+} CP_CATCH(ctx)
 
 int cp_merkle_cap(cp_ctx *ctx, const uint64_t *rows_host, size_t n_leaves, size_t leaf_len,
-                  int cap_height, uint64_t *cap_host) {
+                  int cap_height, uint64_t *cap_host) try {
   CHECK_CTX(ctx);
   if (!rows_host || !cap_host) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
   if (!valid_merkle_shape(n_leaves, cap_height))
@@ -851,13 +644,13 @@ int cp_merkle_cap(cp_ctx *ctx, const uint64_t *rows_host, size_t n_leaves, size_
   hipFree(rows);
   hipFree(cap);
   return rc;
-}
+} CP_CATCH(ctx)
 
 // ---- commit ---------------------------------------------------------------------------------
 
 int cp_commit_batch_dev(cp_ctx *ctx, const uint64_t *values, size_t k, size_t n_trees, int log_n,
                         int rate_bits, int cap_height, uint64_t *coeffs_dev, uint64_t *lde_dev,
-                        uint64_t *digests_dev, uint64_t *caps_dev) {
+                        uint64_t *digests_dev, uint64_t *caps_dev) try {
   CHECK_CTX(ctx);
   if (!values || !lde_dev || !caps_dev) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
   if (k == 0 || n_trees == 0 || k * n_trees > 65535 || n_trees > 65535)
@@ -893,14 +686,14 @@ int cp_commit_batch_dev(cp_ctx *ctx, const uint64_t *values, size_t k, size_t n_
     hipFree(own);
   }
   return rc;
-}
+} CP_CATCH(ctx)
 
 int cp_commit_dev(cp_ctx *ctx, const uint64_t *values, size_t k, int log_n, int rate_bits,
                   int cap_height, uint64_t *coeffs_dev, uint64_t *lde_dev, uint64_t *digests_dev,
-                  uint64_t *cap_dev) {
+                  uint64_t *cap_dev) try {
   return cp_commit_batch_dev(ctx, values, k, 1, log_n, rate_bits, cap_height, coeffs_dev, lde_dev,
                              digests_dev, cap_dev);
-}
+} CP_CATCH(ctx)
 
 }  // extern "C"
 
@@ -910,8 +703,5 @@ int cp_commit_dev(cp_ctx *ctx, const uint64_t *values, size_t k, int log_n, int 
 #include "quotient.h"
 #include "prover_tail.inc"
 #include "verify.inc"
-#include "msm.h"
-#include "msm.inc"
-#include "fr_ntt.h"
-#include "fr_ntt.inc"
-#include "groth16.inc"
+#include "circuit_file.inc"
+// (the BLS12-381 / Groth16 side is its own translation unit: bls.hip)

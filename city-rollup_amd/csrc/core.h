@@ -1,0 +1,240 @@
+// Shared host-side core of libcityprover_hip.so: the context, error reporting, the launch / profiling macros. Included
+// by every translation unit of the library (cityprover.hip: Goldilocks / Plonky2 side; bls.hip: BLS12-381 / Groth16
+// side), which are compiled in parallel and linked into one shared object.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#include "../../include/cityprover.h"
+#include "gl.h"
+#include "host_util.h"
+
+inline thread_local std::string g_tls_error = "";
+
+namespace {
+
+struct PowTable {
+  uint64_t *dev = nullptr;  // 3 x 2048
+};
+
+}  // namespace
+
+struct cp_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  std::string error;
+  // cp_ctx_set_lanes: child contexts (own stream, arena, staging) among which ONE cp_prove_batch_host call is split, so
+  // that a single-threaded caller gets the overlap of host phases and small kernels that several contexts give
+  cp_ctx *parent = nullptr;
+  std::vector<cp_ctx *> lanes;
+  int n_lanes = 1;
+  std::map<uint64_t, PowTable> pow_tables;  // keyed by base
+  struct PreKey { int log_n, rate_bits; uint64_t shift; bool operator<(const PreKey &o) const {
+    return std::tie(log_n, rate_bits, shift) < std::tie(o.log_n, o.rate_bits, o.shift); } };
+  std::map<PreKey, uint64_t *> prescale_tables;  // LDE pre-scale tables [2^rate_bits][n]
+  std::map<std::pair<int, int>, uint64_t *> l0_tables;  // (degree_bits, rate_bits) -> L_0 on the LDE coset [N], storage order
+  // scratch buffer reused by natural-order NTT epilogues / merkle host paths
+  void *scratch = nullptr;
+  size_t scratch_bytes = 0;
+  // page-locked host staging for the small transfers of a proving call (caps, challenges, openings, query words):
+  // pageable copies block inside the runtime and serialise the contexts of a process
+  char *pin = nullptr;
+  size_t pin_bytes = 0, pin_off = 0;
+  // BLS12-381 F_r twiddle tables (fr_ntt.inc), keyed by (log_n, inverse)
+  std::map<std::pair<int, int>, void *> fr_twiddles;
+  void *fr_work = nullptr;  // grow-only work array of the F_r NTT
+  size_t fr_work_bytes = 0;
+  struct FrPowers {         // cached coset power table s^i, i < 2^log_n (Groth16 always asks for the same two)
+    void *tab = nullptr;
+    size_t bytes = 0;
+    int log_n = -1;
+    uint64_t shift[4] = {0, 0, 0, 0};
+  } fr_pow[2];              // [0]: forward (powers of the shift), [1]: inverse (powers of its inverse)
+  void *msm_ws = nullptr;  // grow-only workspace of the MSMs (counts, sorted indices, buckets)
+  size_t msm_ws_bytes = 0;
+  // device staging buffer for wire matrices that arrive in host memory (cp_prove / cp_prove_batch_host)
+  uint64_t *wires_stage = nullptr;
+  size_t wires_stage_bytes = 0;
+  // per-proof workspace arena (prover_tail.inc): chunks survive between proofs
+  struct Arena {
+    std::vector<std::pair<char *, size_t>> chunks;
+    size_t cur = 0, off = 0, used = 0;
+  } arena;
+  // optional per-kernel hipEvent timing (cp_profile_begin / cp_profile_end)
+  bool profiling = false;
+  struct ProfRec { const char *name; hipEvent_t e0, e1; };
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> prof_pool;
+  std::map<std::string, std::pair<uint64_t, double>> prof_acc;  // name -> (launches, total ms)
+  // host-side phase clock (profiling only): wall time per phase of a proving call and the part of it spent
+  // blocked on the stream, reported as "host:<phase>" / "wait:<phase>"
+  const char *phase_name = nullptr;
+  double phase_t0 = 0, phase_wait = 0;
+};
+
+namespace {
+
+int set_error(cp_ctx *ctx, int code, const char *fmt, ...) noexcept {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  try {  // the message is best effort: the status code is what must get out
+    g_tls_error = buf;
+    if (ctx) ctx->error = buf;
+  } catch (...) {
+  }
+  return code;
+}
+
+// Handler of the function-try-block around every extern "C" body: nothing may unwind through the C ABI into the
+// (Rust) host process. Called from inside a catch block.
+int exception_status(cp_ctx *ctx) noexcept {
+  try {
+    throw;
+  } catch (const std::bad_alloc &) {
+    return set_error(ctx, CP_ERR_OOM, "out of host memory");
+  } catch (const std::exception &e) {
+    return set_error(ctx, CP_ERR_INTERNAL, "internal error: %s", e.what());
+  } catch (...) {
+    return set_error(ctx, CP_ERR_INTERNAL, "internal error: unknown exception");
+  }
+}
+#define CP_CATCH(ctxexpr) catch (...) { return exception_status(ctxexpr); }
+
+#define HIP_TRY(ctx, expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess)                                                                  \
+      return set_error(ctx, e__ == hipErrorOutOfMemory ? CP_ERR_OOM : CP_ERR_HIP,           \
+                       "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,    \
+                       __LINE__);                                                           \
+  } while (0)
+
+inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
+
+#define CP_TRY(expr)              \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != CP_OK) return rc__; \
+  } while (0)
+
+#define CHECK_CTX(ctx)                                                          \
+  do {                                                                          \
+    if (!(ctx)) return set_error(nullptr, CP_ERR_INVALID_ARG, "ctx is NULL");   \
+    hipError_t e__ = hipSetDevice((ctx)->device);                               \
+    if (e__ != hipSuccess)                                                      \
+      return set_error(ctx, CP_ERR_HIP, "hipSetDevice(%d): %s", (ctx)->device,  \
+                       hipGetErrorString(e__));                                 \
+  } while (0)
+
+int ensure_scratch(cp_ctx *ctx, size_t bytes) {
+  if (ctx->scratch_bytes >= bytes) return CP_OK;
+  if (ctx->scratch) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+  }
+  HIP_TRY(ctx, hipMalloc(&ctx->scratch, bytes));
+  ctx->scratch_bytes = bytes;
+  return CP_OK;
+}
+
+hipEvent_t prof_event(cp_ctx *ctx) {
+  if (!ctx->prof_pool.empty()) {
+    hipEvent_t e = ctx->prof_pool.back();
+    ctx->prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void prof_flush(cp_ctx *ctx) {
+  for (auto &r : ctx->prof_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      auto &acc = ctx->prof_acc[r.name];
+      acc.first += 1;
+      acc.second += ms;
+    }
+    ctx->prof_pool.push_back(r.e0);
+    ctx->prof_pool.push_back(r.e1);
+  }
+  ctx->prof_recs.clear();
+}
+
+// Per-proof host work of a batch (the Fiat-Shamir transcripts are independent across proofs): run body(p) for
+// p < n on a few short-lived threads (hostu::parallel_for: a thread that cannot be started is done without). The body
+// must not touch the HIP API or the context.
+template <class Body>
+void host_for(size_t n, Body body) {
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t T = n / 4;  // at least four proofs per thread
+  if (T > 8) T = 8;
+  if (hw && T > hw) T = hw;
+  hostu::parallel_for(n, T, body);
+}
+
+double host_now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// closes the running host phase (if any) and opens `name` (nullptr: none)
+void host_phase(cp_ctx *ctx, const char *name) {
+  if (name) hostu::alloc_checkpoint();  // cp_fault_inject(CP_FAULT_ALLOC): one checkpoint per phase of a proving call
+  if (!ctx->profiling) { ctx->phase_name = nullptr; return; }
+  const double t = host_now_ms();
+  if (ctx->phase_name) {
+    auto &a = ctx->prof_acc[std::string("host:") + ctx->phase_name];
+    a.first += 1;
+    a.second += t - ctx->phase_t0;
+    auto &w = ctx->prof_acc[std::string("wait:") + ctx->phase_name];
+    w.first += 1;
+    w.second += ctx->phase_wait;
+  }
+  ctx->phase_name = name;
+  ctx->phase_t0 = t;
+  ctx->phase_wait = 0;
+}
+// hipStreamSynchronize on the context stream, accounted to the running host phase
+hipError_t sync_stream(cp_ctx *ctx) {
+  if (!ctx->profiling) return hipStreamSynchronize(ctx->stream);
+  const double t = host_now_ms();
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  ctx->phase_wait += host_now_ms() - t;
+  return e;
+}
+
+// Launch `kernel` on the context stream; when profiling is on, bracket it with HIP events.
+#define LAUNCH(ctx, name, kernel, grid, block, ...)                                      \
+  do {                                                                                   \
+    cp_ctx::ProfRec pr__{name, nullptr, nullptr};                                        \
+    if ((ctx)->profiling) {                                                              \
+      if ((ctx)->prof_recs.size() >= 8192) prof_flush(ctx);                              \
+      pr__.e0 = prof_event(ctx);                                                         \
+      pr__.e1 = prof_event(ctx);                                                         \
+      (void)hipEventRecord(pr__.e0, (ctx)->stream);                                      \
+    }                                                                                    \
+    hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);              \
+    if ((ctx)->profiling) {                                                              \
+      (void)hipEventRecord(pr__.e1, (ctx)->stream);                                      \
+      (ctx)->prof_recs.push_back(pr__);                                                  \
+    }                                                                                    \
+    HIP_TRY(ctx, hipGetLastError());                                                     \
+  } while (0)
+
+}  // namespace

@@ -136,38 +136,8 @@ GL_HD uint64_t recombine(uint32_t y0, uint32_t y1, uint32_t y2, uint64_t c) {
   return r;
 }
 
-// Alternative: two 32-bit planes carried in 64-bit wrap-around arithmetic (true results < 2^41):
-// a third fewer plane evaluations and a cheaper recombination, paid for with 64-bit adds/subs.
-GL_HD void mds_layer_2planes(uint64_t (&s)[W], int next_rc_base) {
-  uint64_t lo[W], hi[W];
-#pragma unroll
-  for (int i = 0; i < W; i++) {
-    lo[i] = (uint32_t)s[i];
-    hi[i] = s[i] >> 32;
-  }
-  uint64_t yl[W], yh[W];
-  mds_limb(lo, yl);
-  mds_limb(hi, yh);
-#pragma unroll
-  for (int i = 0; i < W; i++) {
-    // value = yl + yh * 2^32 + rc  (< 2^74)
-    gl::u128 v = (gl::u128)yl[i] + ((gl::u128)yh[i] << 32) + (next_rc_base >= 0 ? rc(next_rc_base + i) : 0);
-    uint64_t l = (uint64_t)v, h = (uint64_t)(v >> 64);  // h < 2^10
-    gl::u128 r = (gl::u128)l + ((h << 32) - h);          // + h * (2^32 - 1)
-    s[i] = (uint64_t)r + ((0 - (uint64_t)(r >> 64)) & gl::EPS);
-  }
-}
-
-#ifndef POSEIDON_MDS_PLANES
-#define POSEIDON_MDS_PLANES 3
-#endif
-
 // s <- MDS * s + next_rc   (next_rc_base < 0: no constant)
 GL_HD void mds_layer(uint64_t (&s)[W], int next_rc_base) {
-#if POSEIDON_MDS_PLANES == 2
-  mds_layer_2planes(s, next_rc_base);
-  return;
-#endif
   uint32_t l0[W], l1[W], l2[W];
 #pragma unroll
   for (int i = 0; i < W; i++) {

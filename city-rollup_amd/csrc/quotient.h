@@ -45,6 +45,7 @@ struct Args {
   const uint64_t *zh;             // [2^rb]  Z_H on the coset, and
   const uint64_t *zh_inv;         // [2^rb]  its inverses
   const uint64_t *omega_tab;      // power table of omega_N
+  const uint64_t *l0_tab;         // [N], storage order: L_0(x) = Z_H(x) / (n (x - 1)) on the coset (per shape, cached per context)
   uint64_t *out;                  // [proof][nc][N], NATURAL index order
   size_t out_stride;
   uint64_t *acc;                  // [proof][nc][N], storage order: sum_t alpha^t term_t before the division by Z_H
@@ -65,6 +66,17 @@ __device__ __forceinline__ uint64_t pow_tab(const uint64_t *T, uint64_t e) {
 
 GL_HD int gate_num_constraints(const Gate &g) { return gates::num_constraints(g); }
 
+// L_0 on the LDE coset, storage order: depends on the shape only, so the one field inversion per point is paid once per
+// (degree, rate) and context instead of once per proof and point (it was a Fermat inversion per lane of k_quot_perm).
+__global__ __launch_bounds__(256) void k_fill_l0(uint64_t *out, size_t N, int log_N, int rb, const uint64_t *omega_tab,
+                                                 const uint64_t *zh, uint64_t n_field) {
+  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= N) return;
+  const uint32_t i = __brev((uint32_t)s) >> (32 - log_N);
+  const uint64_t x = gl::mul(7, pow_tab(omega_tab, i));
+  out[s] = gl::mul(zh[i & ((1u << rb) - 1)], gl::inv(gl::mul(n_field, gl::sub(x, 1))));
+}
+
 // grid = (N/256, B). L_0(x)(Z(x)-1) for every challenge, then the partial-product checks: terms 0 .. nc*(npp+2)
 __global__ __launch_bounds__(256) void k_quot_perm(Args a) {
   const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;  // storage (bit-reversed) position
@@ -82,8 +94,7 @@ __global__ __launch_bounds__(256) void k_quot_perm(Args a) {
   const int nc = a.nc;
 
   const uint64_t x = gl::mul(7, pow_tab(a.omega_tab, i));
-  const uint64_t zh = a.zh[i & ((1u << a.rb) - 1)];
-  const uint64_t l0 = gl::mul(zh, gl::inv(gl::mul(a.n_field, gl::sub(x, 1))));
+  const uint64_t l0 = a.l0_tab[s];
 
   uint64_t acc[MAXC];
 #pragma unroll

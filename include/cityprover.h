@@ -18,7 +18,10 @@
  * Conventions
  *  - every plonky2 field element is a canonical Goldilocks u64 (little-endian on the wire), p = 2^64-2^32+1;
  *    BLS12-381 coordinates and scalars are little-endian u64 limbs of the canonical value (6 resp. 4 limbs)
- *  - all functions return 0 on success, a negative cp_status otherwise, and NEVER abort or throw;
+ *  - all functions return 0 on success, a negative cp_status otherwise, and NEVER abort or throw:
+ *    every entry point is a function-try-block that maps std::bad_alloc to CP_ERR_OOM and anything else to
+ *    CP_ERR_INTERNAL, and the internal worker threads (transcript hashing, cp_ctx_set_lanes, the Groth16 side chain)
+ *    fall back to the calling thread when a thread cannot be created (tests: cp_fault_inject);
  *    the message is available from cp_last_error() (the Rust shim turns it into anyhow::bail!,
  *    matching the `anyhow::Result` convention of city_rollup_circuit/src/worker/traits.rs:16-43)
  *  - a cp_ctx is bound to one device and is thread-compatible (one caller at a time); multi-GPU =
@@ -38,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CP_ABI_VERSION 1
+#define CP_ABI_VERSION 2
 
 typedef enum cp_status {
   CP_OK = 0,
@@ -70,6 +73,13 @@ void cp_ctx_destroy(cp_ctx *ctx);
 int cp_ctx_set_lanes(cp_ctx *ctx, int lanes);
 /* last error message of `ctx`, or of the calling thread when ctx == NULL. Never NULL. */
 const char *cp_last_error(cp_ctx *ctx);
+/* Fault injection for tests of the error paths (the reference has none; a backend that lives inside
+ * the worker process must turn every failure into a status): the `after`-th (0 = the next) event of `kind` in this
+ * process fails once - CP_FAULT_THREAD: creation of an internal worker thread (the library must carry on on the calling
+ * thread: same results); CP_FAULT_ALLOC: a host allocation checkpoint inside a proving / verifying call throws
+ * std::bad_alloc (the call must return CP_ERR_OOM and leave the context usable). after < 0 disarms. */
+enum { CP_FAULT_THREAD = 0, CP_FAULT_ALLOC = 1 };
+int cp_fault_inject(int kind, long after);
 
 /* ---- device memory & stream ---------------------------------------------------------- */
 int cp_dev_alloc(cp_ctx *ctx, size_t bytes, void **out);
@@ -185,6 +195,10 @@ typedef struct cp_shape {
   int zero_knowledge; /* CircuitConfig::zero_knowledge (standard_recursion_zk_config, the user-side signature
                          circuits: city_common_circuit/src/circuits/zk_signature/inner.rs:50,116-117): FRI `hiding`, i.e.
                          the Merkle leaves of the wires / Z / quotient oracles end with CP_SALT_SIZE random elements */
+  int num_public_inputs; /* CommonCircuitData::num_public_inputs. The prove entry points and cp_verify refuse any other
+                            count (plonky2 `validate_proof_with_pis_shape`): hash_no_pad is an unpadded sponge, so without
+                            this check a proof would also verify under a zero-extended public-input vector. Proofs of
+                            circuits that differ only in this field may share a batch. */
 } cp_shape;
 #define CP_SALT_SIZE 4
 
@@ -209,6 +223,29 @@ int cp_zs_partial_products_dev(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *
                                const uint64_t *wires_values_dev, const uint64_t *betas_host,
                                const uint64_t *gammas_host, uint64_t *out_dev);
 void cp_circuit_destroy(cp_circuit *circuit);
+
+/* ---- circuit files: the CircuitData import bridge ------------------------------------
+ * A ".cpcirc" file is one built circuit as flat data: cp_shape, circuit_digest, the gate list with its selector
+ * groups, k_is, the positions of the public inputs in the wire matrix, and the constants + sigmas polynomials (values
+ * over <omega_n>, or coefficients as `PolynomialBatch::polynomials` holds them). The Rust side writes it once per
+ * circuit after `CircuitBuilder::build` (rust/plonky2-hwa-patch: `CircuitData::dump_cityprover`; build sites
+ * city_common_circuit/src/proof_minifier/pm_core.rs:96-105, city_rollup_circuit/src/worker/toolbox/root.rs:75-139);
+ * the byte layout is in csrc/circuit_file.inc and INTEGRATION.md section 4. Files carry a version and an FNV-1a
+ * checksum; a file of another version, a truncated or a corrupt one is refused. */
+/* load: cp_circuit_load + cp_circuit_set_gates (+ the public-input targets) from a file. NULL on failure. */
+cp_circuit *cp_circuit_load_file(cp_ctx *ctx, const char *path);
+/* save: writes `circuit` (values form, with k_is and, when set, the public-input targets) */
+int cp_circuit_save_file(cp_circuit *circuit, const char *path);
+/* Parses and checks a file WITHOUT a GPU (structure, sizes, canonical elements, checksum); any out pointer may be NULL.
+ * flags_out: bit 0 = polynomials in coefficient form, bit 1 = k_is present, bit 2 = public-input targets present. */
+int cp_circuit_file_info(const char *path, cp_shape *shape_out, uint64_t digest_out[4], size_t *n_gates_out,
+                         int *num_selectors_out, unsigned *flags_out);
+/* `ProverOnlyCircuitData::public_inputs` as (row, wire) pairs: where public input j sits in the wire matrix. */
+int cp_circuit_set_public_input_targets(cp_circuit *circuit, const uint32_t *row_wire_pairs, size_t n_targets);
+/* public_inputs_out[j] = wires[wire_j][row_j] (what `CircuitData::prove` reads back from the witness) */
+int cp_circuit_public_inputs_from_wires(cp_circuit *circuit, const uint64_t *wires_values_host, uint64_t *public_inputs_out);
+/* the shape and digest a circuit was loaded with */
+int cp_circuit_shape(cp_circuit *circuit, cp_shape *shape_out, uint64_t digest_out[4]);
 /* the circuit's constants_sigmas_cap (2^cap_height x 4), i.e. VerifierOnlyCircuitData */
 int cp_circuit_cs_cap(cp_circuit *circuit, uint64_t *cap_out_host);
 
@@ -389,6 +426,19 @@ typedef struct cp_groth16_pk {
 int cp_groth16_prove_bls12381(cp_ctx *ctx, const cp_groth16_pk *pk, const uint64_t *witness_dev, uint64_t *a_evals_dev,
                               uint64_t *b_evals_dev, uint64_t *c_evals_dev, const uint64_t r[4], const uint64_t s[4],
                               uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12]);
+
+
+/* The proof in the form the worker stores and the chain consumes: `CityGroth16ProofData { pi_a, pi_b_a0, pi_b_a1, pi_c }`
+ * = 4 x 48 bytes (city_rollup_common/src/block_template/data.rs:6-34; produced at
+ * city_rollup_circuit/src/worker/toolbox/root.rs:296-315). Each element is a compressed point: x little-endian, flags in
+ * the two top bits of the last byte (0x80: y is the larger root, 0x40: infinity); pi_b is one G2 point whose
+ * x = a0 + a1 u is split into pi_b_a0 (no flags) and pi_b_a1 (flags). Byte order, flag position and the a0 / a1 order
+ * are pinned on the reference's two samples (data.rs:72-73: all eight elements decompress to points of the r-torsion
+ * subgroups); the choice of root behind 0x80 follows arkworks (y > -y; F_p^2 by c1, then c0). Host arithmetic only:
+ * these two need no context and no GPU. Inputs: affine canonical coordinates as cp_groth16_prove_bls12381 returns them. */
+int cp_groth16_proof_pack_city(const uint64_t a_xy[12], const uint64_t b_xy[24], const uint64_t c_xy[12], uint8_t out[192]);
+/* the inverse (decompression: one square root per element); refuses x that is not on the curve / twist */
+int cp_groth16_proof_unpack_city(const uint8_t in[192], uint64_t a_xy[12], uint64_t b_xy[24], uint64_t c_xy[12]);
 
 #ifdef __cplusplus
 }

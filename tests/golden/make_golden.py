@@ -17,7 +17,11 @@ kept. Sources (paths relative to /root/reference):
   P4     city_common_circuit/src/hash/merkle/gadgets/merkle_proof.rs:243-1121
          city_common_circuit/src/hash/merkle/gadgets/delta_merkle_proof.rs:573-877
   P6/P7  qbench_data/example.bin  (bincode BlockProofStoreDump,
-         city_rollup_core_worker_qbench/src/dump.rs:15-26)
+         city_rollup_core_worker_qbench/src/dump.rs:15-26) - the data file of the reference's own q-bench
+         harness, kept WHOLE as tests/golden/qbench_example.bin (1.4 MB of data: 10 reference proofs, 46 job
+         witnesses, the job DAG): it is the input tools/cityprover_qbench reads natively
+  G16    city_rollup_common/src/block_template/data.rs:72-73
+         the two CityGroth16ProofData samples of `test_serde` (4 x 48-byte compressed BLS12-381 elements each)
 """
 import json
 import os
@@ -160,9 +164,28 @@ def example_bin():
                            "proofs": [rr.delta(), rr.delta()],
                            "allowed_circuit_hashes_root": rr.qhash()})
             assert rr.o + 24 == len(val)
+        elif k["data_type"] == 0 and k["topic"] == 0 and k["circuit_type"] == 4:
+            # CRClaimL1DepositCircuitInput (job_witnesses/op.rs:145-150): the deposit record, then two delta proofs,
+            # the root and the 24-byte signature proof id; the record's size is what the fixed-size tail leaves
+            delta_len = 4 * 72 + 8 + 8 + 32 * 72
+            rr = Rd(val, len(val) - (2 * delta_len + 72 + 24))
+            deltas.append({"circuit_type": 4, "task": k["task_index"], "proofs": [rr.delta(), rr.delta()],
+                           "allowed_circuit_hashes_root": rr.qhash()})
+            assert rr.o + 24 == len(val)
         elif k["data_type"] == 1 and len(val) > 0:
-            proofs.append((k, val))
+            proofs.append((k, val, b.index(val)))
     return cfg, index, deltas, proofs
+
+
+def groth16_samples():
+    """The two `CityGroth16ProofData` JSON samples of data.rs:72-73 (pi_a, pi_b_a0, pi_b_a1, pi_c as hex)."""
+    src = open(f"{REF}/city_rollup_common/src/block_template/data.rs").read()
+    out = []
+    for lit in re.findall(r'r#"(\{"pi_a".*?\})"#', src):
+        d = json.loads(lit)
+        out.append({k: d[k] for k in ("pi_a", "pi_b_a0", "pi_b_a1", "pi_c")})
+    assert len(out) == 2
+    return out
 
 
 def example_job_dag():
@@ -202,16 +225,12 @@ def main():
     json.dump({"config": cfg, "entries": index}, open(f"{OUT}/example_dump_index.json", "w"))
     json.dump(deltas, open(f"{OUT}/example_delta_merkle.json", "w"))
     json.dump(example_job_dag(), open(f"{OUT}/example_job_dag.json", "w"), indent=0)
-    # reference ProofWithPublicInputs blobs (bincode), kept verbatim as binary data:
-    # the first two WrappedSignatureProof (circuit_type 64) and the first Secp256K1SignatureProof (65)
-    kept = []
-    for want, cnt in ((64, 2), (65, 1)):
-        sel = [(k, v) for k, v in proofs if k["circuit_type"] == want][:cnt]
-        for k, v in sel:
-            name = f"example_proof_ct{want}_g{k['group_id']}_t{k['task_index']}.bin"
-            open(f"{OUT}/{name}", "wb").write(v)
-            kept.append({"file": name, **k, "len": len(v)})
+    # the whole dump, verbatim (data): every reference ProofWithPublicInputs is a slice of it
+    import shutil
+    shutil.copyfile(f"{REF}/qbench_data/example.bin", f"{OUT}/qbench_example.bin")
+    kept = [{"file": "qbench_example.bin", "offset": off, **k, "len": len(v)} for k, v, off in proofs]
     json.dump(kept, open(f"{OUT}/example_proofs.json", "w"), indent=1)
+    json.dump(groth16_samples(), open(f"{OUT}/groth16_proof_samples.json", "w"), indent=1)
     print("zero hashes 2x128; fingerprints", len(fingerprints()), "; example entries", len(index),
           "; delta witnesses", len(deltas), "; proofs kept", len(kept), "of", len(proofs))
 

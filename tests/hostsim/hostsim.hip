@@ -123,3 +123,27 @@ void hs_bls_fr_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *out) {
   blsfr::fr_to_canonical(r, out);
 }
 }
+
+// ---- host_util.h: worker threads that cannot take the process down ----
+#include "../../city-rollup_amd/csrc/host_util.h"
+extern "C" {
+// runs parallel_for over n indices on max_threads threads with the `fail_after`-th thread creation failing
+// (-1: none); out[p] += p + 1 for every index done; returns the number of indices whose body ran
+long hs_parallel_for(size_t n, size_t max_threads, long fail_after, uint64_t *out) {
+  hostu::fault_counter(0).store(fail_after);
+  std::atomic<long> ran{0};
+  hostu::parallel_for(n, max_threads, [&](size_t p) { out[p] += p + 1; ran++; });
+  hostu::fault_counter(0).store(-1);
+  return ran.load();
+}
+// body that throws std::bad_alloc at index `bad`: returns 1 when the exception reached the caller after all helpers
+// were joined, 0 when nothing was thrown
+int hs_parallel_for_throw(size_t n, size_t max_threads, size_t bad) {
+  try {
+    hostu::parallel_for(n, max_threads, [&](size_t p) { if (p == bad) throw std::bad_alloc(); });
+  } catch (const std::bad_alloc &) {
+    return 1;
+  }
+  return 0;
+}
+}

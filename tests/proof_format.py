@@ -105,3 +105,13 @@ def find_leaf_index(leaf, siblings, cap, O):
         return None
 
     return rec(0, start, 0)
+
+
+def reference_proofs(golden_dir):
+    """[(meta, bytes)] for the ten reference `ProofWithPublicInputs` of qbench_data/example.bin — slices of the dump the
+    reference's own q-bench harness reads, kept whole as tests/golden/qbench_example.bin (tests/golden/make_golden.py)."""
+    import json
+    import os
+    meta = json.load(open(os.path.join(golden_dir, "example_proofs.json")))
+    blob = open(os.path.join(golden_dir, meta[0]["file"]), "rb").read()
+    return [(m, blob[m["offset"]:m["offset"] + m["len"]]) for m in meta]

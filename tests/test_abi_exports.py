@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_no_gpu_fails_loudly():
     lib = cityprover.load_library()
-    assert lib.cp_abi_version() == 1
+    assert lib.cp_abi_version() == 2
     if lib.cp_device_count() == 0:
         assert not lib.cp_ctx_create(0)
         assert b"no HIP device" in lib.cp_last_error(None)

@@ -89,9 +89,8 @@ def test_merkle_cap_rows_matches_oracle(prover):
 
 def test_reference_proof_merkle_paths_on_gpu(prover, golden_dir):
     """Leaf rows + siblings taken from a REFERENCE proof (example.bin) hash up to the proof's own cap."""
-    from proof_format import parse_proof, find_leaf_index
-    meta = json.load(open(os.path.join(golden_dir, "example_proofs.json")))
-    pf = parse_proof(open(os.path.join(golden_dir, meta[0]["file"]), "rb").read())
+    from proof_format import parse_proof, find_leaf_index, reference_proofs
+    pf = parse_proof(reference_proofs(golden_dir)[0][1])
     caps = [pf["wires_cap"], pf["zs_pp_cap"], pf["quotient_cap"]]
     q = pf["queries"][0]
     # oracle finds the index from the wires path; GPU recomputes the leaf digests and the path

@@ -17,7 +17,7 @@ def prover():
     p.close()
 
 
-def cp_shape_of(cp, s):
+def cp_shape_of(cp, s, num_public_inputs=5):  # the synthetic circuits carry five public inputs
     return cp.standard_recursion_shape(degree_bits=s.degree_bits, num_constants=s.num_constants,
                                        num_routed_wires=s.num_routed_wires, num_wires=s.num_wires,
                                        num_challenges=s.num_challenges, num_partial_products=s.num_partial_products,
@@ -25,7 +25,7 @@ def cp_shape_of(cp, s):
                                        cap_height=s.cap_height, pow_bits=s.pow_bits,
                                        num_query_rounds=s.num_query_rounds,
                                        arity_bits=tuple(s.arity_bits[i] for i in range(s.n_arity)),
-                                       zero_knowledge=s.zero_knowledge)
+                                       zero_knowledge=s.zero_knowledge, num_public_inputs=num_public_inputs)
 
 
 @pytest.mark.parametrize("db,R,W,arity,B", [(5, 16, 20, (2,), 2), (8, 24, 30, (2, 2), 3), (12, 80, 135, (4, 4), 2)])

@@ -45,7 +45,7 @@ SMALL = dict(num_constants=3, num_routed_wires=8, num_wires=12, num_challenges=2
                                             (10, (4, 4), {"num_challenges": 3, "num_partial_products": 1})])
 def test_small_shapes_byte_identical(prover, db, arity, extra):
     import cityprover as cp
-    sh = cp.standard_recursion_shape(degree_bits=db, arity_bits=arity, **{**SMALL, **extra})
+    sh = cp.standard_recursion_shape(degree_bits=db, arity_bits=arity, num_public_inputs=3, **{**SMALL, **extra})
     cs, w, z, q = polys(sh, db)
     digest, pis = [11, 22, 33, 44], [5, 6, 7]
     circ = cp.Circuit(prover, sh, digest, cs)
@@ -59,14 +59,19 @@ def test_small_shapes_byte_identical(prover, db, arity, extra):
     nonce = parse_proof(want)["pow_witness"]
     assert circ.prove_tail(pis, w, z, q, pow_override=nonce) == want
     # no public inputs at all
-    assert circ.prove_tail([], w, z, q) == O.prove_tail(oracle_shape(sh), digest, [], cs, w, z, q)[0]
+    with pytest.raises(cp.CityProverError, match="public inputs"):   # the count is the circuit's
+        circ.prove_tail([], w, z, q)
+    sh0 = cp.standard_recursion_shape(degree_bits=db, arity_bits=arity, num_public_inputs=0, **{**SMALL, **extra})
+    circ0 = cp.Circuit(prover, sh0, digest, cs)
+    assert circ0.prove_tail([], w, z, q) == O.prove_tail(oracle_shape(sh), digest, [], cs, w, z, q)[0]
+    circ0.close()
     circ.close()
 
 
 def test_product_shape_byte_identical(prover):
     """standard_recursion_config: n = 2^12, 135 wires, 28 queries, 16-bit PoW — 130 360-byte proof."""
     import cityprover as cp
-    sh = cp.standard_recursion_shape()
+    sh = cp.standard_recursion_shape(num_public_inputs=8)
     cs, w, z, q = polys(sh, 42)
     digest, pis = [1, 2, 3, 4], list(range(100, 108))
     circ = cp.Circuit(prover, sh, digest, cs)
@@ -84,7 +89,7 @@ def test_product_shape_byte_identical(prover):
 
 def test_error_paths(prover):
     import cityprover as cp
-    sh = cp.standard_recursion_shape(degree_bits=6, arity_bits=(2, 2), **SMALL)
+    sh = cp.standard_recursion_shape(degree_bits=6, arity_bits=(2, 2), num_public_inputs=1, **SMALL)
     cs, w, z, q = polys(sh, 1)
     with pytest.raises(cp.CityProverError):
         cp.Circuit(prover, cp.standard_recursion_shape(degree_bits=6, arity_bits=(5, 5, 5), **SMALL), [0] * 4, cs)
@@ -102,9 +107,11 @@ def test_batched_proofs_of_different_circuits(prover):
     osh = oracle_shape(sh)
     csA, _, _, _ = polys(sh, 100)
     csB, _, _, _ = polys(sh, 200)
-    circA = cp.Circuit(prover, sh, [1, 1, 1, 1], csA)
-    circB = cp.Circuit(prover, sh, [2, 2, 2, 2], csB)
-    circs = [circA, circB, circA, circB, circB]
+    # proof i carries i public inputs: circuits that differ only in num_public_inputs share a batch
+    def shape_with(npi):
+        return cp.standard_recursion_shape(degree_bits=7, arity_bits=(2, 2), num_public_inputs=npi, **SMALL)
+    is_a = [True, False, True, False, False]
+    circs = [cp.Circuit(prover, shape_with(i), [1, 1, 1, 1] if is_a[i] else [2, 2, 2, 2], csA if is_a[i] else csB) for i in range(5)]
     ws, zs, qs, pis = [], [], [], []
     for i in range(5):
         _, w, z, q = polys(sh, 300 + i)
@@ -112,16 +119,19 @@ def test_batched_proofs_of_different_circuits(prover):
     dw, dz, dq = prover.to_device(np.stack(ws)), prover.to_device(np.stack(zs)), prover.to_device(np.stack(qs))
     got = cp.prove_tail_batch_dev(prover, circs, pis, dw.ptr, dz.ptr, dq.ptr)
     for i in range(5):
-        cs, dg = (csA, [1, 1, 1, 1]) if circs[i] is circA else (csB, [2, 2, 2, 2])
+        cs, dg = (csA, [1, 1, 1, 1]) if is_a[i] else (csB, [2, 2, 2, 2])
         want, _ = O.prove_tail(osh, dg, pis[i], cs, ws[i], zs[i], qs[i])
         assert got[i] == want, f"proof {i}"
     # nonce injection for a subset of the batch
     n2 = parse_proof(got[2])["pow_witness"]
     got2 = cp.prove_tail_batch_dev(prover, circs, pis, dw.ptr, dz.ptr, dq.ptr, pow_overrides=[None, None, n2, None, None])
     assert got2 == got
+    with pytest.raises(cp.CityProverError):  # the number of public inputs is the circuit's
+        cp.prove_tail_batch_dev(prover, circs, [p + [0] for p in pis], dw.ptr, dz.ptr, dq.ptr)
     for b in (dw, dz, dq):
         b.free()
-    circA.close(); circB.close()
+    for c in circs:
+        c.close()
 
 
 def test_batch_rejects_mixed_shapes(prover):

@@ -1,0 +1,213 @@
+"""cp_groth16_proof_pack_city / _unpack_city: the 4 x 48-byte `CityGroth16ProofData` the worker stores
+(city_rollup_common/src/block_template/data.rs:6-34). Host arithmetic only — runs without a GPU.
+
+PINNED on reference-held data: the two samples of data.rs:72-73 (tests/golden/groth16_proof_samples.json). An
+independent decompression in Python integers shows that every element is the little-endian x of a point ON the curve /
+twist and IN the r-torsion subgroup (a random x passes that with probability ~2^-127), that the flags live in the two
+top bits of the LAST byte, and that pi_b_a0 / pi_b_a1 are x.c0 / x.c1 in this order (the other order is not even on the
+twist). The library must reproduce the sample bytes from the decompressed points."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "city-rollup_amd"))
+
+p = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+r = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+
+# ---- independent arithmetic in Python integers (F_p, F_p^2 = F_p[u]/(u^2+1), affine group law) ----
+class F1:
+    zero, b = 0, 4
+    add = staticmethod(lambda a, b: (a + b) % p)
+    sub = staticmethod(lambda a, b: (a - b) % p)
+    mul = staticmethod(lambda a, b: a * b % p)
+    inv = staticmethod(lambda a: pow(a, p - 2, p))
+
+    @staticmethod
+    def sqrt(a):
+        y = pow(a, (p + 1) // 4, p)
+        return y if y * y % p == a else None
+
+    @staticmethod
+    def larger(y):
+        return y > (p - y) % p
+
+
+class F2:
+    zero, b = (0, 0), (4, 4)
+    add = staticmethod(lambda a, b: ((a[0] + b[0]) % p, (a[1] + b[1]) % p))
+    sub = staticmethod(lambda a, b: ((a[0] - b[0]) % p, (a[1] - b[1]) % p))
+    mul = staticmethod(lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p))
+
+    @staticmethod
+    def inv(a):
+        n = pow(a[0] * a[0] + a[1] * a[1], p - 2, p)
+        return (a[0] * n % p, -a[1] * n % p)
+
+    @staticmethod
+    def pow(a, e):
+        out = (1, 0)
+        while e:
+            if e & 1:
+                out = F2.mul(out, a)
+            a = F2.mul(a, a)
+            e >>= 1
+        return out
+
+    @staticmethod
+    def sqrt(a):
+        if a == (0, 0):
+            return a
+        a1 = F2.pow(a, (p - 3) // 4)
+        alpha, x0 = F2.mul(F2.mul(a1, a1), a), F2.mul(a1, a)
+        y = F2.mul((0, 1), x0) if alpha == (p - 1, 0) else F2.mul(F2.pow(F2.add((1, 0), alpha), (p - 1) // 2), x0)
+        return y if F2.mul(y, y) == a else None
+
+    @staticmethod
+    def larger(y):
+        n = F2.sub((0, 0), y)
+        return y[1] > n[1] if y[1] != n[1] else y[0] > n[0]
+
+
+def ec_add(F, P, Q):
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    (x1, y1), (x2, y2) = P, Q
+    if x1 == x2:
+        if F.add(y1, y2) == F.zero:
+            return None
+        three = F.add(F.add(F.mul(x1, x1), F.mul(x1, x1)), F.mul(x1, x1))
+        lam = F.mul(three, F.inv(F.add(y1, y1)))
+    else:
+        lam = F.mul(F.sub(y2, y1), F.inv(F.sub(x2, x1)))
+    x3 = F.sub(F.sub(F.mul(lam, lam), x1), x2)
+    return x3, F.sub(F.mul(lam, F.sub(x1, x3)), y1)
+
+
+def ec_mul(F, k, P):
+    R = None
+    while k:
+        if k & 1:
+            R = ec_add(F, R, P)
+        P = ec_add(F, P, P)
+        k >>= 1
+    return R
+
+
+def le(b):
+    return int.from_bytes(b, "little")
+
+
+def decompress(F, xbytes):
+    """x little-endian, flags in the top two bits of the last byte -> (point, flags)"""
+    flags = xbytes[-1] & 0xC0
+    raw = bytes(xbytes[:-1]) + bytes([xbytes[-1] & 0x3F])
+    x = le(raw) if F is F1 else (le(raw[:48]), le(raw[48:]))
+    assert (x < p) if F is F1 else (x[0] < p and x[1] < p)
+    y = F.sqrt(F.add(F.mul(F.mul(x, x), x), F.b))
+    if y is None:
+        return None, flags
+    if F.larger(y) != bool(flags & 0x80):
+        y = F.sub(F.zero, y)
+    return (x, y), flags
+
+
+@pytest.fixture(scope="module")
+def samples(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "groth16_proof_samples.json")))
+
+
+def test_reference_samples_pin_the_encoding(samples):
+    assert len(samples) == 2
+    for s in samples:
+        for name in ("pi_a", "pi_c"):
+            pt, flags = decompress(F1, bytes.fromhex(s[name]))
+            assert pt is not None and not flags & 0x40, name          # on the curve
+            assert ec_mul(F1, r, pt) is None, name                    # in G1
+        b = bytes.fromhex(s["pi_b_a0"]) + bytes.fromhex(s["pi_b_a1"])
+        assert bytes.fromhex(s["pi_b_a0"])[-1] & 0xC0 == 0            # no flag bits on a0: they sit on a1
+        pt, flags = decompress(F2, b)
+        assert pt is not None and ec_mul(F2, r, pt) is None           # on the twist, in G2
+        swapped, _ = decompress(F2, bytes.fromhex(s["pi_b_a1"])[:47] + bytes([bytes.fromhex(s["pi_b_a1"])[47] & 0x3F])
+                                + bytes.fromhex(s["pi_b_a0"]))
+        assert swapped is None                                        # (a1, a0) is not a point: the order is pinned
+
+
+def test_library_reproduces_the_reference_bytes(samples):
+    import cityprover as cp
+    for s in samples:
+        blob = b"".join(bytes.fromhex(s[k]) for k in ("pi_a", "pi_b_a0", "pi_b_a1", "pi_c"))
+        A, B, C = cp.groth16_unpack_city(blob)
+        assert A == decompress(F1, bytes.fromhex(s["pi_a"]))[0]
+        assert C == decompress(F1, bytes.fromhex(s["pi_c"]))[0]
+        assert B == decompress(F2, bytes.fromhex(s["pi_b_a0"]) + bytes.fromhex(s["pi_b_a1"]))[0]
+        assert cp.groth16_pack_city(A, B, C) == blob                  # byte-identical to the reference's samples
+
+
+def test_pack_random_points_and_both_signs():
+    import cityprover as cp
+    import oracle_lib as O
+    _, _, G1 = O.bls_constants()
+    rng = np.random.default_rng(5)
+    # a G2 point: take the first sample-independent x on the twist
+    x = (3, 1)
+    while True:
+        y = F2.sqrt(F2.add(F2.mul(F2.mul(x, x), x), F2.b))
+        if y is not None:
+            break
+        x = (x[0] + 1, x[1])
+    Q = (x, y)
+    for k in range(6):
+        a, c = int(rng.integers(1, 2**62)), int(rng.integers(1, 2**62))
+        A, C = ec_mul(F1, a, G1), ec_mul(F1, c, G1)
+        B = ec_mul(F2, k + 2, Q)
+        for flip in (False, True):
+            if flip:
+                A, B, C = (A[0], p - A[1]), (B[0], F2.sub((0, 0), B[1])), (C[0], p - C[1])
+            blob = cp.groth16_pack_city(A, B, C)
+            assert len(blob) == 192
+            assert decompress(F1, blob[:48])[0] == A and decompress(F1, blob[144:])[0] == C
+            assert decompress(F2, blob[48:144])[0] == B
+            assert cp.groth16_unpack_city(blob) == (A, B, C)
+        # the flag is exactly "y is the larger root": the two encodings of +-P differ in bit 7 of the last byte only
+        neg = cp.groth16_pack_city((A[0], p - A[1]), B, C)
+        assert neg[:47] == blob[:47] and neg[47] ^ blob[47] == 0x80 and neg[48:] == blob[48:]
+
+
+def test_pack_refuses_bad_input():
+    import cityprover as cp
+    import oracle_lib as O
+    _, _, G1 = O.bls_constants()
+    x = (3, 1)
+    while F2.sqrt(F2.add(F2.mul(F2.mul(x, x), x), F2.b)) is None:
+        x = (x[0] + 1, x[1])
+    Q = (x, F2.sqrt(F2.add(F2.mul(F2.mul(x, x), x), F2.b)))
+    good = cp.groth16_pack_city(G1, Q, G1)
+    with pytest.raises(cp.CityProverError, match="not on the curve"):
+        cp.groth16_pack_city((G1[0], G1[1] + 1), Q, G1)
+    with pytest.raises(cp.CityProverError, match="twist"):
+        cp.groth16_pack_city(G1, (Q[0], (Q[1][0] + 1, Q[1][1])), G1)
+    with pytest.raises(cp.CityProverError, match="canonical"):
+        cp.groth16_pack_city((G1[0] + p, G1[1]), Q, G1)
+    bad = bytearray(good)
+    bad[47] |= 0x40
+    with pytest.raises(cp.CityProverError, match="infinity"):
+        cp.groth16_unpack_city(bytes(bad))
+    bad = bytearray(good)
+    bad[95] |= 0x80
+    with pytest.raises(cp.CityProverError, match="flag"):
+        cp.groth16_unpack_city(bytes(bad))
+    # an x that is not on the curve (x = 1: 1 + 4 = 5 ... try until a non-residue)
+    xx = 1
+    while F1.sqrt((xx**3 + 4) % p) is not None:
+        xx += 1
+    bad = bytearray(good)
+    bad[:48] = xx.to_bytes(48, "little")
+    with pytest.raises(cp.CityProverError, match="curve"):
+        cp.groth16_unpack_city(bytes(bad))

@@ -241,3 +241,21 @@ def test_bls_scalar_field_ops(hs):
         e = int(rng.integers(0, 2**62))
         hs.hs_bls_fr_op(4, _w32(a, 8), _w32(e, 8), out)
         assert _from_w32(out) == pow(a, e, r)
+
+
+def test_parallel_for_survives_thread_creation_failures(hs):
+    """host_util.h (the transcript helpers, cp_ctx_set_lanes and the Groth16 side chain are built on it): every index
+    is done exactly once however many helper threads could be started, and an exception inside a helper reaches the
+    caller only after every helper has been joined (never std::terminate)."""
+    hs.hs_parallel_for.restype = ctypes.c_long
+    hs.hs_parallel_for.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_long, ctypes.POINTER(ctypes.c_uint64)]
+    hs.hs_parallel_for_throw.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t]
+    for n, threads in ((0, 4), (1, 4), (7, 1), (64, 8), (1000, 16), (33, 40)):
+        for fail_after in (-1, 0, 1, 3):
+            out = np.zeros(max(n, 1), np.uint64)
+            ran = hs.hs_parallel_for(n, threads, fail_after, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+            assert ran == n
+            assert (out[:n] == np.arange(1, n + 1, dtype=np.uint64)).all(), (n, threads, fail_after)
+    for bad in (0, 17, 63):
+        assert hs.hs_parallel_for_throw(64, 8, bad) == 1
+    assert hs.hs_parallel_for_throw(64, 8, 1000) == 0

@@ -32,10 +32,10 @@ def pscale(a, s): return [emul(x, s) for x in a]
 def base(v): return (v % P, 0)
 
 
-@pytest.mark.parametrize("which", [0, 1, 2])
+@pytest.mark.parametrize("which", range(10))
 def test_reference_proof_fri_combine_initial(golden_dir, which):
-    meta = json.load(open(os.path.join(golden_dir, "example_proofs.json")))
-    pf = parse_proof(open(os.path.join(golden_dir, meta[which]["file"]), "rb").read())
+    from proof_format import reference_proofs
+    pf = parse_proof(reference_proofs(golden_dir)[which][1])
     LOG_N, LOG_DEG = 15, 12
     omega = pow(7, (P - 1) >> LOG_N, P)
     g = pow(7, (P - 1) >> LOG_DEG, P)

@@ -93,10 +93,10 @@ def fold_poly(x, within, arity_bits, evals):
     return lagrange_coeffs(pts, ev)
 
 
-@pytest.mark.parametrize("which", [0, 1, 2])
+@pytest.mark.parametrize("which", range(10))
 def test_reference_proof_fri_folds(golden_dir, which):
-    meta = json.load(open(os.path.join(golden_dir, "example_proofs.json")))
-    pf = parse_proof(open(os.path.join(golden_dir, meta[which]["file"]), "rb").read())
+    from proof_format import reference_proofs
+    pf = parse_proof(reference_proofs(golden_dir)[which][1])
     LOG_N = 15
     omega = pow(7, (P - 1) >> LOG_N, P)
     qs = []

@@ -12,8 +12,10 @@ from proof_format import find_leaf_index, parse_proof, serialize_proof
 
 
 def proofs(golden_dir):
-    meta = json.load(open(os.path.join(golden_dir, "example_proofs.json")))
-    return [(m, open(os.path.join(golden_dir, m["file"]), "rb").read()) for m in meta]
+    from proof_format import reference_proofs
+    got = reference_proofs(golden_dir)
+    assert len(got) == 10   # 8 WrappedSignatureProof + 2 Secp256K1SignatureProof: every proof the dump holds
+    return got
 
 
 def test_bincode_layout_roundtrip(golden_dir):

@@ -67,7 +67,7 @@ POSEIDON_FRACTION = 0.6  # recursion-circuit gate mix (Pose
 def run(prover, B, iters, n_circuits=4, profile=False, poseidon_fraction=POSEIDON_FRACTION, gate_set="city_common",
         host_wires=False):
     cases = cases_for(prover, n_circuits, poseidon_fraction, gate_set)
-    sh = cp.standard_recursion_shape(num_constants=cases[0]["num_constants"])  # selectors + 2 gate constants
+    sh = cp.standard_recursion_shape(num_constants=cases[0]["num_constants"], num_public_inputs=len(cases[0]["public_inputs"]))  # selectors + 2 gate constants
     circs = []
     for i, c in enumerate(cases):
         circ = cp.Circuit(prover, sh, [i, 1, 2, 3], c["cs_values"])
@@ -126,7 +126,7 @@ def run_threads(T, B, iters, device=0, gate_set="city_common", host_wires=False)
     import threading
     provers = [cp.Prover(device) for _ in range(T)]
     cases = cases_for(provers[0], 4, POSEIDON_FRACTION, gate_set)
-    sh = cp.standard_recursion_shape(num_constants=cases[0]["num_constants"])
+    sh = cp.standard_recursion_shape(num_constants=cases[0]["num_constants"], num_public_inputs=len(cases[0]["public_inputs"]))
     start = threading.Barrier(T + 1)
     done = [None] * T
     pick = [i % len(cases) for i in range(B)]

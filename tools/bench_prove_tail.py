@@ -21,7 +21,7 @@ def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     batches = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 4, 16, 64]
     p = cp.Prover(0)
-    sh = cp.standard_recursion_shape()
+    sh = cp.standard_recursion_shape(num_public_inputs=8)
     n = 4096
     circ = cp.Circuit(p, sh, [1, 2, 3, 4], felts((85, n), 1))
     res = {}

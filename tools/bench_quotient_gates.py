@@ -19,7 +19,7 @@ def measure(prover, gate_set, B):
     kw = dict(db=12, num_routed=80, num_wires=135, chunk=8, rate_bits=3, arity_bits=(4, 4), cap_height=4, pow_bits=16,
               num_query_rounds=28, n_copies=64, backend=ProductBackend(prover))
     c = SG.build_gate_set(gate_set, seed=1, **kw)
-    sh = cp.standard_recursion_shape(num_constants=c["num_constants"])
+    sh = cp.standard_recursion_shape(num_constants=c["num_constants"], num_public_inputs=len(c["public_inputs"]))
     circ = cp.Circuit(prover, sh, [1, 1, 2, 3], c["cs_values"])
     cp.set_gates(circ, c["gate_list"], c["num_selectors"])
     dw = prover.to_device(np.stack([c["wires"]] * B))

@@ -69,6 +69,7 @@ Case load_case(const char *path) {
   c.shape.n_arity = sh[11];
   for (int i = 0; i < 8; i++) c.shape.arity_bits[i] = sh[12 + i];
   c.shape.zero_knowledge = sh[20];
+  c.shape.num_public_inputs = sh[21];
   const uint32_t n_gates = rd<uint32_t>(f);
   c.num_selectors = (int)rd<uint32_t>(f);
   c.gates.resize(n_gates);

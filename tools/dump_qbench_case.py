@@ -45,7 +45,7 @@ def main():
         ab = list(sh.arity_bits)[:8]
         f.write(struct.pack("<22i", sh.degree_bits, sh.num_constants, sh.num_routed_wires, sh.num_wires, sh.num_challenges,
                             sh.num_partial_products, sh.quotient_degree_factor, sh.rate_bits, sh.cap_height, sh.pow_bits,
-                            sh.num_query_rounds, sh.n_arity, *ab, 0, 0))
+                            sh.num_query_rounds, sh.n_arity, *ab, 0, len(cases[0]["public_inputs"])))
         gl = cases[0]["gate_list"]
         f.write(struct.pack("<II", len(gl), cases[0]["num_selectors"]))
         for g in gl:

@@ -134,7 +134,7 @@ class Replay:
 def run(n_blocks, threads=3, max_batch=32, device=0, gate_set="city_common", n_circuits=4, pinned=True):
     provers = [cp.Prover(device) for _ in range(threads)]
     cases = bench_prove.cases_for(provers[0], n_circuits, bench_prove.POSEIDON_FRACTION, gate_set)
-    sh = cp.standard_recursion_shape(num_constants=cases[0]["num_constants"])
+    sh = cp.standard_recursion_shape(num_constants=cases[0]["num_constants"], num_public_inputs=len(cases[0]["public_inputs"]))
     circs = []
     for p in provers:   # every context keeps its own resident copy of the circuits
         cs = []
