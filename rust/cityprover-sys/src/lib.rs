@@ -1,0 +1,214 @@
+//! cityprover-sys — Rust side of the drop-in boundary.
+//!
+//! `ffi` is the whole C ABI of `libcityprover_hip.so`, generated from `include/cityprover.h` by
+//! `tools/gen_rust_ffi.py`. The types below are the thin safe layer the patched `plonky2` crate uses
+//! (rust/plonky2-hwa-patch): one [`Context`] per worker process and GPU, one [`Circuit`] per built
+//! `CircuitData`, `prove` = everything of `CircuitData::prove` after witness generation, `verify` =
+//! `CircuitData::verify`. Every error of the library becomes an `anyhow::Error`, the convention of
+//! `city_rollup_circuit/src/worker/traits.rs:16-43`; the library itself never aborts or unwinds.
+//!
+//! NOT COMPILED in the build image (no cargo / rustc there): this is source for a machine with Rust.
+pub mod ffi;
+
+use std::ffi::{CStr, CString};
+use std::os::raw::c_int;
+use std::path::Path;
+use std::ptr;
+
+use anyhow::{anyhow, bail, Result};
+
+pub use ffi::{CpGate, CpShape};
+
+fn last_error(ctx: *mut ffi::CpCtx) -> String {
+    unsafe { CStr::from_ptr(ffi::cp_last_error(ctx)) }.to_string_lossy().into_owned()
+}
+
+fn check(ctx: *mut ffi::CpCtx, rc: c_int) -> Result<()> {
+    if rc == ffi::CP_OK {
+        return Ok(());
+    }
+    bail!("cityprover[{rc}]: {}", last_error(ctx))
+}
+
+/// One context = one GPU + one stream. Thread-compatible: one caller at a time (the worker loop is one
+/// thread per process, city_rollup_core_worker/src/lib.rs:131-145).
+pub struct Context {
+    raw: *mut ffi::CpCtx,
+}
+unsafe impl Send for Context {}
+
+impl Context {
+    pub fn device_count() -> usize {
+        unsafe { ffi::cp_device_count() }.max(0) as usize
+    }
+
+    /// Fails loudly when no GPU is visible: the library has no CPU fallback.
+    pub fn new(device: usize) -> Result<Self> {
+        let abi = unsafe { ffi::cp_abi_version() };
+        if abi != ffi::CP_ABI_VERSION {
+            bail!("libcityprover_hip.so has ABI version {abi}, this crate was generated for {}", ffi::CP_ABI_VERSION);
+        }
+        let raw = unsafe { ffi::cp_ctx_create(device as c_int) };
+        if raw.is_null() {
+            bail!("cp_ctx_create({device}): {}", last_error(ptr::null_mut()));
+        }
+        Ok(Self { raw })
+    }
+
+    /// Internal pipelining of one `prove_batch` call for a single-threaded caller (2..3 pays).
+    pub fn set_lanes(&self, lanes: usize) -> Result<()> {
+        check(self.raw, unsafe { ffi::cp_ctx_set_lanes(self.raw, lanes as c_int) })
+    }
+
+    pub fn raw(&self) -> *mut ffi::CpCtx {
+        self.raw
+    }
+
+    /// `CircuitData::prove` after witness generation for a batch of proofs of ONE shape / gate set
+    /// (circuits may differ). `wires[p]` = `MatrixWitness::wire_values` flattened wire-major
+    /// (`[num_wires][n]` canonical u64), `public_inputs[p]` = the values of `prover_only.public_inputs`.
+    /// `pow_witness[p]`: `Some(w)` injects a proof-of-work witness (e.g. the CPU prover's, whose parallel
+    /// search returns ANY valid witness), `None` = the smallest valid one.
+    /// Returns the bincode bytes of `ProofWithPublicInputs`, i.e. exactly what the worker stores
+    /// (city_redis_store/src/lib.rs:71-83).
+    pub fn prove_batch(
+        &self,
+        circuits: &[&Circuit],
+        wires: &[&[u64]],
+        public_inputs: &[&[u64]],
+        pow_witness: &[Option<u64>],
+    ) -> Result<Vec<Vec<u8>>> {
+        let n = circuits.len();
+        if wires.len() != n || public_inputs.len() != n || pow_witness.len() != n {
+            bail!("prove_batch: argument lengths differ");
+        }
+        for (c, w) in circuits.iter().zip(wires) {
+            let want = (c.shape.num_wires as usize) << c.shape.degree_bits;
+            if w.len() != want {
+                bail!("prove_batch: wire matrix of {} elements, the circuit needs {want}", w.len());
+            }
+        }
+        let cs: Vec<*mut ffi::CpCircuit> = circuits.iter().map(|c| c.raw).collect();
+        let ws: Vec<*const u64> = wires.iter().map(|w| w.as_ptr()).collect();
+        let pis: Vec<*const u64> = public_inputs.iter().map(|p| p.as_ptr()).collect();
+        let npis: Vec<usize> = public_inputs.iter().map(|p| p.len()).collect();
+        let use_pow: Vec<c_int> = pow_witness.iter().map(|w| w.is_some() as c_int).collect();
+        let pow: Vec<u64> = pow_witness.iter().map(|w| w.unwrap_or(0)).collect();
+        let mut out: Vec<*mut u8> = vec![ptr::null_mut(); n];
+        let mut lens = vec![0usize; n];
+        check(self.raw, unsafe {
+            ffi::cp_prove_batch_host(
+                self.raw, n, cs.as_ptr(), pis.as_ptr(), npis.as_ptr(), ws.as_ptr(), use_pow.as_ptr(), pow.as_ptr(),
+                out.as_mut_ptr(), lens.as_mut_ptr(),
+            )
+        })?;
+        Ok(out
+            .into_iter()
+            .zip(lens)
+            .map(|(p, len)| {
+                let v = unsafe { std::slice::from_raw_parts(p, len) }.to_vec();
+                unsafe { ffi::cp_free(p.cast()) };
+                v
+            })
+            .collect())
+    }
+}
+
+impl Drop for Context {
+    fn drop(&mut self) {
+        unsafe { ffi::cp_ctx_destroy(self.raw) }
+    }
+}
+
+/// A circuit resident on the GPU: the constants + sigmas commitment (coefficients, LDE, Merkle tree), the
+/// gate list with its selector groups, k_is — the counterpart of a built `CircuitData`
+/// (`CRWorkerToolboxRootCircuits::new`, city_rollup_circuit/src/worker/toolbox/root.rs:75-139).
+/// Must not outlive its `Context`.
+pub struct Circuit {
+    raw: *mut ffi::CpCircuit,
+    pub shape: CpShape,
+    pub digest: [u64; 4],
+}
+unsafe impl Send for Circuit {}
+
+impl Circuit {
+    /// From flat data (see `plonky2-hwa-patch`: `flatten_circuit`). `cs_values`: the constants (selectors first)
+    /// and sigma polynomials as VALUES over the subgroup, `[num_constants + num_routed_wires][n]`.
+    pub fn load(ctx: &Context, shape: &CpShape, digest: [u64; 4], cs_values: &[u64], k_is: &[u64], gates: &[CpGate], num_selectors: usize) -> Result<Self> {
+        let want = ((shape.num_constants + shape.num_routed_wires) as usize) << shape.degree_bits;
+        if cs_values.len() != want || k_is.len() != shape.num_routed_wires as usize {
+            bail!("Circuit::load: constants/sigmas or k_is have the wrong length");
+        }
+        let raw = unsafe { ffi::cp_circuit_load(ctx.raw, shape, digest.as_ptr(), cs_values.as_ptr(), k_is.as_ptr()) };
+        if raw.is_null() {
+            bail!("cp_circuit_load: {}", last_error(ctx.raw));
+        }
+        let c = Self { raw, shape: *shape, digest };
+        check(ctx.raw, unsafe { ffi::cp_circuit_set_gates(raw, gates.as_ptr(), gates.len(), num_selectors as c_int) })?;
+        Ok(c)
+    }
+
+    /// From a `.cpcirc` file (written by `CircuitData::dump_cityprover` of the patched plonky2, or by the library).
+    pub fn load_file(ctx: &Context, path: &Path) -> Result<Self> {
+        let p = CString::new(path.to_string_lossy().as_bytes())?;
+        let raw = unsafe { ffi::cp_circuit_load_file(ctx.raw, p.as_ptr()) };
+        if raw.is_null() {
+            bail!("cp_circuit_load_file({}): {}", path.display(), last_error(ctx.raw));
+        }
+        let mut shape: CpShape = unsafe { std::mem::zeroed() };
+        let mut digest = [0u64; 4];
+        check(ctx.raw, unsafe { ffi::cp_circuit_shape(raw, &mut shape, digest.as_mut_ptr()) })?;
+        Ok(Self { raw, shape, digest })
+    }
+
+    pub fn save_file(&self, path: &Path) -> Result<()> {
+        let p = CString::new(path.to_string_lossy().as_bytes())?;
+        let rc = unsafe { ffi::cp_circuit_save_file(self.raw, p.as_ptr()) };
+        if rc != ffi::CP_OK {
+            bail!("cp_circuit_save_file[{rc}]: {}", last_error(ptr::null_mut()));
+        }
+        Ok(())
+    }
+
+    /// `VerifierOnlyCircuitData::constants_sigmas_cap` as the GPU computed it (2^cap_height x 4): the shim compares it
+    /// with plonky2's own cap at load time — the first end-to-end parity check on a real circuit (fingerprints P8).
+    pub fn constants_sigmas_cap(&self) -> Result<Vec<[u64; 4]>> {
+        let n = 1usize << self.shape.cap_height;
+        let mut flat = vec![0u64; 4 * n];
+        let rc = unsafe { ffi::cp_circuit_cs_cap(self.raw, flat.as_mut_ptr()) };
+        if rc != ffi::CP_OK {
+            bail!("cp_circuit_cs_cap[{rc}]: {}", last_error(ptr::null_mut()));
+        }
+        Ok(flat.chunks_exact(4).map(|c| [c[0], c[1], c[2], c[3]]).collect())
+    }
+
+    /// `CircuitData::verify` on bincode bytes: `Ok(())` = accepted.
+    pub fn verify(&self, proof: &[u8]) -> Result<()> {
+        let rc = unsafe { ffi::cp_verify(self.raw, proof.as_ptr(), proof.len()) };
+        if rc == ffi::CP_OK {
+            return Ok(());
+        }
+        Err(anyhow!("cityprover[{rc}]: {}", last_error(ptr::null_mut())))
+    }
+
+    pub fn raw(&self) -> *mut ffi::CpCircuit {
+        self.raw
+    }
+}
+
+impl Drop for Circuit {
+    fn drop(&mut self) {
+        unsafe { ffi::cp_circuit_destroy(self.raw) }
+    }
+}
+
+/// `CityGroth16ProofData` bytes (pi_a | pi_b_a0 | pi_b_a1 | pi_c, 4 x 48) from affine coordinates
+/// (city_rollup_common/src/block_template/data.rs:27-34).
+pub fn groth16_pack_city(a_xy: &[u64; 12], b_xy: &[u64; 24], c_xy: &[u64; 12]) -> Result<[u8; 192]> {
+    let mut out = [0u8; 192];
+    let rc = unsafe { ffi::cp_groth16_proof_pack_city(a_xy.as_ptr(), b_xy.as_ptr(), c_xy.as_ptr(), out.as_mut_ptr()) };
+    if rc != ffi::CP_OK {
+        bail!("cp_groth16_proof_pack_city[{rc}]: {}", last_error(ptr::null_mut()));
+    }
+    Ok(out)
+}

@@ -1,0 +1,189 @@
+"""tools/cityprover_qbench — the q-bench harness: reads `BlockProofStoreDump` bincode natively
+(the reference's own qbench_data/example.bin, kept as tests/golden/qbench_example.bin), re-plans the block with its
+restatement of plan_jobs, drains the job queue with the reference's counter / goal / next-jobs semantics on a pool of
+workers and writes the reference's `[{"job_id", "duration"}]` output. CPU tests use --dry-run (the whole schedule, no
+proving, no GPU); the GPU tests prove every job and compare every proof with the oracle's bytes."""
+import json
+import os
+import struct
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tools", "cityprover_qbench")
+
+
+def build_harness():
+    sys.path.insert(0, os.path.join(ROOT, "city-rollup_amd"))
+    from cityprover import build
+    build.build()
+    srcs = [EXE + ".cpp", os.path.join(ROOT, "tools", "qbench", "jobs.h"), os.path.join(ROOT, "tools", "qbench", "pack.h"),
+            os.path.join(ROOT, "include", "cityprover.h")]
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(s) for s in srcs):
+        tmp = "%s.%d.tmp" % (EXE, os.getpid())
+        subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tools"), srcs[0],
+                        "-L" + os.path.join(ROOT, "city-rollup_amd"), "-lcityprover_hip", "-Wl,-rpath,$ORIGIN/../city-rollup_amd",
+                        "-lpthread", "-o", tmp], check=True)
+        os.replace(tmp, EXE)
+
+
+def run(args, ok=True):
+    build_harness()
+    r = subprocess.run([EXE] + args, capture_output=True, text=True)
+    if ok:
+        assert r.returncode == 0, r.stderr
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode != 0
+    return r.stderr
+
+
+def key_fields(hexkey):
+    return struct.unpack("<BQBIIIBB", bytes.fromhex(hexkey))
+
+
+def expected_pop_order(golden_dir):
+    """Independent restatement of the queue semantics (actors/simple.rs:57-115, events.rs:29-48) over the DAG that
+    make_golden.py decoded from the dump's own counter / goal / next-jobs records (not over the harness's planner)."""
+    fx = json.load(open(os.path.join(golden_dir, "example_job_dag.json")))
+    groups = {tuple(g["group"]): (g["goal"], [tuple(n) for n in g["next"]]) for g in fx}
+    cfg = json.load(open(os.path.join(golden_dir, "example_dump_index.json")))["config"]
+    reg, claim, transfer, addw, procw, addd = cfg["job_config"]
+    gid = lambda ct: ct + 0xCF00
+    # leaves in plan_jobs' order (job_planner.rs:141-151): introspections, then the op leaves
+    queue = [(0, 33, gid(33), 0, i) for i in range(addd + 1)]
+    for ct, n in ((0, reg), (4, claim), (6, transfer), (8, addw), (10, procw), (2, addd)):
+        queue += [(0, ct, gid(ct), 0, i) for i in range(n)]
+    counters, popped = {}, []
+    while queue:
+        j = queue.pop(0)
+        popped.append(j)
+        if j[0] == 3:
+            continue
+        goal, nxt = groups[j[:4]]
+        counters[j[:4]] = counters.get(j[:4], 0) + 1
+        if goal and counters[j[:4]] == goal:
+            queue += nxt
+    return popped
+
+
+def test_dry_run_reproduces_the_reference_schedule(golden_dir, tmp_path):
+    dump = os.path.join(golden_dir, "qbench_example.bin")
+    out, trace = str(tmp_path / "out.json"), str(tmp_path / "trace.jsonl")
+    res = run(["-i", dump, "-o", out, "--dry-run", "--check-plan", "--contexts", "1", "--batch", "1", "--trace", trace])
+    assert res["blocks_complete"] == 1 and res["jobs"] == 46 and res["proofs"] == 64
+    # (a) the output file is the reference's format: a JSON list of {"job_id": 48 hex chars, "duration": ms}
+    bench = json.load(open(out))
+    assert len(bench) == 46 and all(set(b) == {"job_id", "duration"} and len(b["job_id"]) == 48 and isinstance(b["duration"], int) for b in bench)
+    assert open(out).read().startswith('[\n  {\n    "job_id": "')       # serde_json::to_vec_pretty's layout
+    # (b) the job-id multiset == the GenerateStandardProof input witnesses the dump holds
+    idx = json.load(open(os.path.join(golden_dir, "example_dump_index.json")))["entries"]
+    want = sorted(e["key"] for e in idx if e["topic"] == 0 and e["data_type"] == 0)
+    assert sorted(b["job_id"] for b in bench) == want
+    # (c) pop order (barrier and notify jobs included) == the independent simulation over the dump's own DAG records
+    popped = []
+    for line in open(trace):
+        d = json.loads(line)
+        if "popped" in d:
+            popped.append((d["topic"], d["circuit_type"], d["group_id"], d["sub_group_id"], d["task_index"]))
+    assert popped == expected_pop_order(golden_dir)
+    assert len(popped) == 60 and popped[-1][0] == 3     # 46 proving jobs + 13 AggregateJobs barriers + the notify job
+    # (d) --check-plan passed: the harness's plan_jobs wrote exactly the records the dump carries (checked inside)
+
+
+def test_worker_pool_iterations_and_blocks_in_flight(golden_dir, tmp_path):
+    dump = os.path.join(golden_dir, "qbench_example.bin")
+    out = str(tmp_path / "out.json")
+    res = run(["-i", dump, dump, "-o", out, "-n", "3", "--dry-run", "--contexts", "4", "--batch", "8", "--blocks-in-flight", "4"])
+    assert res["dumps"] == 2 and res["blocks"] == 6 and res["blocks_complete"] == 6 and res["jobs"] == 6 * 46 and res["proofs"] == 6 * 64
+    bench = json.load(open(out))
+    from collections import Counter
+    assert set(Counter(b["job_id"] for b in bench).values()) == {6}
+
+
+def test_reference_counter_quirk(golden_dir, tmp_path):
+    """The reference never resets `counters` between iterations (memory_proof_store/mod.rs:77-83; qbench.rs:44-61): from
+    the second iteration on no group reaches its goal and only the 23 leaf jobs run. --ref-counters reproduces that."""
+    dump = os.path.join(golden_dir, "qbench_example.bin")
+    out = str(tmp_path / "out.json")
+    res = run(["-i", dump, "-o", out, "-n", "2", "--dry-run", "--ref-counters", "--contexts", "1", "--batch", "1"])
+    assert res["blocks_complete"] == 1 and res["jobs"] == 46 + 23
+    assert len(json.load(open(out))) == 46 + 23
+
+
+def test_bad_inputs_fail_loudly(golden_dir, tmp_path):
+    dump = open(os.path.join(golden_dir, "qbench_example.bin"), "rb").read()
+    p = str(tmp_path / "bad.bin")
+    open(p, "wb").write(dump[:-5])
+    assert "truncated" in run(["-i", p, "--dry-run"], ok=False) or "trailing" in run(["-i", p, "--dry-run"], ok=False)
+    open(p, "wb").write(dump + b"\0")
+    assert "trailing" in run(["-i", p, "--dry-run"], ok=False)
+    # a job whose input witness is missing fails like the reference's store ("Data not found")
+    idx = json.load(open(os.path.join(golden_dir, "example_dump_index.json")))["entries"]
+    victim = next(e for e in idx if e["topic"] == 0 and e["data_type"] == 0 and e["circuit_type"] == 7)
+    key = bytes.fromhex(victim["key"])
+    at = dump.index(key)
+    cut = dump[:at] + dump[at + 24 + 8 + victim["len"]:]
+    cut = cut[:44 + 16] + struct.pack("<Q", struct.unpack_from("<Q", dump, 60)[0] - 1) + cut[68:]   # entry count - 1
+    open(p, "wb").write(cut)
+    assert "Data not found" in run(["-i", p, "--dry-run"], ok=False)
+    # a signature proof a leaf job names is missing: the job fails before proving
+    sig = next(e for e in idx if e["topic"] == 2 and e["len"] > 0)
+    at = dump.index(bytes.fromhex(sig["key"]))
+    cut = dump[:at] + dump[at + 24 + 8 + sig["len"]:]
+    cut = cut[:60] + struct.pack("<Q", struct.unpack_from("<Q", dump, 60)[0] - 1) + cut[68:]
+    open(p, "wb").write(cut)
+    assert "Data not found" in run(["-i", p, "--dry-run"], ok=False)
+    assert "--pack" in run(["-i", os.path.join(golden_dir, "qbench_example.bin")], ok=False)
+
+
+def test_harness_fails_loudly_without_a_gpu(golden_dir, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    err = run(["-i", os.path.join(golden_dir, "qbench_example.bin"), "--pack", str(tmp_path)], ok=False)
+    assert "no HIP device" in err and "no CPU fallback" in err
+
+
+@pytest.mark.gpu
+def test_one_block_end_to_end_with_byte_parity(golden_dir, tmp_path):
+    """One example block proved job by job on 2 worker contexts: 46 jobs = 64 proofs, every proof byte-identical to the
+    CPU oracle's (recorded in the pack's witness files), output in the reference's format."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_circuit_pack
+    pack = make_circuit_pack.make_pack(str(tmp_path / "pack"), n_circuits=3, db=7, small=True)
+    dump = os.path.join(golden_dir, "qbench_example.bin")
+    out = str(tmp_path / "out.json")
+    res = run(["-i", dump, "-o", out, "--pack", pack, "--contexts", "2", "--batch", "8", "--check-plan"])
+    assert res["blocks_complete"] == 1 and res["jobs"] == 46 and res["proofs"] == 64
+    assert res["proofs_byte_checked"] >= 64 and res["workers"] >= 2
+    bench = json.load(open(out))
+    idx = json.load(open(os.path.join(golden_dir, "example_dump_index.json")))["entries"]
+    assert sorted(b["job_id"] for b in bench) == sorted(e["key"] for e in idx if e["topic"] == 0 and e["data_type"] == 0)
+    # the reference's single-threaded loop: one context, one job at a time — same jobs, same order as the dry run
+    out1, trace1, trace0 = str(tmp_path / "o1.json"), str(tmp_path / "t1.jsonl"), str(tmp_path / "t0.jsonl")
+    run(["-i", dump, "-o", out1, "--pack", pack, "--devices", "0", "--contexts", "1", "--batch", "1", "--trace", trace1])
+    run(["-i", dump, "--dry-run", "--contexts", "1", "--batch", "1", "--trace", trace0])
+    pops = lambda p: [json.loads(x)["popped"] for x in open(p) if "popped" in x]
+    assert pops(trace1) == pops(trace0)
+    # a tampered witness file (recorded proof altered) is caught by the byte comparison
+    wit = os.path.join(pack, "synthetic_0.cpwit")
+    from cityprover import files
+    w = files.read_witness_file(wit)
+    files.write_witness_file(wit, w["digest"], w["wires"], w["public_inputs"], proof=w["proof"][:-1] + bytes([w["proof"][-1] ^ 1]))
+    assert "differ" in run(["-i", dump, "--pack", pack, "--contexts", "1"], ok=False)
+
+
+@pytest.mark.gpu
+def test_product_shape_blocks_in_flight_and_throughput(golden_dir, tmp_path):
+    """Product shape (n = 2^12, 135 wires, 28 queries, 16-bit PoW): 3 blocks in flight on 3 contexts, every one of the
+    192 proofs equal to the oracle's 130 KB; then the raw throughput mode."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_circuit_pack
+    pack = make_circuit_pack.make_pack(str(tmp_path / "pack"), n_circuits=2, db=12)
+    dump = os.path.join(golden_dir, "qbench_example.bin")
+    res = run(["-i", dump, "-n", "3", "--pack", pack, "--contexts", "3", "--batch", "32", "--blocks-in-flight", "3"])
+    assert res["blocks_complete"] == 3 and res["proofs"] == 192 and res["proofs_byte_checked"] >= 192
+    res = run(["--mode", "throughput", "--pack", pack, "--contexts", "2", "--batch", "8", "--iters", "2"])
+    assert res["proofs"] >= 32 and res["proofs_byte_checked"] >= 32

@@ -1,19 +1,42 @@
-// cityprover-qbench: native measurement harness above the C ABI (SURVEY.md §8(b) "the build's own C++ harness for
-// measurement without Rust"). It is to libcityprover_hip.so what city-rollup's worker loop is to plonky2:
-//   * one host thread + one cp_ctx per worker, the circuits loaded once per context and kept resident
-//     (CRWorkerToolboxRootCircuits::new, city_rollup_circuit/src/worker/toolbox/root.rs:75-139);
-//   * a shared ready queue from which a worker pops jobs, proves them and releases their dependents
-//     (SimpleActorWorker::process_next_job, city_rollup_core_worker/src/actors/simple.rs:32-106; the q-bench loop
-//     city_rollup_core_worker/src/qbench.rs:44-61) - here up to --batch ready proofs become ONE cp_prove_batch_host call.
-// Input: the case file written by tools/dump_qbench_case.py (synthetic qbench-shaped circuits, witnesses, the CPU
-// oracle's proof bytes for them, and the example block's 64-proof DAG). Output: one JSON line.
-//   --mode throughput : every worker proves --iters batches of --batch independent proofs (common start, wall clock
-//                       until the last worker finishes)
-//   --mode dag        : --blocks example blocks in flight, proof-level dependencies honoured
-//   --lanes L         : cp_ctx_set_lanes(L) on every worker context (internal pipelining of one call; default 1)
-// Before timing, each distinct circuit is proved once and the bytes are compared with the oracle's, then cp_verify'd.
+// cityprover-qbench: the q-bench harness of city-rollup on the MI355X prover, plain C++ above the C ABI
+// (include/cityprover.h). It is to libcityprover_hip.so what the reference's offline benchmark is to plonky2:
+//
+//   city-rollup-cli q-bench -i <dump...> -o <out.json> [-n N]          city_common/src/cli/args.rs:104-117
+//   run_qbench / run_worker_qbench                                      city_rollup_core_worker_qbench/src/qbench.rs:15-85
+//   SimpleActorWorker::process_next_job / process_job                   city_rollup_core_worker/src/actors/simple.rs:32-115
+//   CityEventProcessorMemory (VecDeque job queue, benchmarks)           city_rollup_common/src/actors/simple/events.rs:8-56
+//
+// What it does, like the reference: deserialise each `BlockProofStoreDump` (bincode), per iteration re-plan the block's job
+// DAG into the proof store (plan_jobs), enqueue the leaf jobs, and drain the queue — a job is proved, its output stored
+// under `get_output_id()`, its duration recorded, its group counter incremented and, at the goal, its next jobs enqueued.
+// Output (-o): `[{"job_id": <24 bytes hex>, "duration": <ms>}]`, serde_json's pretty form, in completion order.
+//
+// What differs, by design:
+//   * the queue is drained by a POOL of workers — one host thread + one cp_ctx per worker, --contexts workers on each of
+//     --devices (default: every visible GPU) — pulling one shared ready queue (the in-process form of N worker processes
+//     on one Redis queue, city_rollup_core_worker/src/lib.rs:131-145); --contexts 1 --devices 0 --batch 1 is the
+//     reference's single-threaded loop, job for job in the same order;
+//   * a worker takes up to --batch ready jobs of ONE circuit type and proves them in one cp_prove_batch_host call (a job's
+//     `duration` is then the wall time of the batch it was part of);
+//   * --blocks-in-flight F replays F (dump, iteration) instances concurrently, each with its own proof store
+//     (BASELINE.json configs[3]: independent blocks); F = 1 is the reference's one-block-at-a-time loop;
+//   * circuits come from a circuit pack (tools/qbench/pack.h): `CircuitData` cannot be built without Rust, so every job
+//     type is bound to circuit files + witnesses — dumped from the real worker, or the synthetic shape-equivalent ones —
+//     and witness generation is not part of what is timed. The DATA dependencies are real all the same: a
+//     job needs its witness and the output proofs it names (tools/qbench/jobs.h proof_dependencies) in the store, or fails.
+//   * the Groth16 job (WrapFinalSigHashProofBLS12381) proves its plonky2 wrapper stage and stores the all-zero
+//     CityGroth16ProofData of the reference's GROTH16_DISABLED_DEV_MODE (toolbox/root.rs:287-294): no gnark circuit or
+//     proving key exists in the tree.
+//   * the reference re-plans every iteration but never resets `counters` (memory_proof_store/mod.rs:77-83), so from the
+//     second iteration on no group ever reaches its goal again and only leaf jobs run; here every iteration starts from
+//     fresh counters (--ref-counters keeps the reference's behaviour).
+//
+// Every proof is compared byte for byte with the proof recorded in its witness file (the CPU oracle's, or the Rust
+// prover's under nonce injection) when one is recorded. --dry-run runs the whole schedule without proving anything and
+// without a GPU (tests of the planner and the queue semantics); --mode throughput is the raw proofs/s measurement.
 // Build: g++ -O2 -std=c++17 -Iinclude tools/cityprover_qbench.cpp -Lcity-rollup_amd -lcityprover_hip
 //            -Wl,-rpath,'$ORIGIN/../city-rollup_amd' -lpthread -o tools/cityprover_qbench
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -22,289 +45,557 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "cityprover.h"
+#include "qbench/jobs.h"
+#include "qbench/pack.h"
 
 namespace {
 
-struct CircuitCase {
-  uint64_t digest[4];
-  std::vector<uint64_t> cs_values, public_inputs, wires;
-  std::vector<uint8_t> expected_proof;
-};
-struct Case {
-  cp_shape shape;
-  std::vector<cp_gate> gates;
-  int num_selectors = 0;
-  std::vector<CircuitCase> circuits;
-  std::vector<std::vector<uint32_t>> dag;  // task -> tasks it waits for
-};
+using qb::JobId;
 
 [[noreturn]] void die(const std::string &msg) {
   fprintf(stderr, "cityprover-qbench: %s\n", msg.c_str());
   exit(1);
 }
-void rd(FILE *f, void *dst, size_t bytes) {
-  if (bytes && fread(dst, 1, bytes, f) != bytes) die("case file truncated");
-}
-template <class T> T rd(FILE *f) { T v; rd(f, &v, sizeof v); return v; }
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-Case load_case(const char *path) {
-  FILE *f = fopen(path, "rb");
-  if (!f) die(std::string("cannot open ") + path);
-  char magic[8];
-  rd(f, magic, 8);
-  if (memcmp(magic, "CPQBENCH", 8) != 0 || rd<uint32_t>(f) != 1) die("not a version-1 case file");
-  Case c;
-  int32_t sh[22];
-  rd(f, sh, sizeof sh);
-  memset(&c.shape, 0, sizeof c.shape);
-  c.shape.degree_bits = sh[0]; c.shape.num_constants = sh[1]; c.shape.num_routed_wires = sh[2]; c.shape.num_wires = sh[3];
-  c.shape.num_challenges = sh[4]; c.shape.num_partial_products = sh[5]; c.shape.quotient_degree_factor = sh[6];
-  c.shape.rate_bits = sh[7]; c.shape.cap_height = sh[8]; c.shape.pow_bits = sh[9]; c.shape.num_query_rounds = sh[10];
-  c.shape.n_arity = sh[11];
-  for (int i = 0; i < 8; i++) c.shape.arity_bits[i] = sh[12 + i];
-  c.shape.zero_knowledge = sh[20];
-  c.shape.num_public_inputs = sh[21];
-  const uint32_t n_gates = rd<uint32_t>(f);
-  c.num_selectors = (int)rd<uint32_t>(f);
-  c.gates.resize(n_gates);
-  for (auto &g : c.gates) {
-    int32_t v[7];
-    rd(f, v, sizeof v);
-    g.type = v[0]; g.selector_index = v[1]; g.group_start = v[2]; g.group_end = v[3]; g.param = v[4]; g.param2 = v[5]; g.param3 = v[6];
-  }
-  c.circuits.resize(rd<uint32_t>(f));
-  for (auto &k : c.circuits) {
-    rd(f, k.digest, sizeof k.digest);
-    uint64_t rows = rd<uint64_t>(f), cols = rd<uint64_t>(f);
-    k.cs_values.resize(rows * cols);
-    rd(f, k.cs_values.data(), k.cs_values.size() * 8);
-    k.public_inputs.resize(rd<uint32_t>(f));
-    rd(f, k.public_inputs.data(), k.public_inputs.size() * 8);
-    rows = rd<uint64_t>(f); cols = rd<uint64_t>(f);
-    k.wires.resize(rows * cols);
-    rd(f, k.wires.data(), k.wires.size() * 8);
-    k.expected_proof.resize(rd<uint64_t>(f));
-    rd(f, k.expected_proof.data(), k.expected_proof.size());
-  }
-  c.dag.resize(rd<uint32_t>(f));
-  for (auto &deps : c.dag) {
-    deps.resize(rd<uint32_t>(f));
-    rd(f, deps.data(), deps.size() * 4);
-  }
-  fclose(f);
-  return c;
-}
-
-// one worker = one context with its own resident circuits and page-locked copies of the witnesses
-struct Worker {
-  cp_ctx *ctx = nullptr;
-  std::vector<cp_circuit *> circuits;
-  std::vector<uint64_t *> wires;  // page-locked (cp_host_alloc): DMA copies that overlap other contexts
-  const Case *cs = nullptr;
-
-  void check(int rc, const char *what) const {
-    if (rc != CP_OK) die(std::string(what) + ": " + cp_last_error(ctx));
-  }
-  void open(const Case &c, int device) {
-    cs = &c;
-    ctx = cp_ctx_create(device);
-    if (!ctx) die(std::string("cp_ctx_create: ") + cp_last_error(nullptr));
-    for (const auto &k : c.circuits) {
-      cp_circuit *circ = cp_circuit_load(ctx, &c.shape, k.digest, k.cs_values.data(), nullptr);
-      if (!circ) die(std::string("cp_circuit_load: ") + cp_last_error(ctx));
-      check(cp_circuit_set_gates(circ, c.gates.data(), c.gates.size(), c.num_selectors), "cp_circuit_set_gates");
-      circuits.push_back(circ);
-      void *p = nullptr;
-      check(cp_host_alloc(ctx, k.wires.size() * 8, &p), "cp_host_alloc");
-      memcpy(p, k.wires.data(), k.wires.size() * 8);
-      wires.push_back((uint64_t *)p);
-    }
-  }
-  // proves the circuits `which` as one batch; returns total proof bytes (proofs are freed unless `keep`)
-  size_t prove(const std::vector<uint32_t> &which, std::vector<std::vector<uint8_t>> *keep = nullptr) {
-    const size_t B = which.size();
-    std::vector<cp_circuit *> cc(B);
-    std::vector<const uint64_t *> pis(B), ws(B);
-    std::vector<size_t> npi(B), lens(B);
-    std::vector<uint8_t *> out(B, nullptr);
-    for (size_t i = 0; i < B; i++) {
-      const uint32_t k = which[i];
-      cc[i] = circuits[k];
-      pis[i] = cs->circuits[k].public_inputs.data();
-      npi[i] = cs->circuits[k].public_inputs.size();
-      ws[i] = wires[k];
-    }
-    check(cp_prove_batch_host(ctx, B, cc.data(), pis.data(), npi.data(), ws.data(), nullptr, nullptr, out.data(), lens.data()),
-          "cp_prove_batch_host");
-    size_t total = 0;
-    for (size_t i = 0; i < B; i++) {
-      total += lens[i];
-      if (keep) keep->emplace_back(out[i], out[i] + lens[i]);
-      cp_free(out[i]);
-    }
-    return total;
-  }
-  void close() {
-    for (size_t i = 0; i < circuits.size(); i++) {
-      cp_host_free(ctx, wires[i]);
-      cp_circuit_destroy(circuits[i]);
-    }
-    cp_ctx_destroy(ctx);
-  }
+struct Options {
+  std::vector<std::string> inputs;
+  std::string output, network = "dogeregtest", pack_dir, mode = "qbench", trace_path;
+  int iterations = 1, contexts = 3, batch = 32, blocks_in_flight = 1, lanes = 1, iters = 8;
+  std::vector<int> devices;  // empty: all visible
+  bool dry_run = false, ref_counters = false, check_plan = false;
 };
 
-double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// ---- one (dump, iteration) replay ---------------------------------------------------------------------------------
+struct Instance {
+  size_t index = 0, dump_index = 0;
+  int iteration = 0;
+  qb::ProofStore store;
+  std::mutex m;  // guards `store`
+  bool complete = false;
+  size_t jobs_done = 0, proofs_done = 0;
+  double t_start = 0, t_end = 0;
+};
 
-struct StartGate {  // common start for the workers
+struct QueueEntry { Instance *inst; JobId job; };
+struct BenchRecord { JobId job; uint64_t duration_ms; double t0, t1; int worker, batch; size_t instance; };
+
+// the shared ready queue (CityEventProcessorMemory::job_queue) + the bookkeeping of the run
+struct Scheduler {
   std::mutex m;
   std::condition_variable cv;
-  int waiting = 0, total = 0;
-  bool go = false;
-  void arrive() {
+  std::deque<QueueEntry> queue;
+  size_t in_flight = 0;        // jobs taken and not yet finished
+  size_t pending_instances = 0;  // started and not complete
+  bool failed = false;
+  std::string error;
+  std::vector<BenchRecord> benchmarks;  // completion order
+  std::vector<JobId> processed;        // every job popped, in pop order (barrier and notify jobs included)
+
+  void enqueue(Instance *inst, const std::vector<JobId> &jobs) {
+    std::lock_guard<std::mutex> l(m);
+    for (const JobId &j : jobs) queue.push_back({inst, j});
+    cv.notify_all();
+  }
+  void fail(const std::string &msg) {
+    std::lock_guard<std::mutex> l(m);
+    if (!failed) { failed = true; error = msg; }
+    cv.notify_all();
+  }
+  // Blocks until work is ready. Takes the front job and, when it is a proving job, up to max_batch - 1 further ready jobs of
+  // the same circuit type (FIFO among them). Returns false when the run is over (all instances complete, or a failure).
+  bool take(size_t max_batch, std::vector<QueueEntry> &out) {
     std::unique_lock<std::mutex> l(m);
-    if (++waiting == total) { go = true; cv.notify_all(); }
-    cv.wait(l, [&] { return go; });
-  }
-};
-
-// ready-queue scheduler over `blocks` copies of the DAG (group semantics are already expanded to proof level)
-struct Dag {
-  std::mutex m;
-  std::condition_variable cv;
-  std::deque<uint32_t> ready;
-  std::vector<int> missing;
-  std::vector<std::vector<uint32_t>> children;
-  size_t done = 0, total = 0;
-  Dag(const Case &c, int blocks) {
-    const uint32_t per = (uint32_t)c.dag.size();
-    total = (size_t)per * blocks;
-    missing.assign(total, 0);
-    children.assign(total, {});
-    for (int b = 0; b < blocks; b++)
-      for (uint32_t t = 0; t < per; t++) {
-        const uint32_t id = b * per + t;
-        missing[id] = (int)c.dag[t].size();
-        for (uint32_t d : c.dag[t]) children[b * per + d].push_back(id);
-        if (!missing[id]) ready.push_back(id);
+    for (;;) {
+      if (failed) return false;
+      if (!queue.empty()) break;
+      if (in_flight == 0 && pending_instances == 0) return false;
+      if (in_flight == 0 && queue.empty() && pending_instances > 0) {
+        // nothing running, nothing ready, blocks unfinished: the DAG cannot make progress
+        failed = true;
+        error = "the job queue ran dry before every block completed (a group never reached its goal)";
+        cv.notify_all();
+        return false;
       }
-  }
-  bool take(size_t max_batch, std::vector<uint32_t> &out) {  // false when everything is done
-    std::unique_lock<std::mutex> l(m);
-    cv.wait(l, [&] { return !ready.empty() || done == total; });
-    if (ready.empty()) return false;
+      cv.wait(l);
+    }
     out.clear();
-    while (!ready.empty() && out.size() < max_batch) { out.push_back(ready.front()); ready.pop_front(); }
+    out.push_back(queue.front());
+    queue.pop_front();
+    const JobId first = out[0].job;
+    if (first.topic == qb::GenerateStandardProof)
+      for (auto it = queue.begin(); it != queue.end() && out.size() < max_batch;) {
+        if (it->job.topic == qb::GenerateStandardProof && it->job.circuit_type == first.circuit_type) {
+          out.push_back(*it);
+          it = queue.erase(it);
+        } else {
+          ++it;
+        }
+      }
+    for (const auto &e : out) processed.push_back(e.job);
+    in_flight += out.size();
     return true;
   }
-  void finish(const std::vector<uint32_t> &ids) {
+  void finished(size_t n) {
     std::lock_guard<std::mutex> l(m);
-    for (uint32_t id : ids)
-      for (uint32_t ch : children[id])
-        if (--missing[ch] == 0) ready.push_back(ch);
-    done += ids.size();
+    in_flight -= n;
     cv.notify_all();
   }
 };
 
+// ---- a worker: one context, its own resident circuits, page-locked witnesses ----------------------------------------
+struct Worker {
+  int index = 0, device = 0;
+  cp_ctx *ctx = nullptr;
+  const qb::Pack *pack = nullptr;
+  std::vector<cp_circuit *> circuits;   // pack circuit index -> resident circuit of this context
+  std::vector<uint64_t *> wires;        // pack witness index -> page-locked copy of the wire matrix
+  size_t parity_checked = 0, proofs = 0;
+
+  void check(int rc, const char *what) const {
+    if (rc != CP_OK) throw std::runtime_error(std::string(what) + ": " + cp_last_error(ctx));
+  }
+  void open(const qb::Pack &p, int dev, int lanes) {
+    pack = &p;
+    device = dev;
+    ctx = cp_ctx_create(dev);
+    if (!ctx) throw std::runtime_error(std::string("cp_ctx_create: ") + cp_last_error(nullptr));
+    check(cp_ctx_set_lanes(ctx, lanes), "cp_ctx_set_lanes");
+    for (const auto &f : p.circuit_files) {
+      cp_circuit *c = cp_circuit_load_file(ctx, f.c_str());
+      if (!c) throw std::runtime_error("cp_circuit_load_file(" + f + "): " + cp_last_error(ctx));
+      circuits.push_back(c);
+    }
+    for (size_t w = 0; w < p.witnesses.size(); w++) {
+      const qb::Witness &wt = *p.witnesses[w];
+      cp_shape sh;
+      uint64_t dg[4];
+      check(cp_circuit_shape(circuits[p.witness_circuit[w]], &sh, dg), "cp_circuit_shape");
+      if (memcmp(dg, wt.digest, 32) != 0) throw std::runtime_error("witness " + std::to_string(w) + " was made for another circuit (digest differs)");
+      if ((int)wt.num_wires != sh.num_wires || (int)wt.degree_bits != sh.degree_bits || (int)wt.public_inputs.size() != sh.num_public_inputs)
+        throw std::runtime_error("witness " + std::to_string(w) + " does not fit its circuit's shape");
+      void *pinned = nullptr;
+      check(cp_host_alloc(ctx, wt.wires.size() * 8, &pinned), "cp_host_alloc");
+      memcpy(pinned, wt.wires.data(), wt.wires.size() * 8);
+      wires.push_back((uint64_t *)pinned);
+    }
+  }
+  // proves one (circuit, witness) binding `count` times as ONE batch; every proof is compared with the recorded bytes.
+  // Returns the proofs (all equal: same circuit, same witness, smallest proof-of-work witness).
+  std::vector<std::vector<uint8_t>> prove_stage(const qb::Binding &b, size_t count) {
+    const qb::Witness &wt = *pack->witnesses[b.witness];
+    std::vector<cp_circuit *> cc(count, circuits[b.circuit]);
+    std::vector<const uint64_t *> pis(count, wt.public_inputs.data()), ws(count, wires[b.witness]);
+    std::vector<size_t> npi(count, wt.public_inputs.size()), lens(count);
+    std::vector<uint8_t *> out(count, nullptr);
+    check(cp_prove_batch_host(ctx, count, cc.data(), pis.data(), npi.data(), ws.data(), nullptr, nullptr, out.data(), lens.data()),
+          "cp_prove_batch_host");
+    std::vector<std::vector<uint8_t>> res(count);
+    bool bad = false;
+    for (size_t i = 0; i < count; i++) {
+      res[i].assign(out[i], out[i] + lens[i]);
+      cp_free(out[i]);
+      if (!wt.expected_proof.empty()) {
+        bad = bad || res[i] != wt.expected_proof;
+        parity_checked++;
+      }
+    }
+    proofs += count;
+    if (bad) throw std::runtime_error("proof bytes differ from the bytes recorded in the witness file (circuit " + pack->circuit_files[b.circuit] + ")");
+    return res;
+  }
+  void close() {
+    for (auto *w : wires) cp_host_free(ctx, w);
+    for (auto *c : circuits) cp_circuit_destroy(c);
+    if (ctx) cp_ctx_destroy(ctx);
+    ctx = nullptr;
+  }
+};
+
+// bincode of CityGroth16ProofData with all-zero elements: 4 x (u64 length 96 + 96 hex characters) — each
+// Serialized2DFeltBLS12381 serialises as a hex STRING (serde_with::hex::Hex; city_crypto/src/field/serialized_2d_felt_bls12381.rs:9-11)
+std::vector<uint8_t> zero_groth16_bincode() {
+  std::vector<uint8_t> v;
+  for (int e = 0; e < 4; e++) {
+    const uint64_t n = 96;
+    v.insert(v.end(), (const uint8_t *)&n, (const uint8_t *)&n + 8);
+    v.insert(v.end(), 96, (uint8_t)'0');
+  }
+  return v;
+}
+
+// process_job (actors/simple.rs:57-115) for a batch of jobs of one circuit type, or a single non-proving job
+void process_batch(const Options &opt, Scheduler &S, Worker *worker, const qb::Pack *pack, const std::vector<QueueEntry> &batch) {
+  const JobId first = batch[0].job;
+  const double t0 = now_s();
+  std::vector<std::vector<uint8_t>> outputs(batch.size());
+  if (first.topic == qb::GenerateStandardProof) {
+    // inputs: the job's witness and every proof it names must be in the store (worker/traits.rs:74-83,164-202)
+    for (const auto &e : batch) {
+      std::lock_guard<std::mutex> l(e.inst->m);
+      const std::vector<uint8_t> &w = e.inst->store.get_bytes(e.job);
+      for (const JobId &dep : qb::proof_dependencies(e.job, w))
+        if (e.inst->store.get_bytes(dep).empty()) throw qb::StoreError("Proof " + dep.hex() + " needed by " + e.job.hex() + " is empty");
+    }
+    const int n_stages = qb::proofs_per_job(first.circuit_type);
+    if (!opt.dry_run) {
+      const auto &stages = pack->stages_for(first.circuit_type);
+      if ((int)stages.size() != n_stages)
+        throw std::runtime_error("the pack binds " + std::to_string(stages.size()) + " stages to circuit type " + std::to_string(first.circuit_type) +
+                                 ", the job proves " + std::to_string(n_stages));
+      for (int s = 0; s < n_stages; s++) {  // the stages of a job are a chain: stage s + 1 verifies the proof of stage s
+        auto proofs = worker->prove_stage(stages[s], batch.size());
+        if (s + 1 == n_stages) outputs = std::move(proofs);
+      }
+    } else {
+      for (auto &o : outputs) o.assign(1, 0);  // placeholder: "an output exists"
+    }
+    if (first.circuit_type == qb::WrapFinalSigHashProofBLS12381)
+      for (auto &o : outputs) o = zero_groth16_bincode();  // GROTH16_DISABLED_DEV_MODE (toolbox/root.rs:287-294)
+  }
+  const double t1 = now_s();
+  const uint64_t ms = (uint64_t)((t1 - t0) * 1e3);
+  for (size_t i = 0; i < batch.size(); i++) {
+    Instance *inst = batch[i].inst;
+    const JobId job = batch[i].job;
+    std::vector<JobId> release;
+    {
+      std::lock_guard<std::mutex> l(inst->m);
+      if (job.topic == qb::GenerateStandardProof) {
+        inst->store.set_bytes(job.output_id(), outputs[i]);
+        inst->jobs_done++;
+        inst->proofs_done += (size_t)qb::proofs_per_job(job.circuit_type);
+      }
+      if (job.topic == qb::NotifyOrchestratorComplete) {
+        inst->complete = true;
+        inst->t_end = t1;
+      } else {
+        const uint32_t goal = inst->store.get_goal(job);
+        if (goal != 0 && inst->store.inc_counter(job.counter_id()) == goal) release = inst->store.get_next_jobs(job);
+      }
+    }
+    {
+      std::lock_guard<std::mutex> l(S.m);
+      if (job.topic == qb::GenerateStandardProof)
+        S.benchmarks.push_back({job, ms, t0, t1, worker ? worker->index : -1, (int)batch.size(), inst->index});
+      if (job.topic == qb::NotifyOrchestratorComplete) S.pending_instances--;
+    }
+    if (!release.empty()) S.enqueue(inst, release);
+  }
+}
+
+void worker_loop(const Options &opt, Scheduler &S, Worker *worker, const qb::Pack *pack) {
+  std::vector<QueueEntry> batch;
+  while (S.take((size_t)opt.batch, batch)) {
+    try {
+      process_batch(opt, S, worker, pack, batch);
+    } catch (const std::exception &e) {
+      S.fail(e.what());
+    }
+    S.finished(batch.size());
+  }
+}
+
+// re-plans the block into `store` (plan_jobs) and returns the leaves; with check: the records must equal the dump's own
+std::vector<JobId> plan_instance(const qb::Dump &dump, qb::ProofStore &store, bool check) {
+  const qb::OpJobIds ops = qb::OpJobIds::dummy_from_config(dump.config);
+  const size_t num_input_witnesses = dump.config.add_deposit_count + 1;  // qbench.rs:37
+  qb::ProofStore planned;
+  const std::vector<JobId> leaves = qb::plan_jobs(planned, ops, num_input_witnesses, dump.config.checkpoint_id);
+  if (check) {
+    size_t in_dump = 0;
+    for (const auto &kv : dump.store.proofs)
+      if (kv.first.data_type == qb::Counter) in_dump++;
+    for (const auto &kv : planned.proofs) {
+      auto it = dump.store.proofs.find(kv.first);
+      if (it == dump.store.proofs.end()) die("--check-plan: the dump has no record " + kv.first.hex());
+      if (it->second != kv.second) die("--check-plan: record " + kv.first.hex() + " differs from the dump's");
+    }
+    if (in_dump != planned.proofs.size())
+      die("--check-plan: the dump holds " + std::to_string(in_dump) + " counter records, plan_jobs wrote " + std::to_string(planned.proofs.size()));
+  }
+  for (const auto &kv : planned.proofs) store.proofs[kv.first] = kv.second;
+  return leaves;
+}
+
+std::string json_escape(const std::string &s) {
+  std::string o;
+  for (char c : s) {
+    if (c == '"' || c == '\\') { o += '\\'; o += c; }
+    else if ((unsigned char)c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; }
+    else o += c;
+  }
+  return o;
+}
+
+int run_qbench(const Options &opt) {
+  if (opt.inputs.empty()) die("-i/--input: at least one dump");
+  std::vector<qb::Dump> dumps;
+  for (const auto &path : opt.inputs) {
+    try {
+      dumps.push_back(qb::parse_dump(qb::read_file(path)));
+    } catch (const std::exception &e) {
+      die(path + ": " + e.what());
+    }
+  }
+  // instances in the reference's order: dump by dump, iteration by iteration
+  std::vector<std::unique_ptr<Instance>> instances;
+  std::vector<std::vector<JobId>> leaves;
+  {
+    for (size_t d = 0; d < dumps.size(); d++) {
+      for (int it = 0; it < opt.iterations; it++) {
+        auto inst = std::make_unique<Instance>();
+        inst->index = instances.size();
+        inst->dump_index = d;
+        inst->iteration = it;
+        inst->store = dumps[d].store;
+        leaves.push_back(plan_instance(dumps[d], inst->store, opt.check_plan));
+        instances.push_back(std::move(inst));
+      }
+    }
+  }
+  if (opt.ref_counters && opt.blocks_in_flight != 1) die("--ref-counters needs --blocks-in-flight 1 (one store per dump, used iteration after iteration)");
+
+  // circuit pack + workers
+  qb::Pack pack;
+  std::vector<Worker> workers;
+  std::vector<int> devices = opt.devices;
+  if (!opt.dry_run) {
+    if (opt.pack_dir.empty()) die("--pack DIR is required (circuit files + witnesses; tools/make_circuit_pack.py writes a synthetic one)");
+    const int n_dev = cp_device_count();
+    if (n_dev <= 0) die("no HIP device visible: this library has no CPU fallback (use --dry-run to exercise the schedule only)");
+    if (devices.empty())
+      for (int d = 0; d < n_dev; d++) devices.push_back(d);
+    for (int d : devices)
+      if (d < 0 || d >= n_dev) die("--devices: device " + std::to_string(d) + " is not visible (have " + std::to_string(n_dev) + ")");
+    try {
+      pack = qb::load_pack(opt.pack_dir);
+    } catch (const std::exception &e) {
+      die(std::string("circuit pack: ") + e.what());
+    }
+    workers.resize(devices.size() * (size_t)opt.contexts);
+    try {
+      for (size_t w = 0; w < workers.size(); w++) {
+        workers[w].index = (int)w;
+        workers[w].open(pack, devices[w / (size_t)opt.contexts], opt.lanes);
+      }
+      // warm-up = parity gate: every binding once on every worker (allocations, staging ring; bytes == recorded bytes)
+      for (auto &w : workers)
+        for (const auto &kv : pack.by_type)
+          for (const auto &b : kv.second) w.prove_stage(b, 1);
+    } catch (const std::exception &e) {
+      die(e.what());
+    }
+  }
+  const size_t n_workers = opt.dry_run ? (size_t)std::max(1, opt.contexts) : workers.size();
+
+  Scheduler S;
+  const double t_begin = now_s();
+  // instances are started in waves of --blocks-in-flight; the next wave starts when the queue has drained
+  size_t next = 0;
+  while (next < instances.size() && !S.failed) {
+    const size_t wave_end = std::min(instances.size(), next + (size_t)opt.blocks_in_flight);
+    {
+      std::lock_guard<std::mutex> l(S.m);
+      S.pending_instances = wave_end - next;
+    }
+    for (size_t i = next; i < wave_end; i++) {
+      Instance &inst = *instances[i];
+      if (opt.ref_counters && inst.iteration > 0) {
+        // the reference clones the store once per dump and re-plans into it every iteration (qbench.rs:39-50): plan_jobs
+        // rewrites the records but `counters` keeps counting
+        inst.store = instances[i - 1]->store;
+        plan_instance(dumps[inst.dump_index], inst.store, false);
+      }
+      inst.t_start = now_s();
+      S.enqueue(&inst, leaves[i]);
+    }
+    std::vector<std::thread> threads;
+    for (size_t w = 0; w < n_workers; w++)
+      threads.emplace_back([&, w] {
+        worker_loop(opt, S, opt.dry_run ? nullptr : &workers[w], opt.dry_run ? nullptr : &pack);
+      });
+    for (auto &t : threads) t.join();
+    if (opt.ref_counters && !S.failed && !instances[next]->complete) {
+      // the reference's quirk: later iterations stop after the leaves; the queue simply empties (qbench.rs:52)
+      std::lock_guard<std::mutex> l(S.m);
+      S.pending_instances = 0;
+    }
+    next = wave_end;
+  }
+  const double t_end = now_s();
+  if (S.failed && !(opt.ref_counters && S.error.find("ran dry") != std::string::npos)) die(S.error);
+
+  // -o: Vec<QWorkerJobBenchmark> as serde_json::to_vec_pretty writes it (job_id.rs:194-202, qbench.rs:81-82)
+  if (!opt.output.empty()) {
+    FILE *f = fopen(opt.output.c_str(), "wb");
+    if (!f) die("cannot write " + opt.output);
+    if (S.benchmarks.empty()) fputs("[]", f);
+    else {
+      fputs("[\n", f);
+      for (size_t i = 0; i < S.benchmarks.size(); i++)
+        fprintf(f, "  {\n    \"job_id\": \"%s\",\n    \"duration\": %llu\n  }%s\n", S.benchmarks[i].job.hex().c_str(),
+                (unsigned long long)S.benchmarks[i].duration_ms, i + 1 < S.benchmarks.size() ? "," : "");
+      fputs("]", f);
+    }
+    fclose(f);
+  }
+  if (!opt.trace_path.empty()) {  // one JSON object per line: every job popped, in pop order, then every benchmark with its timing
+    FILE *f = fopen(opt.trace_path.c_str(), "wb");
+    if (!f) die("cannot write " + opt.trace_path);
+    for (const JobId &j : S.processed)
+      fprintf(f, "{\"popped\": \"%s\", \"topic\": %u, \"circuit_type\": %u, \"group_id\": %u, \"sub_group_id\": %u, \"task_index\": %u}\n", j.hex().c_str(),
+              j.topic, j.circuit_type, j.group_id, j.sub_group_id, j.task_index);
+    for (const auto &b : S.benchmarks)
+      fprintf(f, "{\"job_id\": \"%s\", \"circuit_type\": %u, \"start_ms\": %.3f, \"end_ms\": %.3f, \"worker\": %d, \"batch\": %d}\n", b.job.hex().c_str(),
+              b.job.circuit_type, (b.t0 - t_begin) * 1e3, (b.t1 - t_begin) * 1e3, b.worker, b.batch);
+    fclose(f);
+  }
+  size_t complete = 0, jobs = 0, proofs = 0, parity = 0;
+  double latency_sum = 0;
+  for (const auto &inst : instances) {
+    if (inst->complete) { complete++; latency_sum += inst->t_end - inst->t_start; }
+    jobs += inst->jobs_done;
+    proofs += inst->proofs_done;
+  }
+  for (const auto &w : workers) parity += w.parity_checked;
+  const double wall = t_end - t_begin;
+  std::string devs;
+  for (size_t i = 0; i < devices.size(); i++) devs += (i ? "," : "") + std::to_string(devices[i]);
+  printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"%s\", \"dumps\": %zu, \"iterations\": %d, \"blocks\": %zu, \"blocks_complete\": %zu, "
+         "\"jobs\": %zu, \"proofs\": %zu, \"jobs_per_block\": %.1f, \"proofs_per_block\": %.1f, \"wall_s\": %.6f, \"blocks_per_s\": %.4f, "
+         "\"proofs_per_s\": %.2f, \"mean_block_latency_ms\": %.2f, \"devices\": [%s], \"contexts_per_device\": %d, \"workers\": %zu, "
+         "\"max_batch\": %d, \"blocks_in_flight\": %d, \"proofs_byte_checked\": %zu, \"pack\": \"%s\", \"timed\": \"from the first enqueue to the "
+         "last completion; circuits resident, witnesses page-locked on the host (PCIe-inclusive), witness generation excluded\"}\n",
+         opt.dry_run ? "dry-run" : "qbench", dumps.size(), opt.iterations, instances.size(), complete, jobs, proofs,
+         instances.empty() ? 0.0 : (double)jobs / instances.size(), instances.empty() ? 0.0 : (double)proofs / instances.size(), wall,
+         wall > 0 ? complete / wall : 0.0, wall > 0 ? proofs / wall : 0.0, complete ? latency_sum / complete * 1e3 : 0.0, devs.c_str(), opt.contexts,
+         n_workers, opt.batch, opt.blocks_in_flight, parity, json_escape(opt.pack_dir).c_str());
+  for (auto &w : workers) w.close();
+  return complete == instances.size() || opt.ref_counters ? 0 : 1;
+}
+
+// raw throughput: every worker proves --iters batches of --batch proofs, cycling through the pack's bindings
+int run_throughput(const Options &opt) {
+  if (opt.pack_dir.empty()) die("--pack DIR is required");
+  const int n_dev = cp_device_count();
+  if (n_dev <= 0) die("no HIP device visible: this library has no CPU fallback");
+  std::vector<int> devices = opt.devices;
+  if (devices.empty())
+    for (int d = 0; d < n_dev; d++) devices.push_back(d);
+  qb::Pack pack;
+  try {
+    pack = qb::load_pack(opt.pack_dir);
+  } catch (const std::exception &e) {
+    die(std::string("circuit pack: ") + e.what());
+  }
+  std::vector<qb::Binding> bindings;
+  for (const auto &kv : pack.by_type)
+    for (const auto &b : kv.second) bindings.push_back(b);
+  std::vector<Worker> workers(devices.size() * (size_t)opt.contexts);
+  try {
+    for (size_t w = 0; w < workers.size(); w++) {
+      workers[w].index = (int)w;
+      workers[w].open(pack, devices[w / (size_t)opt.contexts], opt.lanes);
+      for (const auto &b : bindings) workers[w].prove_stage(b, 1);
+      workers[w].prove_stage(bindings[0], (size_t)opt.batch);  // the staging buffers of the full batch size
+    }
+  } catch (const std::exception &e) {
+    die(e.what());
+  }
+  std::mutex m;
+  std::condition_variable cv;
+  size_t waiting = 0;
+  bool go = false;
+  std::string error;
+  std::vector<std::thread> threads;
+  for (size_t w = 0; w < workers.size(); w++)
+    threads.emplace_back([&, w] {
+      {
+        std::unique_lock<std::mutex> l(m);
+        waiting++;
+        cv.notify_all();
+        cv.wait(l, [&] { return go; });
+      }
+      try {
+        for (int it = 0; it < opt.iters; it++) workers[w].prove_stage(bindings[(w + it) % bindings.size()], (size_t)opt.batch);
+      } catch (const std::exception &e) {
+        std::lock_guard<std::mutex> l(m);
+        error = e.what();
+      }
+    });
+  {
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] { return waiting == workers.size(); });
+    go = true;
+    cv.notify_all();
+  }
+  const double t0 = now_s();
+  for (auto &t : threads) t.join();
+  const double dt = now_s() - t0;
+  if (!error.empty()) die(error);
+  const size_t proofs = workers.size() * (size_t)opt.iters * (size_t)opt.batch;
+  size_t parity = 0;
+  for (const auto &w : workers) parity += w.parity_checked;
+  printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"throughput\", \"devices\": %zu, \"contexts_per_device\": %d, \"lanes_per_context\": %d, "
+         "\"max_batch\": %d, \"proofs\": %zu, \"wall_s\": %.6f, \"proofs_per_s\": %.2f, \"blocks_per_s\": %.3f, \"proofs_byte_checked\": %zu, "
+         "\"wires\": \"host (page-locked), PCIe-inclusive\"}\n",
+         devices.size(), opt.contexts, opt.lanes, opt.batch, proofs, dt, proofs / dt, proofs / dt / 64.0, parity);
+  for (auto &w : workers) w.close();
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
-  std::string path = "tools/qbench_case.bin", mode = "throughput";
-  int contexts = 3, batch = 32, iters = 8, blocks = 32, device = 0, lanes = 1;
+  Options opt;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
-    auto val = [&]() -> const char * { if (i + 1 >= argc) die("missing value for " + a); return argv[++i]; };
-    if (a == "--case") path = val();
-    else if (a == "--mode") mode = val();
-    else if (a == "--contexts") contexts = atoi(val());
-    else if (a == "--batch") batch = atoi(val());
-    else if (a == "--iters") iters = atoi(val());
-    else if (a == "--blocks") blocks = atoi(val());
-    else if (a == "--device") device = atoi(val());
-    else if (a == "--lanes") lanes = atoi(val());
-    else die("unknown argument " + a);
-  }
-  if (contexts < 1 || batch < 1 || iters < 1 || blocks < 1) die("bad argument value");
-  if (cp_device_count() <= 0) die("no HIP device visible: this library has no CPU fallback");
-  const Case cs = load_case(path.c_str());
-  const uint32_t n_circ = (uint32_t)cs.circuits.size();
-  std::vector<Worker> workers(contexts);
-  for (auto &w : workers) {
-    w.open(cs, device);
-    w.check(cp_ctx_set_lanes(w.ctx, lanes), "cp_ctx_set_lanes");  // > 1: one call is pipelined inside the library
-  }
-
-  // parity gate: every circuit once, bytes against the oracle's, then the library's verifier
-  {
-    std::vector<uint32_t> all(n_circ);
-    for (uint32_t k = 0; k < n_circ; k++) all[k] = k;
-    std::vector<std::vector<uint8_t>> got;
-    workers[0].prove(all, &got);
-    for (uint32_t k = 0; k < n_circ; k++) {
-      if (got[k] != cs.circuits[k].expected_proof) die("proof bytes of circuit " + std::to_string(k) + " differ from the oracle's");
-      workers[0].check(cp_verify(workers[0].circuits[k], got[k].data(), got[k].size()), "cp_verify");
-    }
-  }
-  for (auto &w : workers) {  // warm every context (allocations, staging ring)
-    std::vector<uint32_t> warm(batch);
-    for (int i = 0; i < batch; i++) warm[i] = i % n_circ;
-    w.prove(warm);
-  }
-
-  StartGate gate;
-  gate.total = contexts + 1;
-  std::vector<std::thread> threads;
-  std::atomic<size_t> proofs{0}, batches{0};
-  double t0 = 0, t1 = 0;
-  if (mode == "throughput") {
-    for (int t = 0; t < contexts; t++)
-      threads.emplace_back([&, t] {
-        std::vector<uint32_t> which(batch);
-        for (int i = 0; i < batch; i++) which[i] = (t + i) % n_circ;
-        gate.arrive();
-        for (int it = 0; it < iters; it++) { workers[t].prove(which); proofs += batch; batches++; }
-      });
-    gate.arrive();
-    t0 = now();
-    for (auto &th : threads) th.join();
-    t1 = now();
-  } else if (mode == "dag") {
-    Dag dag(cs, blocks);
-    for (int t = 0; t < contexts; t++)
-      threads.emplace_back([&, t] {
-        std::vector<uint32_t> ids, which;
-        gate.arrive();
-        while (dag.take((size_t)batch, ids)) {
-          which.resize(ids.size());
-          for (size_t i = 0; i < ids.size(); i++) which[i] = ids[i] % n_circ;
-          workers[t].prove(which);
-          proofs += ids.size();
-          batches++;
-          dag.finish(ids);
+    auto val = [&]() -> std::string { if (i + 1 >= argc) die("missing value for " + a); return argv[++i]; };
+    if (a == "-i" || a == "--input") {  // num_args = 1.. (args.rs:106): every following non-option is an input
+      opt.inputs.push_back(val());
+      while (i + 1 < argc && argv[i + 1][0] != '-') opt.inputs.push_back(argv[++i]);
+    } else if (a == "-o" || a == "--output") opt.output = val();
+    else if (a == "-n" || a == "--num-iterations") opt.iterations = atoi(val().c_str());
+    else if (a == "--network") opt.network = val();  // selects the network magic baked into the circuits: the pack's business here
+    else if (a == "--pack") opt.pack_dir = val();
+    else if (a == "--mode") opt.mode = val();
+    else if (a == "--contexts") opt.contexts = atoi(val().c_str());
+    else if (a == "--batch") opt.batch = atoi(val().c_str());
+    else if (a == "--iters") opt.iters = atoi(val().c_str());
+    else if (a == "--blocks-in-flight") opt.blocks_in_flight = atoi(val().c_str());
+    else if (a == "--lanes") opt.lanes = atoi(val().c_str());
+    else if (a == "--trace") opt.trace_path = val();
+    else if (a == "--dry-run") opt.dry_run = true;
+    else if (a == "--ref-counters") opt.ref_counters = true;
+    else if (a == "--check-plan") opt.check_plan = true;
+    else if (a == "--devices") {
+      const std::string v = val();
+      if (v != "all") {
+        size_t p = 0;
+        while (p < v.size()) {
+          size_t q = v.find(',', p);
+          if (q == std::string::npos) q = v.size();
+          opt.devices.push_back(atoi(v.substr(p, q - p).c_str()));
+          p = q + 1;
         }
-      });
-    gate.arrive();
-    t0 = now();
-    for (auto &th : threads) th.join();
-    t1 = now();
-    if (proofs != dag.total) die("scheduler finished early");
-  } else {
-    die("--mode must be throughput or dag");
+      }
+    } else die("unknown argument " + a);
   }
-  const double dt = t1 - t0;
-  const size_t per_block = cs.dag.size();
-  printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"%s\", \"contexts\": %d, \"lanes_per_context\": %d, \"max_batch\": %d, \"proofs\": %zu, "
-         "\"wall_s\": %.6f, \"proofs_per_s\": %.2f, \"blocks_per_s\": %.3f, \"mean_batch\": %.2f, \"proofs_per_block\": %zu, "
-         "\"blocks_in_flight\": %d, \"proof_bytes\": %zu, \"parity\": \"proof bytes == oracle bytes for all %u circuits; cp_verify ok\", "
-         "\"wires\": \"host (page-locked), PCIe-inclusive\"}\n",
-         mode.c_str(), contexts, lanes, batch, (size_t)proofs, dt, proofs / dt, proofs / dt / (double)per_block,
-         (double)proofs / (double)batches, per_block, mode == "dag" ? blocks : 0, cs.circuits[0].expected_proof.size(), n_circ);
-  for (auto &w : workers) w.close();
-  return 0;
+  if (opt.iterations < 1 || opt.contexts < 1 || opt.batch < 1 || opt.blocks_in_flight < 1 || opt.iters < 1 || opt.lanes < 1) die("bad argument value");
+  try {
+    if (opt.mode == "qbench") return run_qbench(opt);
+    if (opt.mode == "throughput") return run_throughput(opt);
+  } catch (const std::exception &e) {
+    die(e.what());
+  }
+  die("--mode must be qbench or throughput");
 }
