@@ -866,3 +866,49 @@ def groth16_unpack_city(data):
         raise CityProverError(f"[{rc}] " + lib.cp_last_error(None).decode())
     val = lambda x: sum(int(v) << (64 * j) for j, v in enumerate(x))
     return ((val(a[:6]), val(a[6:])), ((val(b[:6]), val(b[6:12])), (val(b[12:18]), val(b[18:]))), (val(c[:6]), val(c[6:])))
+
+
+# ---- FRI primitives and the verifier's audit hook ----
+ABI["cp_verify_fri_queries_with_challenges"] = (ctypes.c_int, [ctypes.POINTER(Shape), ctypes.c_char_p, ctypes.c_size_t, _u64p, _u64p, _u64p, _u64p])
+ABI["cp_fri_combine_dev"] = (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _u64p, _vp])
+ABI["cp_fri_fold_dev"] = (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_int, _u64p, _vp])
+
+
+def verify_fri_queries_with_challenges(shape, proof_bytes, alpha, zeta, fri_betas, x_indices):
+    """cp_verify's query phase with supplied challenges (no circuit, no GPU). Raises CityProverError on rejection."""
+    lib = load_library()
+    a, z = _as_u64(alpha), _as_u64(zeta)
+    fb = _as_u64(fri_betas).reshape(-1)
+    xi = _as_u64(x_indices)
+    rc = lib.cp_verify_fri_queries_with_challenges(ctypes.byref(shape), proof_bytes, len(proof_bytes), _ptr(a), _ptr(z),
+                                                   _ptr(fb) if fb.size else None, _ptr(xi))
+    if rc != 0:
+        raise CityProverError(f"[{rc}] " + lib.cp_last_error(None).decode())
+
+
+def fri_combine(prover, polys, alpha):
+    """sum_j alpha^j polys[j] over F_p^2 on the GPU (cp_fri_combine_dev). polys: (k, n) uint64 -> (n, 2) uint64."""
+    f = _as_u64(polys)
+    k, n = f.shape
+    din, dout = prover.to_device(f), prover.alloc(2 * n)
+    try:
+        a = _as_u64(alpha)
+        prover._check(prover.lib.cp_fri_combine_dev(prover.ctx, din.ptr, k, n, _ptr(a), dout.ptr))
+        return dout.download().reshape(n, 2)
+    finally:
+        din.free()
+        dout.free()
+
+
+def fri_fold(prover, coeffs_re_im, arity_bits, beta):
+    """one FRI reduction layer in coefficient space (cp_fri_fold_dev). coeffs_re_im: (2, n_in) uint64 -> (2, n_in >> arity_bits)."""
+    c = _as_u64(coeffs_re_im)
+    n_in = c.shape[1]
+    din, dout = prover.to_device(c), prover.alloc(2 * (n_in >> arity_bits))
+    try:
+        b = _as_u64(beta)
+        prover._check(prover.lib.cp_fri_fold_dev(prover.ctx, din.ptr, n_in, arity_bits, _ptr(b), dout.ptr))
+        return dout.download().reshape(2, n_in >> arity_bits)
+    finally:
+        din.free()
+        dout.free()

@@ -349,6 +349,27 @@ int cp_prove_batch_zk_host(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circ
  * permutations). 0 = accepted; CP_ERR_VERIFY with cp_last_error() naming the first failing check. */
 int cp_verify(cp_circuit *circuit, const uint8_t *proof, size_t proof_len);
 void cp_free(void *ptr);
+/* Audit hook — the query phase of cp_verify (per query round: the Merkle paths of the wires / Z / quotient oracles and
+ * of every FRI layer, fri_combine_initial, the fold chain, the final polynomial) with the challenges SUPPLIED instead of
+ * derived from the transcript, and without a circuit (the constants/sigmas path is not checked). The reference proofs
+ * of qbench_data/example.bin come without their circuits, but alpha, zeta and the FRI betas can be recovered from the
+ * proof bytes by algebra (tests/reference_challenges.py): this holds the very code cp_verify runs against plonky2's own
+ * output. fri_betas: n_arity x 2; x_indices: num_query_rounds leaf indices. Host arithmetic only, no context. */
+int cp_verify_fri_queries_with_challenges(const cp_shape *shape, const uint8_t *proof, size_t proof_len,
+                                          const uint64_t alpha[2], const uint64_t zeta[2], const uint64_t *fri_betas,
+                                          const uint64_t *x_indices);
+
+/* ---- FRI primitives, the kernels the opening proof is built from ------------------------
+ * cp_fri_combine_dev: comp[c] = sum_{j<k} alpha^j f_j[c] over F_p^2 for k base-field vectors of length n (polynomial j at
+ *   polys_dev + j*n) — plonky2's `ReducingFactor::reduce_polys_base`, the batch polynomial of the FRI opening proof.
+ *   comp_dev: n extension elements (2 u64 each).
+ * cp_fri_fold_dev: one reduction layer in coefficient space, out[j] = sum_{i < 2^arity_bits} beta^i c[(j << arity_bits) + i]
+ *   (= plonky2's `compute_evaluation` of every coset at beta, without leaving coefficient space).
+ *   coeffs_dev: [re | im][n_in]; out_dev: [re | im][n_in >> arity_bits]. */
+int cp_fri_combine_dev(cp_ctx *ctx, const uint64_t *polys_dev, size_t k, size_t n, const uint64_t alpha[2],
+                       uint64_t *comp_dev);
+int cp_fri_fold_dev(cp_ctx *ctx, const uint64_t *coeffs_dev, size_t n_in, int arity_bits, const uint64_t beta[2],
+                    uint64_t *out_dev);
 
 /* ---- BLS12-381 G1 multi-scalar multiplication ---------------------------------
  * The G1 MSMs of the Groth16 wrap proof: replaces the CPU MSM inside `gnark_plonky2_wrapper::wrap_plonky2_proof`

@@ -20,6 +20,8 @@ kept. Sources (paths relative to /root/reference):
          city_rollup_core_worker_qbench/src/dump.rs:15-26) - the data file of the reference's own q-bench
          harness, kept WHOLE as tests/golden/qbench_example.bin (1.4 MB of data: 10 reference proofs, 46 job
          witnesses, the job DAG): it is the input tools/cityprover_qbench reads natively
+  P5     city_rollup_common/src/config/sighash_wrapper_config.rs:16-1900 (+ the leaf order of
+         city_store/src/store/sighash/mod.rs:50-73): the whitelist tree of 1875 circuit fingerprints and its root
   G16    city_rollup_common/src/block_template/data.rs:72-73
          the two CityGroth16ProofData samples of `test_serde` (4 x 48-byte compressed BLS12-381 elements each)
 """
@@ -177,6 +179,31 @@ def example_bin():
     return cfg, index, deltas, proofs
 
 
+def whitelist_tree():
+    """P5: the sighash circuit whitelist — 1875 circuit fingerprints (sighash_wrapper_config.rs:24-1900) and the root of
+    the height-16 Merkle tree over them (:16-23). Leaf order: the gadget ids of generate_id_permutations
+    (introspection.rs:402-431), sorted by the derived Ord of SigHashGadgetId (field order at :157-163); leaf i of the
+    tree holds the fingerprint of the i-th SORTED id (city_store/src/store/sighash/mod.rs:50-73)."""
+    src = open(f"{REF}/city_rollup_common/src/config/sighash_wrapper_config.rs").read()
+    live, commented = src.split("/*", 1)      # the file also keeps the tree of an earlier configuration (max 2 / 2) in a comment
+    out = []
+    for text, m in ((live, 4), (commented, 2)):
+        vals = [int(x) for x in re.findall(r"GoldilocksField\((\d+)\)", text)]
+        count = (m + 1) ** 3 * (m + 1) * (m + 2) // 2
+        assert len(vals) == 4 + 4 * count, (len(vals), count)
+        root, fps = vals[:4], [vals[4 + 4 * i:8 + 4 * i] for i in range(count)]
+        ids = []
+        for lw in range(m + 1):
+            for ld in range(m + 1):
+                for w in range(m + 1):
+                    for d in range(m + 1):
+                        for s in range(d + 1):
+                            ids.append((d, w, ld, lw, s))   # (num_deposits, num_withdrawals, last deposits, last withdrawals, spend index)
+        order = sorted(range(count), key=lambda i: ids[i])
+        out.append({"max_deposits": m, "max_withdrawals": m, "height": 16, "root": root, "leaves": [fps[i] for i in order]})
+    return out
+
+
 def groth16_samples():
     """The two `CityGroth16ProofData` JSON samples of data.rs:72-73 (pi_a, pi_b_a0, pi_b_a1, pi_c as hex)."""
     src = open(f"{REF}/city_rollup_common/src/block_template/data.rs").read()
@@ -231,6 +258,7 @@ def main():
     kept = [{"file": "qbench_example.bin", "offset": off, **k, "len": len(v)} for k, v, off in proofs]
     json.dump(kept, open(f"{OUT}/example_proofs.json", "w"), indent=1)
     json.dump(groth16_samples(), open(f"{OUT}/groth16_proof_samples.json", "w"), indent=1)
+    json.dump(whitelist_tree(), open(f"{OUT}/sighash_whitelist_tree.json", "w"))
     print("zero hashes 2x128; fingerprints", len(fingerprints()), "; example entries", len(index),
           "; delta witnesses", len(deltas), "; proofs kept", len(kept), "of", len(proofs))
 
