@@ -5,6 +5,7 @@
 #include "ntt.h"
 #include "ntt16.h"
 #include "poseidon.h"
+#include "poseidon_coop.h"
 
 namespace {
 
@@ -192,8 +193,15 @@ int merkle_levels(cp_ctx *ctx, uint64_t *D, size_t per_tree, size_t n_leaves, si
     size_t pstride;
     if (np == cap_n) { parent = caps; pstride = cap_n * 4; }
     else { parent = D + off + n * 4; pstride = per_tree; }
-    LAUNCH(ctx, "merkle_level", merkle::k_level, dim3(blocks_for(np, merkle::THREADS), (unsigned)n_trees),
-           dim3(merkle::THREADS), child, np, parent, per_tree, pstride);
+    // a launch that cannot fill the chip is bound by the latency of ONE permutation: twelve lanes per state then
+    // (poseidon_coop.h); lane-per-state otherwise. CITYPROVER_COOP_MAX overrides the switch (0 = never) for measurements.
+    static const size_t coop_max = getenv("CITYPROVER_COOP_MAX") ? strtoull(getenv("CITYPROVER_COOP_MAX"), nullptr, 10) : 32768;
+    if (np * n_trees <= coop_max)
+      LAUNCH(ctx, "merkle_level_coop", pcoop::k_level_coop, dim3(blocks_for(np, pcoop::STATES_PER_BLOCK), (unsigned)n_trees), dim3(256), child,
+             np, parent, per_tree, pstride);
+    else
+      LAUNCH(ctx, "merkle_level", merkle::k_level, dim3(blocks_for(np, merkle::THREADS), (unsigned)n_trees),
+             dim3(merkle::THREADS), child, np, parent, per_tree, pstride);
     off += n * 4;
     n = np;
   }

@@ -63,7 +63,7 @@ GL_HD uint64_t mul_lazy(uint64_t a, uint64_t b) {
   return gl::reduce128_lazy(lo, hi);
 }
 GL_HD uint64_t sbox_lazy(uint64_t x) {
-  uint64_t x2 = mul_lazy(x, x), x4 = mul_lazy(x2, x2), x3 = mul_lazy(x, x2);
+  const uint64_t x2 = mul_lazy(x, x), x4 = mul_lazy(x2, x2), x3 = mul_lazy(x, x2);
   return mul_lazy(x3, x4);
 }
 GL_HD uint64_t add_const_lazy(uint64_t a, uint64_t c) {  // c canonical

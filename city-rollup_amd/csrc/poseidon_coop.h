@@ -1,0 +1,86 @@
+// Lane-cooperative Poseidon permutation for the latency-bound small launches (the upper levels of the Merkle trees).
+//
+// With one lane per state (poseidon.h) a permutation is a chain of ~23 K instructions: a wave that is alone on its SIMD
+// issues one instruction per 4 cycles, so a launch with fewer states than the chip has lanes takes ~40 us however small
+// it is — ten such levels per tree. Here TWELVE lanes share one state, one element each: the twelve S-boxes of a full
+// round run side by side, and the MDS row of every element is a 12-term dot product over the state, which the group
+// exchanges through LDS (one ds_write_b64 + six ds_read_b128 per lane and round; five states per wave, lanes 60..63 idle).
+// ~4 K instructions per lane and permutation instead of 23 K: a small level takes ~10 us instead of ~40 us, at ~2x the
+// total lane-instructions — which is why only launches that cannot fill the chip use it (merkle_levels in cityprover.hip).
+// Textbook round structure (constants, S-box, MDS), bit-exact with poseidon::permute.
+#pragma once
+#include "poseidon.h"
+
+namespace pcoop {
+
+constexpr int GROUP = 12;             // lanes per state
+constexpr int STATES_PER_WAVE = 5;    // 60 of 64 lanes
+constexpr int WAVES = 4;              // per workgroup (256 threads)
+constexpr int STATES_PER_BLOCK = STATES_PER_WAVE * WAVES;
+
+// lane e of a group computes y_e = sum_j MDS[e][j] s_j with MDS[e][j] = C[(j - e) mod 12] (+ 8 on [0][0])
+__device__ __forceinline__ uint32_t mds_coef(int e, int j) {
+  constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};  // == POSEIDON_MDS_CIRC (tests/test_tables.py)
+  int d = j - e;
+  if (d < 0) d += 12;
+  return C[d] + ((e == 0 && j == 0) ? 8u : 0u);
+}
+
+// One permutation per 12-lane group. x: this lane's element (any u64 representative on entry), returns the canonical
+// element. sh: the wave's LDS exchange area, STATES_PER_WAVE * 12 u64, 16-byte aligned. All 64 lanes of the wave must
+// call this together (lanes 60..63 and groups without a state carry dummies).
+__device__ __forceinline__ uint64_t permute(uint64_t x, int g, int e, bool lane_used, uint64_t *sh, const uint32_t (&coef)[GROUP]) {
+  uint64_t *mine = sh + g * GROUP;
+  // the round constant of this lane's element is a per-lane (divergent) load: fetched one round ahead, so that its
+  // latency (a few hundred cycles from L2) hides under the S-box instead of heading every round
+  uint64_t rc_next = poseidon::d_RC[e];
+#pragma unroll 1
+  for (int r = 0; r < poseidon::ROUNDS; r++) {
+    const uint64_t rc_cur = rc_next;
+    rc_next = poseidon::d_RC[(r + 1 < poseidon::ROUNDS ? r + 1 : r) * GROUP + e];
+    x = poseidon::add_const_lazy(x, rc_cur);
+    const bool full = r < poseidon::HALF_FULL || r >= poseidon::HALF_FULL + poseidon::PARTIAL;
+    if (full || e == 0) x = poseidon::sbox_lazy(x);
+    if (lane_used) mine[e] = x;  // lanes 60..63 shadow group 0 / element 0 and must not write
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // dot product in two 64-bit accumulators (low / high words of the lazy u64 elements): 12 x 41 x 2^32 < 2^41
+    uint64_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < GROUP; j++) {
+      const uint64_t s = mine[j];
+      lo += (uint64_t)(uint32_t)s * coef[j];
+      hi += (uint64_t)(uint32_t)(s >> 32) * coef[j];
+    }
+    __builtin_amdgcn_wave_barrier();  // every lane has read the state before anyone overwrites it
+    // value = lo + hi * 2^32 < 2^74
+    const uint64_t l = lo + (hi << 32);
+    const uint64_t h = (hi >> 32) + (l < lo);
+    x = gl::reduce128_lazy(l, h);
+  }
+  return gl::canon(x);
+}
+
+// one tree level for launches that cannot fill the chip: parent[i] = two_to_one(child[2i], child[2i+1]), 12 lanes per parent.
+// grid = (ceil(n_parents / 20), n_trees), block = 256
+__global__ __launch_bounds__(256) void k_level_coop(const uint64_t *__restrict__ child, size_t n_parents, uint64_t *__restrict__ parent,
+                                                    size_t child_tree_stride, size_t parent_tree_stride) {
+  __shared__ __attribute__((aligned(16))) uint64_t sh[WAVES][STATES_PER_WAVE * GROUP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / GROUP, e = lane - g * GROUP;
+  const bool lane_used = g < STATES_PER_WAVE;
+  const size_t i = (size_t)blockIdx.x * STATES_PER_BLOCK + wave * STATES_PER_WAVE + (lane_used ? g : 0);
+  const bool active = lane_used && i < n_parents;
+  child += (size_t)blockIdx.y * child_tree_stride;
+  parent += (size_t)blockIdx.y * parent_tree_stride;
+  uint32_t coef[GROUP];
+#pragma unroll
+  for (int j = 0; j < GROUP; j++) coef[j] = mds_coef(lane_used ? e : 0, j);
+  uint64_t x = 0;
+  if (active && e < 8) x = child[8 * i + e];
+  x = permute(x, lane_used ? g : 0, lane_used ? e : 0, lane_used, sh[wave], coef);
+  if (active && e < 4) parent[4 * i + e] = x;
+}
+
+}  // namespace pcoop
