@@ -76,6 +76,7 @@ def cpu_baseline(cols_host, log_n, cap_h):
     cores = min(len(os.sched_getaffinity(0)), 64)
     L = O.lib()
     L.or_set_threads(cores)
+    L.or_set_fast_poseidon(1)   # multiplier-free MDS planes, branch-free field ops: the faster form of the port
     k, n = cols_host.shape
     work = cols_host.copy()
     import ctypes
@@ -99,11 +100,13 @@ def cpu_baseline(cols_host, log_n, cap_h):
     t3 = time.perf_counter()
     O.permute_many(st)
     t4 = time.perf_counter()
+    L.or_set_fast_poseidon(0)
     perms = n * ((k + 7) // 8) + (n - 16)
     return {
         "value": (t2 - t0) * 1e3 / k, "unit": "ms/NTT", "cores": cores, "kind": "port",
         "poseidon_perms_per_s_all_cores": perms / (t2 - t1), "poseidon_perms_per_s_one_thread": len(st) / (t4 - t3),
-        "note": "a plain C restatement (textbook Poseidon rounds, u128 MDS products), NOT plonky2's AVX2 / rayon prover: no "
+        "note": "a C restatement (scalar code: multiplier-free MDS on 32-bit planes, branch-free field ops, textbook round "
+                "structure, OpenMP over columns / leaves), NOT plonky2's AVX2 / rayon prover: no "
                 "speed-up over the reference may be read off this number (the reference cannot be built here: no Rust toolchain)",
         "sample": f"one full step on the host: {k} x 2^{log_n} NTT (+bit-reverse) = {(t1 - t0):.2f} s, "
                   f"Poseidon Merkle cap over 2^{log_n} x {k} = {(t2 - t1):.2f} s; C oracle, "
@@ -131,12 +134,14 @@ def cpu_port_proof(prover, cores):
     got = cp.prove(circ, c["wires"], c["public_inputs"])
     circ.close()
     O.lib().or_set_threads(cores)
+    O.lib().or_set_fast_poseidon(1)
     t0 = time.perf_counter()
     O.commit_batch(c["cs_values"], 3, 4, want=("cap",))   # circuit data: built once per circuit upstream, not per proof
     t1 = time.perf_counter()
     want, _ = O.prove_full(osh, og, digest, c["public_inputs"], c["cs_values"], c["wires"])
     t2 = time.perf_counter()
     O.lib().or_set_threads(1)
+    O.lib().or_set_fast_poseidon(0)
     assert got == want, "GPU proof bytes != CPU oracle proof bytes"
     sec = (t2 - t1) - (t1 - t0)
     return {"proofs_per_s": 1.0 / sec, "seconds_per_proof": sec, "cores": cores, "kind": "port",

@@ -147,6 +147,59 @@ static inline void mds_layer(uint64_t s[POS_W]) {
   memcpy(s, o, sizeof o);
 }
 
+/* The MDS layer without 128-bit products (what plonky2's portable code reaches with its `mds_multiply_freq`): each element
+ * is split into its 32-bit halves, each half-plane goes through a multiplier-free decomposition of the circulant
+ * (mds_plane below), and one 96-bit recombination + reduction per output replaces 12 u128 multiply-adds.
+ * Same map as mds_layer: or_set_fast_poseidon(1) routes every permutation of the oracle through it — the CPU
+ * BASELINE of bench.py uses it (a port that keeps the textbook MDS would be a strawman); tests/test_oracle_golden.py
+ * pins both forms on the reference's known-answer data. */
+static int g_fast_poseidon = 0;
+void or_set_fast_poseidon(int on) { g_fast_poseidon = on != 0; }
+
+/* One 32-bit plane of the state (values < 2^32 held in u64): y[r] = sum_i C[i] s[(i + r) % 12] + 8 s[0] [r == 0] in
+ * wrap-around 64-bit arithmetic (true results < 2^41). The length-12 cyclic correlation splits through
+ * x^12 - 1 = (x^6 - 1)(x^6 + 1), x^6 - 1 = (x^3 - 1)(x^3 + 1) into a cyclic-3, a negacyclic-3 and a negacyclic-6 part whose
+ * transformed kernels [16,16,32], [-1,-8,2], [2,-4,16,1,-1,-1] are powers of two: shifts and adds only (the same
+ * decomposition plonky2 reaches with its `mds_multiply_freq`; here over the integers instead of an FFT). */
+static inline void mds_plane(const uint64_t s[POS_W], uint64_t y[POS_W]) {
+  uint64_t a[6], b[6];
+  for (int i = 0; i < 6; i++) {
+    a[i] = s[i] + s[i + 6];
+    b[i] = s[i] - s[i + 6];
+  }
+  const uint64_t aa0 = a[0] + a[3], aa1 = a[1] + a[4], aa2 = a[2] + a[5];
+  const uint64_t ab0 = a[0] - a[3], ab1 = a[1] - a[4], ab2 = a[2] - a[5];
+  const uint64_t t16 = (aa0 + aa1 + aa2) << 4;
+  const uint64_t e0 = t16 + (aa2 << 4), e1 = t16 + (aa0 << 4), e2 = t16 + (aa1 << 4);
+  const uint64_t f0 = (ab2 << 3) - ab0 - (ab1 << 1);
+  const uint64_t f1 = 0 - (ab0 << 3) - ab1 - (ab2 << 1);
+  const uint64_t f2 = (ab0 << 1) - (ab1 << 3) - ab2;
+  const uint64_t pc[6] = {e0 + f0, e1 + f1, e2 + f2, e0 - f0, e1 - f1, e2 - f2};
+  uint64_t v[6];
+  v[0] = (b[0] << 1) + b[1] + b[2] - b[3] - (b[4] << 4) + (b[5] << 2);
+  v[1] = (b[1] << 1) - (b[0] << 2) + b[2] + b[3] - b[4] - (b[5] << 4);
+  v[2] = (b[0] << 4) - (b[1] << 2) + (b[2] << 1) + b[3] + b[4] - b[5];
+  v[3] = b[0] + (b[1] << 4) - (b[2] << 2) + (b[3] << 1) + b[4] + b[5];
+  v[4] = b[1] - b[0] + (b[2] << 4) - (b[3] << 2) + (b[4] << 1) + b[5];
+  v[5] = b[2] - b[0] - b[1] + (b[3] << 4) - (b[4] << 2) + (b[5] << 1);
+  for (int i = 0; i < 6; i++) {
+    y[i] = pc[i] + v[i];
+    y[i + 6] = pc[i] - v[i];
+  }
+  y[0] += s[0] << 3;
+}
+
+static inline void mds_layer_fast(uint64_t s[POS_W]) {
+  uint64_t lo[POS_W], hi[POS_W], yl[POS_W], yh[POS_W];
+  for (int i = 0; i < POS_W; i++) {
+    lo[i] = (uint32_t)s[i];
+    hi[i] = s[i] >> 32;
+  }
+  mds_plane(lo, yl);
+  mds_plane(hi, yh);
+  for (int i = 0; i < POS_W; i++) s[i] = gl_reduce128((gl_u128)yl[i] + ((gl_u128)yh[i] << 32));
+}
+
 /* The textbook ("naive") form: every round = add constants, S-box (all lanes in
  * full rounds, lane 0 in partial rounds), full MDS. plonky2's optimised partial
  * rounds are algebraically the same map. */
@@ -159,7 +212,8 @@ void or_poseidon_permute(uint64_t s[POS_W]) {
     } else {
       s[0] = sbox7(s[0]);
     }
-    mds_layer(s);
+    if (g_fast_poseidon) mds_layer_fast(s);
+    else mds_layer(s);
   }
 }
 

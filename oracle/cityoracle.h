@@ -35,6 +35,9 @@ uint64_t or_gl_root_of_unity(int log_n);
 void or_poseidon_round_constants(uint64_t *out);
 /* MDS: circulant first row (12) and diagonal (12). */
 void or_poseidon_mds(uint64_t *circ, uint64_t *diag);
+/* 1: the MDS layer without 128-bit products (plonky2's portable form: 32-bit halves, u64 dot products) in every
+ * permutation of the oracle; 0 (default): the textbook layer. Same results (tests/test_oracle_golden.py). */
+void or_set_fast_poseidon(int on);
 void or_poseidon_permute(uint64_t state[12]);
 void or_poseidon_permute_many(uint64_t *states, size_t count);
 

@@ -26,17 +26,17 @@
 
 typedef unsigned __int128 gl_u128;
 
-static inline uint64_t gl_canon(uint64_t x) { return x >= GL_P ? x - GL_P : x; }
+/* (branch-free forms throughout: the conditions depend on the data, a mispredicted branch costs more than the arithmetic) */
+static inline uint64_t gl_canon(uint64_t x) { return x - (GL_P & (0 - (uint64_t)(x >= GL_P))); }
 
 static inline uint64_t gl_add(uint64_t a, uint64_t b) {
   /* a, b canonical */
   uint64_t s = a + b;
-  if (s < a || s >= GL_P) s -= GL_P;
-  return s;
+  return s - (GL_P & (0 - (uint64_t)((s < a) | (s >= GL_P))));
 }
 
 static inline uint64_t gl_sub(uint64_t a, uint64_t b) {
-  return a >= b ? a - b : a + (GL_P - b);
+  return a - b + (GL_P & (0 - (uint64_t)(a < b)));
 }
 
 static inline uint64_t gl_neg(uint64_t a) { return a ? GL_P - a : 0; }
@@ -49,10 +49,10 @@ static inline uint64_t gl_reduce128(gl_u128 x) {
   uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
   uint64_t hh = hi >> 32, hl = hi & GL_EPS;
   uint64_t t0 = lo - hh;
-  if (lo < hh) t0 -= GL_EPS; /* borrowed 2^64 == EPS (mod p) */
+  t0 -= GL_EPS & (0 - (uint64_t)(lo < hh)); /* borrowed 2^64 == EPS (mod p) */
   uint64_t t1 = hl * GL_EPS;
   uint64_t r = t0 + t1;
-  if (r < t1) r += GL_EPS; /* carried 2^64 == EPS (mod p) */
+  r += GL_EPS & (0 - (uint64_t)(r < t1)); /* carried 2^64 == EPS (mod p) */
   return gl_canon(r);
 }
 

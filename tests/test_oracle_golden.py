@@ -135,3 +135,25 @@ def test_merkle_verify_uses_same_direction_rule():
         i >>= 1
     assert O.merkle_verify(leaves[idx], idx, np.array(sib), cap, 2)
     assert not O.merkle_verify(leaves[idx], idx ^ 1, np.array(sib), cap, 2)
+
+
+def test_fast_mds_form_is_the_same_permutation(golden_dir):
+    """or_set_fast_poseidon(1) — the multiplier-free 32-bit-plane MDS the CPU baseline of bench.py runs on — is the same
+    map as the textbook layer: equal on random and edge states, and it reproduces the reference's iterated zero hashes."""
+    L = O.lib()
+    st = O.splitmix64_felts(77, 12 * 5000).reshape(-1, 12).copy()
+    st[0] = 0
+    st[1] = O.P - 1
+    st[2, ::2] = O.P - 1
+    try:
+        L.or_set_fast_poseidon(0)
+        want = O.permute_many(st.copy())
+        L.or_set_fast_poseidon(1)
+        assert (O.permute_many(st.copy()) == want).all()
+        zh = load(golden_dir, "poseidon_zero_hashes.json")["two_to_one"]
+        cur = np.zeros(4, np.uint64)
+        for i in range(1, 40):
+            cur = O.two_to_one(cur, cur)
+            assert [int(x) for x in cur] == zh[i]
+    finally:
+        L.or_set_fast_poseidon(0)
