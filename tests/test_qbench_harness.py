@@ -167,6 +167,10 @@ def test_one_block_end_to_end_with_byte_parity(golden_dir, tmp_path):
     run(["-i", dump, "--dry-run", "--contexts", "1", "--batch", "1", "--trace", trace0])
     pops = lambda p: [json.loads(x)["popped"] for x in open(p) if "popped" in x]
     assert pops(trace1) == pops(trace0)
+    # the Groth16 job with the prover kernels on a synthetic key (five MSMs + quotient + the 192-byte packing) instead of
+    # the all-zero dev-mode proof: three per block
+    res = run(["-i", dump, "--pack", pack, "--contexts", "2", "--batch", "8", "--groth16-log-size", "10"])
+    assert res["blocks_complete"] == 1 and res["groth16_proofs"] == 3 and res["groth16_log_constraints"] == 10
     # a tampered witness file (recorded proof altered) is caught by the byte comparison
     wit = os.path.join(pack, "synthetic_0.cpwit")
     from cityprover import files

@@ -26,7 +26,8 @@
 //     job needs its witness and the output proofs it names (tools/qbench/jobs.h proof_dependencies) in the store, or fails.
 //   * the Groth16 job (WrapFinalSigHashProofBLS12381) proves its plonky2 wrapper stage and stores the all-zero
 //     CityGroth16ProofData of the reference's GROTH16_DISABLED_DEV_MODE (toolbox/root.rs:287-294): no gnark circuit or
-//     proving key exists in the tree.
+//     proving key exists in the tree. --groth16-log-size L adds the Groth16 prover kernels on a synthetic key of 2^L
+//     constraints (five MSMs + quotient + the 192-byte packing): the cost of that stage, not a valid proof.
 //   * the reference re-plans every iteration but never resets `counters` (memory_proof_store/mod.rs:77-83), so from the
 //     second iteration on no group ever reaches its goal again and only leaf jobs run; here every iteration starts from
 //     fresh counters (--ref-counters keeps the reference's behaviour).
@@ -70,6 +71,7 @@ struct Options {
   std::vector<std::string> inputs;
   std::string output, network = "dogeregtest", pack_dir, mode = "qbench", trace_path;
   int iterations = 1, contexts = 3, batch = 32, blocks_in_flight = 1, lanes = 1, iters = 8;
+  int groth16_log = 0;  // > 0: the Groth16 job runs cp_groth16_prove_bls12381 on a synthetic key of 2^groth16_log constraints
   std::vector<int> devices;  // empty: all visible
   bool dry_run = false, ref_counters = false, check_plan = false;
 };
@@ -151,6 +153,92 @@ struct Scheduler {
   }
 };
 
+// ---- the Groth16 stage of the WrapFinalSigHashProofBLS12381 job, on a SYNTHETIC proving key ----------------------------
+// The reference proves a gnark circuit that verifies the wrapper's plonky2 proof (toolbox/root.rs:296-304); neither that
+// circuit nor its proving key exists in the tree, so with --groth16-log-size L the harness measures the
+// prover kernels on a stand-in of the same SHAPE: point sets (a i + b) G built on the device, a witness with 60 % of its
+// wires in {0, 1} (what R1CS witnesses look like), random evaluation vectors. The output goes through the real tail:
+// cp_groth16_proof_pack_city -> CityGroth16ProofData -> bincode (four hex strings), stored like the reference stores it.
+// The proof is NOT a valid proof of anything (no circuit) — correctness of the assembly is tests/test_gpu_groth16.py.
+static const uint64_t BLS_G1[12] = {0xfb3af00adb22c6bbull, 0x6c55e83ff97a1aefull, 0xa14e3a3f171bac58ull, 0xc3688c4f9774b905ull,
+                                    0x2695638c4fa9ac0full, 0x17f1d3a73197d794ull, 0x0caa232946c5e7e1ull, 0xd03cc744a2888ae4ull,
+                                    0x00db18cb2c04b3edull, 0xfcf5e095d5d00af6ull, 0xa09e30ed741d8ae4ull, 0x08b3f481e3aaa0f1ull};
+static const uint64_t BLS_G2[24] = {0xd48056c8c121bdb8ull, 0x0bac0326a805bbefull, 0xb4510b647ae3d177ull, 0xc6e47ad4fa403b02ull, 0x260805272dc51051ull, 0x024aa2b2f08f0a91ull,
+    0xe5ac7d055d042b7eull, 0x334cf11213945d57ull, 0xb5da61bbdc7f5049ull, 0x596bd0d09920b61aull, 0x7dacd3a088274f65ull, 0x13e02b6052719f60ull,
+    0xe193548608b82801ull, 0x923ac9cc3baca289ull, 0x6d429a695160d12cull, 0xadfd9baa8cbdd3a7ull, 0x8cc9cdc6da2e351aull, 0x0ce5d527727d6e11ull,
+    0xaaa9075ff05f79beull, 0x3f370d275cec1da1ull, 0x267492ab572e99abull, 0xcb3e287e85a763afull, 0x32acd2b02bc28b99ull, 0x0606c4a02ea734ccull};
+
+struct Groth16Stage {
+  int log_n = 0;
+  cp_groth16_pk pk;
+  void *sets[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  void *witness = nullptr, *ev_master = nullptr, *ev[3] = {nullptr, nullptr, nullptr};
+
+  void open(cp_ctx *ctx, int log_size) {
+    log_n = log_size;
+    const size_t n = (size_t)1 << log_n;
+    auto check = [&](int rc, const char *what) { if (rc != CP_OK) throw std::runtime_error(std::string(what) + ": " + cp_last_error(ctx)); };
+    const uint32_t ab[5][2] = {{3, 1}, {5, 2}, {7, 3}, {11, 4}, {13, 5}};
+    for (int k = 0; k < 5; k++) {
+      const bool g2 = k == 2;
+      check(cp_dev_alloc(ctx, n * (g2 ? CP_G2_AFFINE_BYTES : CP_G1_AFFINE_BYTES), &sets[k]), "cp_dev_alloc");
+      check(g2 ? cp_msm_bls12381_g2_synthetic_points_dev(ctx, BLS_G2, ab[k][0], ab[k][1], n, sets[k])
+               : cp_msm_bls12381_g1_synthetic_points_dev(ctx, BLS_G1, ab[k][0], ab[k][1], n, sets[k]), "synthetic points");
+    }
+    std::vector<uint64_t> w(4 * n), e(4 * n);
+    uint64_t x = 0x9E3779B97F4A7C15ull + (uint64_t)log_n;
+    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (size_t i = 0; i < n; i++) {
+      const bool small = next() % 10 < 6;
+      for (int j = 0; j < 4; j++) {
+        w[4 * i + j] = small ? (j == 0 ? next() & 1 : 0) : next() & (j == 3 ? ((1ull << 62) - 1) : ~0ull);
+        e[4 * i + j] = next() & (j == 3 ? ((1ull << 62) - 1) : ~0ull);
+      }
+    }
+    check(cp_dev_alloc(ctx, n * 32, &witness), "cp_dev_alloc");
+    check(cp_h2d(ctx, witness, w.data(), n * 32), "cp_h2d");
+    check(cp_dev_alloc(ctx, n * 32, &ev_master), "cp_dev_alloc");
+    check(cp_h2d(ctx, ev_master, e.data(), n * 32), "cp_h2d");
+    for (auto &p : ev) check(cp_dev_alloc(ctx, n * 32, &p), "cp_dev_alloc");
+    memset(&pk, 0, sizeof pk);
+    pk.n_wires = n;
+    pk.n_private = n - 16;
+    pk.log_domain = log_n;
+    pk.a_g1 = sets[0]; pk.b_g1 = sets[1]; pk.b_g2 = sets[2]; pk.k_g1 = sets[3]; pk.z_g1 = sets[4];
+    memcpy(pk.alpha_g1, BLS_G1, sizeof BLS_G1);
+    memcpy(pk.beta_g1, BLS_G1, sizeof BLS_G1);
+    memcpy(pk.delta_g1, BLS_G1, sizeof BLS_G1);
+    memcpy(pk.beta_g2, BLS_G2, sizeof BLS_G2);
+    memcpy(pk.delta_g2, BLS_G2, sizeof BLS_G2);
+  }
+  // one Groth16 proof -> bincode of CityGroth16ProofData
+  std::vector<uint8_t> prove(cp_ctx *ctx, uint64_t seed) {
+    auto check = [&](int rc, const char *what) { if (rc != CP_OK) throw std::runtime_error(std::string(what) + ": " + cp_last_error(ctx)); };
+    const size_t n = (size_t)1 << log_n;
+    for (auto &p : ev) check(cp_d2d(ctx, p, ev_master, n * 32), "cp_d2d");   // the prover overwrites its evaluation vectors
+    const uint64_t r[4] = {seed * 2 + 1, 11, 22, 33}, s[4] = {seed * 2 + 2, 44, 55, 66};
+    uint64_t a[12], b[24], c[12];
+    check(cp_groth16_prove_bls12381(ctx, &pk, (const uint64_t *)witness, (uint64_t *)ev[0], (uint64_t *)ev[1], (uint64_t *)ev[2], r, s, a, b, c),
+          "cp_groth16_prove_bls12381");
+    uint8_t packed[192];
+    if (cp_groth16_proof_pack_city(a, b, c, packed) != CP_OK) throw std::runtime_error(std::string("cp_groth16_proof_pack_city: ") + cp_last_error(nullptr));
+    std::vector<uint8_t> v;  // bincode: each Serialized2DFeltBLS12381 is a hex STRING (serde_with::hex::Hex): u64 length 96 + 96 characters
+    static const char *d = "0123456789abcdef";
+    for (int el = 0; el < 4; el++) {
+      const uint64_t len = 96;
+      v.insert(v.end(), (const uint8_t *)&len, (const uint8_t *)&len + 8);
+      for (int i = 0; i < 48; i++) { v.push_back((uint8_t)d[packed[48 * el + i] >> 4]); v.push_back((uint8_t)d[packed[48 * el + i] & 15]); }
+    }
+    return v;
+  }
+  void close(cp_ctx *ctx) {
+    for (auto *p : sets) if (p) cp_dev_free(ctx, p);
+    if (witness) cp_dev_free(ctx, witness);
+    if (ev_master) cp_dev_free(ctx, ev_master);
+    for (auto *p : ev) if (p) cp_dev_free(ctx, p);
+  }
+};
+
 // ---- a worker: one context, its own resident circuits, page-locked witnesses ----------------------------------------
 struct Worker {
   int index = 0, device = 0;
@@ -158,7 +246,9 @@ struct Worker {
   const qb::Pack *pack = nullptr;
   std::vector<cp_circuit *> circuits;   // pack circuit index -> resident circuit of this context
   std::vector<uint64_t *> wires;        // pack witness index -> page-locked copy of the wire matrix
-  size_t parity_checked = 0, proofs = 0;
+  size_t parity_checked = 0, proofs = 0, groth16_proofs = 0;
+  Groth16Stage groth16;
+  bool has_groth16 = false;
 
   void check(int rc, const char *what) const {
     if (rc != CP_OK) throw std::runtime_error(std::string(what) + ": " + cp_last_error(ctx));
@@ -213,6 +303,7 @@ struct Worker {
     return res;
   }
   void close() {
+    if (has_groth16) groth16.close(ctx);
     for (auto *w : wires) cp_host_free(ctx, w);
     for (auto *c : circuits) cp_circuit_destroy(c);
     if (ctx) cp_ctx_destroy(ctx);
@@ -259,7 +350,14 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const qb::P
       for (auto &o : outputs) o.assign(1, 0);  // placeholder: "an output exists"
     }
     if (first.circuit_type == qb::WrapFinalSigHashProofBLS12381)
-      for (auto &o : outputs) o = zero_groth16_bincode();  // GROTH16_DISABLED_DEV_MODE (toolbox/root.rs:287-294)
+      for (size_t i = 0; i < outputs.size(); i++) {
+        if (worker && worker->has_groth16) {  // the Groth16 prover kernels on a synthetic key (Groth16Stage)
+          outputs[i] = worker->groth16.prove(worker->ctx, batch[i].job.goal_id * 16 + batch[i].job.task_index);
+          worker->groth16_proofs++;
+        } else {
+          outputs[i] = zero_groth16_bincode();  // GROTH16_DISABLED_DEV_MODE (toolbox/root.rs:287-294)
+        }
+      }
   }
   const double t1 = now_s();
   const uint64_t ms = (uint64_t)((t1 - t0) * 1e3);
@@ -388,9 +486,15 @@ int run_qbench(const Options &opt) {
         workers[w].open(pack, devices[w / (size_t)opt.contexts], opt.lanes);
       }
       // warm-up = parity gate: every binding once on every worker (allocations, staging ring; bytes == recorded bytes)
-      for (auto &w : workers)
+      for (auto &w : workers) {
         for (const auto &kv : pack.by_type)
           for (const auto &b : kv.second) w.prove_stage(b, 1);
+        if (opt.groth16_log > 0) {
+          w.groth16.open(w.ctx, opt.groth16_log);
+          w.has_groth16 = true;
+          w.groth16.prove(w.ctx, 0);
+        }
+      }
     } catch (const std::exception &e) {
       die(e.what());
     }
@@ -466,19 +570,20 @@ int run_qbench(const Options &opt) {
     jobs += inst->jobs_done;
     proofs += inst->proofs_done;
   }
-  for (const auto &w : workers) parity += w.parity_checked;
+  size_t groth16_proofs = 0;
+  for (const auto &w : workers) { parity += w.parity_checked; groth16_proofs += w.groth16_proofs; }
   const double wall = t_end - t_begin;
   std::string devs;
   for (size_t i = 0; i < devices.size(); i++) devs += (i ? "," : "") + std::to_string(devices[i]);
   printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"%s\", \"dumps\": %zu, \"iterations\": %d, \"blocks\": %zu, \"blocks_complete\": %zu, "
          "\"jobs\": %zu, \"proofs\": %zu, \"jobs_per_block\": %.1f, \"proofs_per_block\": %.1f, \"wall_s\": %.6f, \"blocks_per_s\": %.4f, "
          "\"proofs_per_s\": %.2f, \"mean_block_latency_ms\": %.2f, \"devices\": [%s], \"contexts_per_device\": %d, \"workers\": %zu, "
-         "\"max_batch\": %d, \"blocks_in_flight\": %d, \"proofs_byte_checked\": %zu, \"pack\": \"%s\", \"timed\": \"from the first enqueue to the "
+         "\"max_batch\": %d, \"blocks_in_flight\": %d, \"proofs_byte_checked\": %zu, \"groth16_proofs\": %zu, \"groth16_log_constraints\": %d, \"pack\": \"%s\", \"timed\": \"from the first enqueue to the "
          "last completion; circuits resident, witnesses page-locked on the host (PCIe-inclusive), witness generation excluded\"}\n",
          opt.dry_run ? "dry-run" : "qbench", dumps.size(), opt.iterations, instances.size(), complete, jobs, proofs,
          instances.empty() ? 0.0 : (double)jobs / instances.size(), instances.empty() ? 0.0 : (double)proofs / instances.size(), wall,
          wall > 0 ? complete / wall : 0.0, wall > 0 ? proofs / wall : 0.0, complete ? latency_sum / complete * 1e3 : 0.0, devs.c_str(), opt.contexts,
-         n_workers, opt.batch, opt.blocks_in_flight, parity, json_escape(opt.pack_dir).c_str());
+         n_workers, opt.batch, opt.blocks_in_flight, parity, groth16_proofs, opt.groth16_log, json_escape(opt.pack_dir).c_str());
   for (auto &w : workers) w.close();
   return complete == instances.size() || opt.ref_counters ? 0 : 1;
 }
@@ -574,6 +679,7 @@ int main(int argc, char **argv) {
     else if (a == "--blocks-in-flight") opt.blocks_in_flight = atoi(val().c_str());
     else if (a == "--lanes") opt.lanes = atoi(val().c_str());
     else if (a == "--trace") opt.trace_path = val();
+    else if (a == "--groth16-log-size") opt.groth16_log = atoi(val().c_str());
     else if (a == "--dry-run") opt.dry_run = true;
     else if (a == "--ref-counters") opt.ref_counters = true;
     else if (a == "--check-plan") opt.check_plan = true;
@@ -590,6 +696,7 @@ int main(int argc, char **argv) {
       }
     } else die("unknown argument " + a);
   }
+  if (opt.groth16_log != 0 && (opt.groth16_log < 4 || opt.groth16_log > 26)) die("--groth16-log-size must be 0 (off) or 4..26");
   if (opt.iterations < 1 || opt.contexts < 1 || opt.batch < 1 || opt.blocks_in_flight < 1 || opt.iters < 1 || opt.lanes < 1) die("bad argument value");
   try {
     if (opt.mode == "qbench") return run_qbench(opt);
