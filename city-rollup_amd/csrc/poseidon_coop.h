@@ -17,6 +17,7 @@ constexpr int GROUP = 12;             // lanes per state
 constexpr int STATES_PER_WAVE = 5;    // 60 of 64 lanes
 constexpr int WAVES = 4;              // per workgroup (256 threads)
 constexpr int STATES_PER_BLOCK = STATES_PER_WAVE * WAVES;
+constexpr int RATE_ = 8;              // sponge rate
 
 // lane e of a group computes y_e = sum_j MDS[e][j] s_j with MDS[e][j] = C[(j - e) mod 12] (+ 8 on [0][0])
 __device__ __forceinline__ uint32_t mds_coef(int e, int j) {
@@ -81,6 +82,40 @@ __global__ __launch_bounds__(256) void k_level_coop(const uint64_t *__restrict__
   if (active && e < 8) x = child[8 * i + e];
   x = permute(x, lane_used ? g : 0, lane_used ? e : 0, lane_used, sh[wave], coef);
   if (active && e < 4) parent[4 * i + e] = x;
+}
+
+// FRI layer leaves for launches that cannot fill the chip (same layout as fri::k_leaf_hash_fri): leaf j = the `arity`
+// extension values at bit-reversed positions [arity*j, arity*(j+1)), flattened (a0, b0, a1, b1, ...), hashed by the
+// overwrite-mode sponge — 2*arity/8 chained permutations, 12 lanes per leaf. vals: [proof][re | im][n_vals].
+// grid = (ceil(n_leaves / 20), B), block = 256
+__global__ __launch_bounds__(256) void k_leaf_hash_fri_coop(const uint64_t *__restrict__ vals, size_t vals_stride, size_t n_vals, size_t n_leaves,
+                                                            int arity, uint64_t *__restrict__ digests, size_t dig_stride) {
+  __shared__ __attribute__((aligned(16))) uint64_t sh[WAVES][STATES_PER_WAVE * GROUP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / GROUP, e = lane - g * GROUP;
+  const bool lane_used = g < STATES_PER_WAVE;
+  const size_t j = (size_t)blockIdx.x * STATES_PER_BLOCK + wave * STATES_PER_WAVE + (lane_used ? g : 0);
+  const bool active = lane_used && j < n_leaves;
+  const uint64_t *re = vals + (size_t)blockIdx.y * vals_stride, *im = re + n_vals;
+  uint32_t coef[GROUP];
+#pragma unroll
+  for (int k = 0; k < GROUP; k++) coef[k] = mds_coef(lane_used ? e : 0, k);
+  const int len = 2 * arity;
+  // element `idx` of the flattened leaf
+  auto elem = [&](int idx) -> uint64_t { return (idx & 1) ? im[arity * j + (idx >> 1)] : re[arity * j + (idx >> 1)]; };
+  uint64_t x = 0;
+  if (len <= 4) {  // hash_or_noop: a leaf of at most four elements is its own digest
+    if (active && e < len) x = elem(e);
+  } else {
+    uint64_t nxt = (active && e < RATE_ && e < len) ? elem(e) : 0;
+    for (int e0 = 0; e0 < len; e0 += RATE_) {
+      if (e < RATE_ && e0 + e < len) x = nxt;  // overwrite the rate part with this chunk (a short last chunk keeps the rest)
+      const int n0 = e0 + RATE_;
+      nxt = (active && e < RATE_ && n0 + e < len) ? elem(n0 + e) : 0;  // fetched under the permutation
+      x = permute(x, lane_used ? g : 0, lane_used ? e : 0, lane_used, sh[wave], coef);
+    }
+  }
+  if (active && e < 4) digests[(size_t)blockIdx.y * dig_stride + 4 * j + e] = x;
 }
 
 }  // namespace pcoop
