@@ -150,18 +150,15 @@ def cpu_port_proof(prover, cores):
             "parity": "GPU proof bytes == oracle proof bytes (%d B)" % len(got)}
 
 
-def native_qbench(device, rank):
+def native_qbench(device, rank, pack):
     """Second half of BASELINE.json's metric, "block proofs/sec (qbench)", from the native harness (tools/cityprover_qbench:
     the reference's q-bench loop on a worker pool above the C ABI): the example dump replayed with 32 blocks in flight,
     one block alone, and the raw proofs/s mode — every proof compared with the oracle's bytes recorded in the pack."""
     import subprocess
     import tempfile
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import make_circuit_pack
     exe = os.path.join(ROOT, "tools", "cityprover_qbench")
     dump = os.path.join(ROOT, "tests", "golden", "qbench_example.bin")
     with tempfile.TemporaryDirectory(prefix="cpq%d_" % rank) as tmp:
-        pack = make_circuit_pack.make_pack(os.path.join(tmp, "pack"), n_circuits=4, db=12)
 
         def run(args):
             r = subprocess.run([exe] + args + ["--pack", pack, "--devices", str(device)], capture_output=True, text=True)
@@ -312,9 +309,20 @@ def main():
     # "block proofs/sec (qbench)": every rank runs the native harness on its own GPU (jobs shard by block, no collective)
     qb = None
     if not args.no_qbench:
+        # the synthetic circuit pack (4 circuits + witnesses + the oracle's proofs of them) is written once, by rank 0
+        import shutil
+        import tempfile
+        pack = os.path.join(tempfile.gettempdir(), "cityprover_pack_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
+        if rank == 0:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import make_circuit_pack
+            shutil.rmtree(pack, ignore_errors=True)
+            make_circuit_pack.make_pack(pack, n_circuits=4, db=12)
         barrier()
-        mine = native_qbench(device, rank)
+        mine = native_qbench(device, rank, pack)
         barrier()
+        if rank == 0:
+            shutil.rmtree(pack, ignore_errors=True)
         qb = dict(mine)
         for key in ("blocks_per_s", "proofs_per_s", "throughput_mode_proofs_per_s"):
             qb[key] = D.sum_over_ranks(dist, mine[key])
