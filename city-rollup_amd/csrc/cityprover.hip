@@ -63,8 +63,8 @@ int get_prescale_table(cp_ctx *ctx, int log_n, int rate_bits, uint64_t shift, co
 
 int upload_constants(cp_ctx *ctx) {
   HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_RC), POSEIDON_RC, sizeof POSEIDON_RC));
-  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_PK), POSEIDON_PLANE_K, sizeof POSEIDON_PLANE_K));
-  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_PLAST), POSEIDON_PLANE_LAST, sizeof POSEIDON_PLANE_LAST));
+  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DK), POSEIDON_DOM_K, sizeof POSEIDON_DOM_K));
+  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DLAST), POSEIDON_DOM_LAST, sizeof POSEIDON_DOM_LAST));
   return CP_OK;
 }
 

@@ -197,8 +197,10 @@ __global__ __launch_bounds__(256) void k_leaf_hash_fri(const uint64_t *__restric
 // order (next_range[proof], atomicAdd); a workgroup keeps taking ranges of "its" proof until a witness below the next
 // range is known (best[proof], atomicMin), then moves on to a proof that is still searching, and exits when none is.
 // So the chip stays full until the last proof is done, and the work beyond each proof's first witness is only what
-// was in flight when it was found. Ranges complete out of order, but a range is handed out only after all smaller
-// ones, and every range taken is finished: the minimum over all found witnesses is the smallest one.
+// was in flight when it was found — and that is dropped at the next round boundary of its permutation (`permute_until`
+// polls best[proof]): with ~400 K candidates resident, finishing them all cost as much again as the search itself.
+// Ranges complete out of order, but a range is handed out only after all smaller ones, and a range is abandoned only when a
+// witness BELOW it is known: the minimum over all found witnesses is the smallest one.
 // Exit: next_range only grows and is bounded by count / 256, so every workgroup runs out of work.
 struct PowState { uint64_t s[12]; int pos; int pad; };
 __global__ __launch_bounds__(256) void k_pow_grind(const PowState *__restrict__ st, uint64_t start, uint64_t count,
@@ -239,7 +241,10 @@ __global__ __launch_bounds__(256) void k_pow_grind(const PowState *__restrict__ 
 #pragma unroll
     for (int k = 0; k < 8; k++)
       if (k == pos) s[k] = cand;
-    poseidon::permute(s);
+    // a witness below this range has appeared: nothing in the range can be the smallest any more
+    const uint64_t range_start = start + ((uint64_t)r << 8);
+    const unsigned long long *bq = best + q;
+    if (!poseidon::permute_until(s, [=]() { return __hip_atomic_load(bq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < range_start; })) continue;
     if (pow_bits <= 0 || (s[7] >> (64 - pow_bits)) == 0) atomicMin(best + q, (unsigned long long)cand);
   }
 }

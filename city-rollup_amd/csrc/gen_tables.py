@@ -141,15 +141,20 @@ def fast_partial(RC):
     return first, K, vs, whats, init
 
 
-def plane_constants(RC):
-    """Partial-round constants pushed forward through the MDS (the form poseidon.h runs): round 0 of the partial
-    rounds gets its whole constant vector (folded into the preceding full round), round i >= 1 only a scalar K[i] on
-    element 0 — the rest of its vector commutes with the element-0 S-box and is carried through M into the next round —
-    and what is still pending after the last partial round, plus the next full round's constants, is LAST."""
+def plane_constants(RC, first_too=False):
+    """Partial-round constants pushed forward through the MDS: round 0 of the partial rounds gets its whole constant vector
+    (folded into the preceding full round), round i >= 1 only a scalar K[i] on element 0 — the rest of its vector commutes
+    with the element-0 S-box and is carried through M into the next round — and what is still pending after the last partial
+    round, plus the next full round's constants, is LAST. first_too (the form poseidon.h runs): round 0 is treated like the
+    others — K[0] on element 0, its other eleven constants pushed forward — so the last full round before the partial rounds
+    adds no constants at all."""
     M = mds_matrix()
     c = [RC[(RF_HALF + i) * W:(RF_HALF + i + 1) * W] for i in range(RP)]
     K = [0] * RP
     R = [0] * W
+    if first_too:
+        K[0] = c[0][0]
+        R = [0] + c[0][1:]
     for i in range(1, RP):
         pend = matvec(M, R)
         Pi = [(c[i][j] + pend[j]) % P for j in range(W)]
@@ -160,7 +165,7 @@ def plane_constants(RC):
     return K, [(nxt[j] + pend[j]) % P for j in range(W)]
 
 
-def perm_planes(s, RC, K, LAST):
+def perm_planes(s, RC, K, LAST, first_too=False):
     s = list(s)
     M = mds_matrix()
     r = 0
@@ -169,7 +174,8 @@ def perm_planes(s, RC, K, LAST):
         s = [pow(x, 7, P) for x in s]
         s = matvec(M, s)
         r += 1
-    s = [(s[i] + RC[r * W + i]) % P for i in range(W)]
+    if not first_too:
+        s = [(s[i] + RC[r * W + i]) % P for i in range(W)]
     for i in range(RP):
         s[0] = pow((s[0] + K[i]) % P, 7, P)
         s = matvec(M, s)
@@ -247,6 +253,16 @@ def main():
     out += "// partial-round constants pushed forward through the MDS (gen_tables.plane_constants)\n"
     out += c_array("POSEIDON_PLANE_K", PK)
     out += c_array("POSEIDON_PLANE_LAST", PLAST)
+    # for the transformed-domain partial rounds (poseidon.h): every partial round has only its scalar; the limb sums there are
+    # signed, so 2^30 is added to each of the three 22-bit limbs before the 96-bit recombination and taken out of the constant here
+    DK, DLAST = plane_constants(RC, first_too=True)
+    for _ in range(4):
+        s = [rnd.randrange(P) for _ in range(W)]
+        assert perm_planes(s, RC, DK, DLAST, first_too=True) == perm_naive(s, RC)
+    bias = (1 << 30) * (1 + (1 << 22) + (1 << 44)) % P
+    out += "// the same with the first partial round treated like the others, minus the limb bias 2^30 (1 + 2^22 + 2^44)\n"
+    out += c_array("POSEIDON_DOM_K", [(k - bias) % P for k in DK])
+    out += c_array("POSEIDON_DOM_LAST", [(k - bias) % P for k in DLAST])
     out += "// primitive 2^k-th roots of unity, k = 0..32 (7^((p-1)/2^k))\n"
     out += c_array("GL_ROOTS", roots)
     out += c_array("GL_ROOTS_INV", [pow(r, P - 2, P) for r in roots])

@@ -4,18 +4,21 @@
 // reference; call sites: city_crypto/src/hash/traits/hasher.rs:77-159 and every Merkle tree /
 // challenger use inside `CircuitData::prove`).
 //
-// One lane owns one 12-element state (24 VGPRs): no cross-lane traffic, pure 32-bit integer VALU.
-// What shapes the code (measured on MI355X, profiles/r01_*): `v_mad_u64_u32` is quarter rate
-// (8 cycles per wave64) and everything else is full rate (2 cycles), so
-//   * the S-box (x^7 = 4 modular multiplications, 14 mads) keeps 64-bit multiplies, but
+// One lane owns one 12-element state (24 VGPRs): no cross-lane traffic, pure 32-bit integer VALU, bound by instruction
+// issue. What shapes the code (measured on MI355X, profiles/r01_ubench_valu.txt, r02_ubench_poseidon.txt):
+//   * a 64-bit modular multiplication is 15 instructions: 4 `v_mad_u64_u32` for the product (the third takes the whole
+//     second as its addend and hands its carry-out on), 5 for `lo - w3` with its borrow, and ONE more multiply-add for
+//     `+ w2 (2^32 - 1)` whose carry-out selects the repair. The two carry-outs are out of the compiler's reach (it
+//     zero-extends and compares instead: 19 instructions), hence two three-line `asm` blocks in `mul_lazy` / `fold_top`;
 //   * the MDS layer (circulant, entries <= 41, + diag 8) uses NO multiplies at all: each element
 //     is split into three 22-bit limbs and the length-12 cyclic convolution is evaluated per limb
 //     in wrap-around 32-bit arithmetic through the CRT split
 //         x^12-1 = (x^6-1)(x^6+1),  x^6-1 = (x^3-1)(x^3+1)
 //     whose transformed kernels are all +-powers of two ([16,16,32], [-1,-8,2], [2,-4,16,1,-1,-1])
-//     -> ~96 shift-adds per limb instead of 288 quarter-rate mads per state.
+//     -> ~90 shift-adds per limb instead of 288 quarter-rate mads per state;
 //   * state is carried lazily (any u64 congruent to the value); the next round's constant is
-//     folded into the 96-bit recombination, and only the final output is canonicalised.
+//     folded into the 96-bit recombination, and only the final output is canonicalised;
+//   * the 22 partial rounds never leave the transformed domain of that CRT split (see `permute_until`).
 #pragma once
 #include "gl.h"
 #include "poseidon_tables.h"
@@ -38,29 +41,65 @@ GL_HD uint64_t rc(int i) {
   return POSEIDON_RC[i];
 #endif
 }
-// partial-round constants pushed forward through the MDS (see `permute`)
-__constant__ uint64_t d_PK[22];
-__constant__ uint64_t d_PLAST[12];
-GL_HD uint64_t plane_k(int i) {
+// partial-round constants pushed forward through the MDS (gen_tables.plane_constants): one scalar per partial round on
+// element 0, one vector after the last; both minus the limb bias of the signed recombination (DOM_BIAS)
+__constant__ uint64_t d_DK[PARTIAL];
+__constant__ uint64_t d_DLAST[W];
+GL_HD uint64_t dom_k(int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return d_PK[i];
+  return d_DK[i];
 #else
-  return POSEIDON_PLANE_K[i];
+  return POSEIDON_DOM_K[i];
 #endif
 }
-GL_HD uint64_t plane_last(int i) {
+GL_HD uint64_t dom_last(int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return d_PLAST[i];
+  return d_DLAST[i];
 #else
-  return POSEIDON_PLANE_LAST[i];
+  return POSEIDON_DOM_LAST[i];
 #endif
 }
 
 // ---- lazy field helpers: inputs/outputs are arbitrary u64 congruent to the value ----------
+// lo + top * (2^32 - 1) as a lazy u64 (top * 2^64 == top * (2^32 - 1))
+GL_HD uint64_t fold_top(uint64_t lo, uint32_t top) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // one multiply-add; its carry-out (one wrap of 2^64 == + EPS) selects the repair. The repaired sum cannot wrap again:
+  // lo + top (2^32 - 1) < 2^65 - 2^33, so after one wrap it is below 2^64 - 2^33.
+  uint64_t r, cy;
+  uint32_t m;
+  asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, -1, %1" : "=&v"(r), "=&s"(cy), "=v"(m) : "v"(top), "v"(lo));
+  return r + m;
+#else
+  const gl::u128 s = (gl::u128)lo + (((uint64_t)top << 32) - top);
+  return (uint64_t)s + ((0 - (uint64_t)(s >> 64)) & gl::EPS);
+#endif
+}
 GL_HD uint64_t mul_lazy(uint64_t a, uint64_t b) {
   uint64_t lo, hi;
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    // 64x64 -> 128: the third multiply-add takes the whole second one as its addend; its carry-out replaces two
+    // zero-extending moves and a 64-bit addition
+    const uint32_t a0 = gl::lo32(a), a1 = gl::hi32(a), b0 = gl::lo32(b), b1 = gl::hi32(b);
+    const uint64_t p00 = (uint64_t)a0 * b0;
+    const uint64_t q = (uint64_t)a0 * b1 + (p00 >> 32);  // < 2^64
+    uint64_t r, cr;
+    uint32_t cbit;
+    asm("v_mad_u64_u32 %0, %1, %3, %4, %5\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, 1, %1"
+        : "=&v"(r), "=&s"(cr), "=&v"(cbit)
+        : "v"(a1), "v"(b0), "v"(q));
+    lo = gl::pack(gl::lo32(p00), gl::lo32(r));
+    hi = (uint64_t)a1 * b1 + gl::pack(gl::hi32(r), cbit);
+  }
+#else
   gl::mul_wide(a, b, lo, hi);
-  return gl::reduce128_lazy(lo, hi);
+#endif
+  // lo - w3 + w2 (2^32 - 1)
+  const uint32_t w2 = gl::lo32(hi), w3 = gl::hi32(hi);
+  const gl::u128 t = (gl::u128)lo - w3;
+  const uint64_t t0 = (uint64_t)t - ((uint64_t)(t >> 64) & gl::EPS);
+  return fold_top(t0, w2);
 }
 GL_HD uint64_t sbox_lazy(uint64_t x) {
   const uint64_t x2 = mul_lazy(x, x), x4 = mul_lazy(x2, x2), x3 = mul_lazy(x, x2);
@@ -77,75 +116,79 @@ GL_HD uint64_t add_const_lazy(uint64_t a, uint64_t c) {  // c canonical
 
 // ---- MDS layer on one 22-bit limb plane, arithmetic mod 2^32 (exact: true results < 2^31) ----
 // y[r] = sum_i C[i] * s[(i+r) % 12] + 8*s[0]*[r==0],  C = {17,15,41,16,2,28,13,13,39,18,34,20}
-template <typename T>
-GL_HD void mds_limb(const T (&s)[W], T (&y)[W]) {
-  T a[6], b[6];
+// as T^-1' . K . T: T = two butterfly levels (`dom_enter`), K = three small component-wise products (`dom_mul`),
+// T^-1' = the butterflies back (`dom_leave`). Index layout of a transformed plane: [0..2] = aa, [3..5] = ab, [6..11] = b.
+GL_HD void dom_enter(const uint32_t (&s)[W], uint32_t (&u)[W]) {
+  uint32_t a[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     a[i] = s[i] + s[i + 6];
-    b[i] = s[i] - s[i + 6];
+    u[6 + i] = s[i] - s[i + 6];
   }
-  // cyclic-6 part: a (*) [15,24,18,17,40,14]  via  (x^3-1)(x^3+1)
-  T aa0 = a[0] + a[3], aa1 = a[1] + a[4], aa2 = a[2] + a[5];
-  T ab0 = a[0] - a[3], ab1 = a[1] - a[4], ab2 = a[2] - a[5];
-  T T16 = (aa0 + aa1 + aa2) << 4;
-  T E0 = T16 + (aa2 << 4), E1 = T16 + (aa0 << 4), E2 = T16 + (aa1 << 4);
-  T F0 = (ab2 << 3) - ab0 - (ab1 << 1);
-  T F1 = (T)0 - (ab0 << 3) - ab1 - (ab2 << 1);
-  T F2 = (ab0 << 1) - (ab1 << 3) - ab2;
-  T pc[6] = {E0 + F0, E1 + F1, E2 + F2, E0 - F0, E1 - F1, E2 - F2};
-  // negacyclic-6 part: b (*) [2,-4,16,1,-1,-1] mod (x^6+1)
-  // V[k] = sum_{i+j=k} b[i]N[j] - sum_{i+j=k+6} b[i]N[j]
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    u[i] = a[i] + a[i + 3];
+    u[3 + i] = a[i] - a[i + 3];
+  }
+}
+GL_HD void dom_mul(const uint32_t (&u)[W], uint32_t (&o)[W]) {
+  typedef uint32_t T;
+  // cyclic-3 part: aa (*) [16,16,32]
+  const T T16 = (u[0] + u[1] + u[2]) << 4;
+  o[0] = T16 + (u[2] << 4);
+  o[1] = T16 + (u[0] << 4);
+  o[2] = T16 + (u[1] << 4);
+  // negacyclic-3 part: ab (*) [-1,-8,2]
+  o[3] = (u[5] << 3) - u[3] - (u[4] << 1);
+  o[4] = (T)0 - (u[3] << 3) - u[4] - (u[5] << 1);
+  o[5] = (u[3] << 1) - (u[4] << 3) - u[5];
+  // negacyclic-6 part: b (*) N mod (x^6+1), N = [2,-4,16,1,-1,-1]:  v[k] = sum_{i+j=k} b[i]N[j] - sum_{i+j=k+6} b[i]N[j]
+  const T *b = &u[6];
   T nb[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) nb[i] = (T)0 - b[i];
-  T v[6];
-  // N0=2 (<<1), N1=-4 (<<2, neg), N2=16 (<<4), N3=1, N4=-1, N5=-1
-  // k=0: b0N0 - (b1N5 + b2N4 + b3N3 + b4N2 + b5N1)
-  v[0] = (b[0] << 1) + b[1] + b[2] + nb[3] + (nb[4] << 4) + (b[5] << 2);
-  // k=1: b0N1 + b1N0 - (b2N5 + b3N4 + b4N3 + b5N2)
-  v[1] = (nb[0] << 2) + (b[1] << 1) + b[2] + b[3] + nb[4] + (nb[5] << 4);
-  // k=2: b0N2 + b1N1 + b2N0 - (b3N5 + b4N4 + b5N3)
-  v[2] = (b[0] << 4) + (nb[1] << 2) + (b[2] << 1) + b[3] + b[4] + nb[5];
-  // k=3: b0N3 + b1N2 + b2N1 + b3N0 - (b4N5 + b5N4)
-  v[3] = b[0] + (b[1] << 4) + (nb[2] << 2) + (b[3] << 1) + b[4] + b[5];
-  // k=4: b0N4 + b1N3 + b2N2 + b3N1 + b4N0 - (b5N5)
-  v[4] = nb[0] + b[1] + (b[2] << 4) + (nb[3] << 2) + (b[4] << 1) + b[5];
-  // k=5: b0N5 + b1N4 + b2N3 + b3N2 + b4N1 + b5N0
-  v[5] = nb[0] + nb[1] + b[2] + (b[3] << 4) + (nb[4] << 2) + (b[5] << 1);
+  o[6] = (b[0] << 1) + b[1] + b[2] + nb[3] + (nb[4] << 4) + (b[5] << 2);
+  o[7] = (nb[0] << 2) + (b[1] << 1) + b[2] + b[3] + nb[4] + (nb[5] << 4);
+  o[8] = (b[0] << 4) + (nb[1] << 2) + (b[2] << 1) + b[3] + b[4] + nb[5];
+  o[9] = b[0] + (b[1] << 4) + (nb[2] << 2) + (b[3] << 1) + b[4] + b[5];
+  o[10] = nb[0] + b[1] + (b[2] << 4) + (nb[3] << 2) + (b[4] << 1) + b[5];
+  o[11] = nb[0] + nb[1] + b[2] + (b[3] << 4) + (nb[4] << 2) + (b[5] << 1);
+}
+GL_HD void dom_leave(const uint32_t (&o)[W], uint32_t (&y)[W]) {
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
-    y[i] = pc[i] + v[i];
-    y[i + 6] = pc[i] - v[i];
+  for (int i = 0; i < 3; i++) {
+    const uint32_t p = o[i] + o[3 + i], q = o[i] - o[3 + i];
+    y[i] = p + o[6 + i];
+    y[i + 6] = p - o[6 + i];
+    y[i + 3] = q + o[9 + i];
+    y[i + 9] = q - o[9 + i];
   }
+}
+GL_HD void mds_limb(const uint32_t (&s)[W], uint32_t (&y)[W]) {
+  uint32_t u[W], o[W];
+  dom_enter(s, u);
+  dom_mul(u, o);
+  dom_leave(o, y);
   y[0] += s[0] << 3;
 }
 
-// y = y0 + 2^22 y1 + 2^44 y2 + c  (y* < 2^31, c < 2^64)  ->  lazy u64
+// y = y0 + 2^22 y1 + 2^44 y2 + c  (y* < 2^32, c < 2^64)  ->  lazy u64
 GL_HD uint64_t recombine(uint32_t y0, uint32_t y1, uint32_t y2, uint64_t c) {
-  uint64_t v = (uint64_t)y0 + ((uint64_t)y1 << 22);  // < 2^54
-  uint64_t w_lo = (uint64_t)y2 << 44;
-  uint32_t top = y2 >> 20;                            // weight 2^64
-  uint64_t t = v + w_lo;
-  top += (t < w_lo);
-  uint64_t t2 = t + c;
-  top += (t2 < c);
-  uint64_t u = ((uint64_t)top << 32) - top;           // top * (2^32 - 1)
-  uint64_t r = t2 + u;
-  if (r < u) r += gl::EPS;
-  return r;
+  const gl::u128 acc = (gl::u128)c + y0 + ((uint64_t)y1 << 22) + ((gl::u128)y2 << 44);  // < 2^77: plain carry chains
+  return fold_top((uint64_t)acc, (uint32_t)(acc >> 64));
+}
+GL_HD void split3(uint64_t v, uint32_t &a, uint32_t &b, uint32_t &c) {
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  a = lo & 0x3FFFFFu;
+  b = ((lo >> 22) | (hi << 10)) & 0x3FFFFFu;
+  c = hi >> 12;
 }
 
 // s <- MDS * s + next_rc   (next_rc_base < 0: no constant)
 GL_HD void mds_layer(uint64_t (&s)[W], int next_rc_base) {
   uint32_t l0[W], l1[W], l2[W];
 #pragma unroll
-  for (int i = 0; i < W; i++) {
-    uint32_t lo = (uint32_t)s[i], hi = (uint32_t)(s[i] >> 32);
-    l0[i] = lo & 0x3FFFFFu;
-    l1[i] = ((lo >> 22) | (hi << 10)) & 0x3FFFFFu;
-    l2[i] = hi >> 12;
-  }
+  for (int i = 0; i < W; i++) split3(s[i], l0[i], l1[i], l2[i]);
   uint32_t y0[W], y1[W], y2[W];
   mds_limb(l0, y0);
   mds_limb(l1, y1);
@@ -181,67 +224,132 @@ GL_HD void permute_textbook(uint64_t (&s)[W]) {
   for (int i = 0; i < W; i++) s[i] = gl::canon(s[i]);
 }
 
-// ---- partial rounds with the state resident in limb planes ------------------------------------------------
-// Only element 0 meets an S-box in a partial round; the other eleven go from one MDS straight into the next.
-// They therefore stay in their three 22-bit limb planes for all 22 rounds: after each MDS a carry
-// normalisation (13 integer ops per element) replaces recombine-to-u64 + split-again (24), and they need no
-// round constants at all — those are pushed forward through the MDS offline (gen_tables.plane_constants:
-// a scalar K[i] on element 0 per round, one vector LAST at the end).
-GL_HD void split3(uint64_t v, uint32_t &a, uint32_t &b, uint32_t &c) {
-  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-  a = lo & 0x3FFFFFu;
-  b = ((lo >> 22) | (hi << 10)) & 0x3FFFFFu;
-  c = hi >> 12;
+// ---- partial rounds in the transformed domain of the circulant --------------------------------------------
+// Only element 0 meets an S-box in a partial round; the other eleven go from one MDS straight into the next, and they
+// need no round constants at all — those are pushed forward through the MDS offline (gen_tables.plane_constants: one
+// scalar per round on element 0, one vector at the end). Between two MDS layers T . T^-1' is only a scaling: if
+// o = (E, F, v) are the products of one layer, the next layer's transformed input is T(y) = (4E, 4F, 2v). So the state
+// stays in the domain for all 22 rounds, as three limb planes of field elements mod p with SIGNED limbs:
+//   * per round and plane the 36 butterfly additions are gone; the scaling is folded into the carry normalisation
+//     (`renorm_scaled`), which also replaces recombine-to-u64 + split-again;
+//   * element 0 of the state is read off the products as E0 + F0 + v0 + 8 * (previous S-box output) — exact integer
+//     limbs — recombined, S-boxed, split; the difference to what the domain holds for it is added to aa0, ab0, b0 (T of the
+//     unit vector) before those three components are normalised;
+//   * a negative top limb folds like a positive one (2^64 == 2^32 - 1: + top 2^10 on plane 1, - top on plane 0), so the
+//     normalisation needs no borrow handling.
+// Magnitudes: normalised limbs lie in (-2^19, 2^22 + 2^19) (top limb [0, 2^20)); |products| <= 64 x that < 2^28.2, times 4
+// < 2^30.2; the element-0 components before their normalisation < 2^30.2 + 2^28.3 + 2^25 < 2^31. Entering from the full
+// rounds (limbs < 2^22, so aa < 2^24 would give products up to 2^30) the three aa components are normalised first.
+// tests/test_hostsim.py checks the bounds with interval arithmetic and the permutation against the oracle.
+constexpr uint32_t DOM_BIAS = 1u << 30;  // makes the signed element-0 limbs (|.| < 2^29) non-negative for `recombine`
+// signed carry normalisation in place: |y*| <= 2^31 - 2^10, same value mod p
+GL_HD void renorm_s(uint32_t &y0, uint32_t &y1, uint32_t &y2) {
+  const int32_t t1 = (int32_t)y1 + ((int32_t)y0 >> 22);
+  const int32_t t2 = (int32_t)y2 + (t1 >> 22);
+  const int32_t top = t2 >> 20;
+  y0 = (y0 & 0x3FFFFFu) - (uint32_t)top;
+  y1 = ((uint32_t)t1 & 0x3FFFFFu) + ((uint32_t)top << 10);
+  y2 = (uint32_t)t2 & 0xFFFFFu;
 }
-// MDS outputs of one element (y0, y1 < 2^31.1, y2 < 2^28.1) -> limbs l0, l1 < 2^23, l2 < 2^20 of a congruent value.
-// The part above 2^64 (top) is folded with 2^64 == 2^32 - 1: +top*2^10 on plane 1, -top on plane 0, the latter
-// paid for by borrowing one unit of plane 1 (only when top != 0, so nothing ever goes negative).
-GL_HD void renorm(uint32_t y0, uint32_t y1, uint32_t y2, uint32_t &l0, uint32_t &l1, uint32_t &l2) {
-  const uint32_t t1 = y1 + (y0 >> 22);
-  const uint32_t t2 = y2 + (t1 >> 22);
-  const uint32_t top = t2 >> 20;
-  const uint32_t adj = top < 1u ? top : 1u;
-  l0 = (y0 & 0x3FFFFFu) + (adj << 22) - top;
-  l1 = (t1 & 0x3FFFFFu) + (top << 10) - adj;
-  l2 = t2 & 0xFFFFFu;
+// the same for 2^S * (o0, o1, o2), 2^S |o*| <= 2^31 - 2^10, without forming the scaled limbs
+template <int S>
+GL_HD void renorm_scaled(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t &l0, uint32_t &l1, uint32_t &l2) {
+  const int32_t t1 = (int32_t)(o1 << S) + ((int32_t)o0 >> (22 - S));
+  const int32_t t2 = (int32_t)(o2 << S) + (t1 >> 22);
+  const int32_t top = t2 >> 20;
+  l0 = ((o0 << S) & 0x3FFFFFu) - (uint32_t)top;
+  l1 = ((uint32_t)t1 & 0x3FFFFFu) + ((uint32_t)top << 10);
+  l2 = (uint32_t)t2 & 0xFFFFFu;
 }
 
-GL_HD void permute(uint64_t (&s)[W]) {
+// `stop` is polled between rounds (every full round, every fourth partial round); when it answers true the permutation is
+// abandoned and false returned. It must answer the same for every lane of a wave. The proof-of-work search uses it to drop
+// candidates that can no longer be the smallest witness.
+template <typename Stop>
+GL_HD bool permute_until(uint64_t (&s)[W], Stop stop) {
 #pragma unroll
   for (int i = 0; i < W; i++) s[i] = add_const_lazy(s[i], rc(i));
 #pragma unroll 1
-  for (int r = 0; r < HALF_FULL; r++) {
+  for (int r = 0; r < HALF_FULL - 1; r++) {
+    if (stop()) return false;
 #pragma unroll
     for (int i = 0; i < W; i++) s[i] = sbox_lazy(s[i]);
-    mds_layer(s, (r + 1) * W);  // r = 3: adds the whole constant vector of the first partial round
+    mds_layer(s, (r + 1) * W);
   }
   {
-    uint32_t l0[W], l1[W], l2[W], y0[W], y1[W], y2[W];
+    // the last full round before the partial rounds: S-boxes, then straight into the domain (no constants: all pushed forward)
+    uint32_t u0[W], u1[W], u2[W], o0[W], o1[W], o2[W];
+    uint32_t n0, n1, n2;  // limbs of the latest S-box output on element 0
+    {
+      uint32_t l0[W], l1[W], l2[W];
 #pragma unroll
-    for (int k = 1; k < W; k++) split3(s[k], l0[k], l1[k], l2[k]);
-    uint64_t x0 = s[0];
+      for (int k = 0; k < W; k++) {
+        s[k] = sbox_lazy(s[k]);
+        split3(s[k], l0[k], l1[k], l2[k]);
+      }
+      n0 = l0[0], n1 = l1[0], n2 = l2[0];
+      dom_enter(l0, u0);
+      dom_enter(l1, u1);
+      dom_enter(l2, u2);
+#pragma unroll
+      for (int k = 0; k < 3; k++) renorm_s(u0[k], u1[k], u2[k]);
+      dom_mul(u0, o0);
+      dom_mul(u1, o1);
+      dom_mul(u2, o2);
+    }
 #pragma unroll 1
     for (int i = 0; i < PARTIAL; i++) {
-      x0 = sbox_lazy(x0);
-      split3(x0, l0[0], l1[0], l2[0]);
-      mds_limb(l0, y0);
-      mds_limb(l1, y1);
-      mds_limb(l2, y2);
+      if ((i & 3) == 0 && stop()) return false;
+      // element 0 of the state: E0 + F0 + v0 + the diagonal 8 of the MDS on the previous S-box output
+      const uint32_t z0 = o0[0] + o0[3] + o0[6], z1 = o1[0] + o1[3] + o1[6], z2 = o2[0] + o2[3] + o2[6];
+      const uint64_t x = recombine(z0 + (n0 << 3) + DOM_BIAS, z1 + (n1 << 3) + DOM_BIAS, z2 + (n2 << 3) + DOM_BIAS, dom_k(i));
+      split3(sbox_lazy(x), n0, n1, n2);
+      // the nine components that do not see element 0 directly: scale and normalise
 #pragma unroll
-      for (int k = 0; k < W; k++) renorm(y0[k], y1[k], y2[k], l0[k], l1[k], l2[k]);
-      if (i + 1 < PARTIAL) x0 = recombine(l0[0], l1[0], l2[0], plane_k(i + 1));
+      for (int k = 1; k < 3; k++) {
+        renorm_scaled<2>(o0[k], o1[k], o2[k], u0[k], u1[k], u2[k]);
+        renorm_scaled<2>(o0[3 + k], o1[3 + k], o2[3 + k], u0[3 + k], u1[3 + k], u2[3 + k]);
+      }
+#pragma unroll
+      for (int k = 7; k < W; k++) renorm_scaled<1>(o0[k], o1[k], o2[k], u0[k], u1[k], u2[k]);
+      // aa0, ab0, b0: scaled products + diagonal + (new element 0 - old element 0) = scaled products + new - z
+      {
+        const uint32_t d0 = n0 - z0, d1 = n1 - z1, d2 = n2 - z2;
+        u0[0] = (o0[0] << 2) + d0, u0[3] = (o0[3] << 2) + d0, u0[6] = (o0[6] << 1) + d0;
+        u1[0] = (o1[0] << 2) + d1, u1[3] = (o1[3] << 2) + d1, u1[6] = (o1[6] << 1) + d1;
+        u2[0] = (o2[0] << 2) + d2, u2[3] = (o2[3] << 2) + d2, u2[6] = (o2[6] << 1) + d2;
+        renorm_s(u0[0], u1[0], u2[0]);
+        renorm_s(u0[3], u1[3], u2[3]);
+        renorm_s(u0[6], u1[6], u2[6]);
+      }
+      dom_mul(u0, o0);
+      dom_mul(u1, o1);
+      dom_mul(u2, o2);
     }
+    // leave the domain: natural limbs (signed, |.| < 2^29), + what is pending of the constants
+    uint32_t y0[W], y1[W], y2[W];
+    dom_leave(o0, y0);
+    dom_leave(o1, y1);
+    dom_leave(o2, y2);
+    y0[0] += n0 << 3, y1[0] += n1 << 3, y2[0] += n2 << 3;
 #pragma unroll
-    for (int k = 0; k < W; k++) s[k] = recombine(l0[k], l1[k], l2[k], plane_last(k));
+    for (int k = 0; k < W; k++) s[k] = recombine(y0[k] + DOM_BIAS, y1[k] + DOM_BIAS, y2[k] + DOM_BIAS, dom_last(k));
   }
 #pragma unroll 1
   for (int r = HALF_FULL + PARTIAL; r < ROUNDS; r++) {
+    if (stop()) return false;
 #pragma unroll
     for (int i = 0; i < W; i++) s[i] = sbox_lazy(s[i]);
     mds_layer(s, r + 1 < ROUNDS ? (r + 1) * W : -1);
   }
 #pragma unroll
   for (int i = 0; i < W; i++) s[i] = gl::canon(s[i]);
+  return true;
 }
+
+struct NeverStop {
+  GL_HD bool operator()() const { return false; }
+};
+GL_HD void permute(uint64_t (&s)[W]) { permute_until(s, NeverStop()); }
 
 }  // namespace poseidon

@@ -21,8 +21,23 @@ void hs_poseidon_permute_textbook(uint64_t *states, size_t n) {
     for (int k = 0; k < 12; k++) states[12 * i + k] = s[k];
   }
 }
-// carry normalisation of the plane-resident partial rounds: returns the limbs; value must be preserved mod p
-void hs_renorm(const uint32_t *y, uint32_t *l) { poseidon::renorm(y[0], y[1], y[2], l[0], l[1], l[2]); }
+// signed carry normalisations of the transformed-domain partial rounds: return the limbs; the value must be preserved mod p
+void hs_renorm(const uint32_t *y, uint32_t *l) {
+  l[0] = y[0], l[1] = y[1], l[2] = y[2];
+  poseidon::renorm_s(l[0], l[1], l[2]);
+}
+void hs_renorm_scaled(int s, const uint32_t *y, uint32_t *l) {
+  if (s == 2) poseidon::renorm_scaled<2>(y[0], y[1], y[2], l[0], l[1], l[2]);
+  else poseidon::renorm_scaled<1>(y[0], y[1], y[2], l[0], l[1], l[2]);
+}
+void hs_dom(int op, const uint32_t *s, uint32_t *y) {  // 0: dom_enter, 1: dom_mul, 2: dom_leave
+  uint32_t a[12], b[12];
+  for (int i = 0; i < 12; i++) a[i] = s[i];
+  if (op == 0) poseidon::dom_enter(a, b);
+  else if (op == 1) poseidon::dom_mul(a, b);
+  else poseidon::dom_leave(a, b);
+  for (int i = 0; i < 12; i++) y[i] = b[i];
+}
 uint64_t hs_mul(uint64_t a, uint64_t b) { return gl::mul(a, b); }
 uint64_t hs_mul_lazy(uint64_t a, uint64_t b) { return poseidon::mul_lazy(a, b); }
 uint64_t hs_add(uint64_t a, uint64_t b) { return gl::add(a, b); }

@@ -112,21 +112,80 @@ def test_plane_resident_permute_equals_textbook(hs):
     assert (a == O.permute_many(st).reshape(-1, 12)).all()
 
 
-def test_renorm_preserves_the_value_and_bounds(hs):
-    """Carry normalisation of MDS outputs: limbs within their bounds, value congruent mod p, for extreme inputs."""
-    hs.hs_renorm.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 2
+def _s32(v):
+    v &= 0xFFFFFFFF
+    return v - (1 << 32) if v >> 31 else v
+
+
+def test_signed_renorms_preserve_the_value_and_bounds(hs):
+    """Carry normalisations of the transformed-domain partial rounds (signed limbs): limbs within their bounds, value
+    congruent mod p — plain and with the scaling by 4 / 2 folded in — for extreme and random inputs."""
+    p32 = ctypes.POINTER(ctypes.c_uint32)
+    hs.hs_renorm.argtypes = [p32] * 2
+    hs.hs_renorm_scaled.argtypes = [ctypes.c_int, p32, p32]
     rng = np.random.default_rng(3)
-    hi01, hi2 = 264 * (1 << 23), 264 * (1 << 20)     # largest outputs the MDS can produce from normalised limbs
-    cases = [(0, 0, 0), (hi01 - 1, hi01 - 1, hi2 - 1), (0, 0, hi2 - 1), ((1 << 22) - 1, (1 << 22) - 1, (1 << 20) - 1),
-             (0, 0, 1 << 20), (5, 0, 1 << 20), (0, (1 << 22) - 1, (1 << 20) - 1), ((1 << 22), 0, 0)]
-    cases += [(int(rng.integers(0, hi01)), int(rng.integers(0, hi01)), int(rng.integers(0, hi2))) for _ in range(2000)]
+    B = (1 << 31) - (1 << 10)                            # the contract: |y*| <= 2^31 - 2^10 (the carries added stay in range)
+    cases = [(0, 0, 0), (B, B, B), (-B, -B, -B), (B, -B, B), (-B, B, -B), (0, 0, 1 << 20), (5, 0, -(1 << 20)), (-1, 0, 0), (0, -1, 0),
+             (0, 0, -1), ((1 << 22) - 1, (1 << 22) - 1, (1 << 20) - 1), (1 << 22, 0, 0)]
+    cases += [tuple(int(v) for v in rng.integers(-B, B, 3)) for _ in range(3000)]
+    lim = (1 << 22) + (1 << 21) + (1 << 12)
     for y in cases:
-        yy = (ctypes.c_uint32 * 3)(*y)
-        ll = (ctypes.c_uint32 * 3)()
-        hs.hs_renorm(yy, ll)
-        l0, l1, l2 = ll[0], ll[1], ll[2]
-        assert l0 < (1 << 23) and l1 < (1 << 23) and l2 < (1 << 20), (y, l0, l1, l2)
-        assert (l0 + (l1 << 22) + (l2 << 44)) % P == (y[0] + (y[1] << 22) + (y[2] << 44)) % P, y
+        for scale in (0, 1, 2):
+            yy = tuple(v >> scale for v in y) if scale else y          # |o| < 2^(31 - S)
+            arr = (ctypes.c_uint32 * 3)(*[v & 0xFFFFFFFF for v in yy])
+            ll = (ctypes.c_uint32 * 3)()
+            if scale:
+                hs.hs_renorm_scaled(scale, arr, ll)
+            else:
+                hs.hs_renorm(arr, ll)
+            l0, l1, l2 = _s32(ll[0]), _s32(ll[1]), _s32(ll[2])
+            assert -(1 << 12) < l0 < (1 << 22) + (1 << 12) and -lim < l1 < lim and 0 <= l2 < (1 << 20), (y, scale, l0, l1, l2)
+            assert (l0 + (l1 << 22) + (l2 << 44)) % P == ((yy[0] + (yy[1] << 22) + (yy[2] << 44)) << scale) % P, (y, scale)
+
+
+def test_transformed_domain_identities(hs):
+    """T^-1' . K . T is the MDS without its diagonal, and T . T^-1' scales by (4, 4, 2): what the partial rounds rest on."""
+    p32 = ctypes.POINTER(ctypes.c_uint32)
+    hs.hs_dom.argtypes = [ctypes.c_int, p32, p32]
+    C = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
+    rng = np.random.default_rng(4)
+
+    def dom(op, v):
+        a = (ctypes.c_uint32 * 12)(*[int(x) & 0xFFFFFFFF for x in v])
+        b = (ctypes.c_uint32 * 12)()
+        hs.hs_dom(op, a, b)
+        return [_s32(x) for x in b]
+    for _ in range(200):
+        s = [int(x) for x in rng.integers(-(1 << 19), 1 << 19, 12)]   # T(y) below sums four outputs: keep them in 32 bits
+        o = dom(1, dom(0, s))
+        y = dom(2, o)
+        assert y == [sum(C[i] * s[(i + r) % 12] for i in range(12)) for r in range(12)]
+        t = dom(0, y)
+        assert t == [4 * v for v in o[:6]] + [2 * v for v in o[6:]]
+        assert y[0] == o[0] + o[3] + o[6]
+
+
+def test_transformed_domain_magnitudes():
+    """Worst-case magnitudes of the partial rounds (poseidon.h `permute_until`) by interval arithmetic: nothing leaves the
+    signed 32-bit range, and the element-0 limbs stay below the bias of the recombination."""
+    top_max = (1 << 9)                                    # |t2| < 2^28.3 + carry  ->  |top| <= 2^8.3 + 1
+    L0 = (1 << 22) + top_max                              # normalised limb 0: (-top, 2^22 + top)
+    L1 = (1 << 22) + (top_max << 10)                      # normalised limb 1
+    L = max(L0, L1)
+    prod = {"aa": 64 * L, "ab": 11 * L, "b": 25 * L}      # |dom_mul| per class: sums of |kernel| x max input
+    assert max(prod.values()) < 1 << 29                   # renorm_scaled<2> needs |o| < 2^29, <1> needs < 2^30
+    z = prod["aa"] + prod["ab"] + prod["b"]               # E0 + F0 + v0
+    assert z + 8 * (1 << 22) < 1 << 30                    # element-0 limbs + diagonal: below DOM_BIAS, so + bias < 2^31
+    n = 1 << 22
+    for cls, sh in (("aa", 2), ("ab", 2), ("b", 1)):
+        assert (prod[cls] << sh) + n + z < 1 << 31        # aa0 / ab0 / b0 before their normalisation
+    # the top limb plane: inputs in [0, 2^20), so |t2| and the fold stay as small as assumed above
+    t2 = 4 * 64 * (1 << 20) + (1 << 10)
+    assert (t2 >> 20) + 1 <= top_max
+    # entry from the full rounds: limbs < 2^22; aa (sums of four) is normalised before the first products
+    assert 64 * L < 1 << 29 and 11 * (2 << 22) < 1 << 29 and 25 * (1 << 22) < 1 << 30
+    # leaving: natural limbs |E + F + v| + 8 n, again below the bias
+    assert z + 8 * n < 1 << 30
 
 
 # ---- BLS12-381 device formulas (csrc/bls12_381.h) on the host ------------------------------------------------

@@ -171,6 +171,11 @@ def test_one_block_end_to_end_with_byte_parity(golden_dir, tmp_path):
     # the all-zero dev-mode proof: three per block
     res = run(["-i", dump, "--pack", pack, "--contexts", "2", "--batch", "8", "--groth16-log-size", "10"])
     assert res["blocks_complete"] == 1 and res["groth16_proofs"] == 3 and res["groth16_log_constraints"] == 10
+    # the worker pool over a device LIST (section 8(e)): the one GPU of the test box named twice gives two device entries,
+    # each with its own contexts and resident circuits, all four workers on the one ready queue
+    res = run(["-i", dump, "-n", "2", "--blocks-in-flight", "2", "--pack", pack, "--devices", "0,0", "--contexts", "2", "--batch", "8",
+               "--check-plan"])
+    assert res["blocks_complete"] == 2 and res["workers"] == 4 and res["devices"] == [0, 0] and res["proofs_byte_checked"] >= 128
     # a tampered witness file (recorded proof altered) is caught by the byte comparison
     wit = os.path.join(pack, "synthetic_0.cpwit")
     from cityprover import files

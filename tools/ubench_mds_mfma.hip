@@ -208,8 +208,8 @@ static float best_ms(Fn launch) {
 
 int main() {
   hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_RC), POSEIDON_RC, sizeof POSEIDON_RC);
-  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_PK), POSEIDON_PLANE_K, sizeof POSEIDON_PLANE_K);
-  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_PLAST), POSEIDON_PLANE_LAST, sizeof POSEIDON_PLANE_LAST);
+  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DK), POSEIDON_DOM_K, sizeof POSEIDON_DOM_K);
+  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DLAST), POSEIDON_DOM_LAST, sizeof POSEIDON_DOM_LAST);
   const int blocks = 256 * 16;
   const size_t n = (size_t)blocks * 256;
   uint64_t *a, *b;

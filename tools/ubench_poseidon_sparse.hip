@@ -139,8 +139,8 @@ int main() {
   uint64_t *a, *b;
   hipMalloc(&a, n * 8);
   hipMalloc(&b, n * 8);
-  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_PK), POSEIDON_PLANE_K, sizeof POSEIDON_PLANE_K);
-  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_PLAST), POSEIDON_PLANE_LAST, sizeof POSEIDON_PLANE_LAST);
+  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DK), POSEIDON_DOM_K, sizeof POSEIDON_DOM_K);
+  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DLAST), POSEIDON_DOM_LAST, sizeof POSEIDON_DOM_LAST);
   uint64_t *c;
   hipMalloc(&c, n * 8);
   hipLaunchKernelGGL(sp::k_chain<0>, dim3(blocks), dim3(256), 0, 0, a, 12345ull, 3);
