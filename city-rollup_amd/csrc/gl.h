@@ -6,7 +6,7 @@
 // values may be carried "lazily" as any u64 congruent to the value.
 //
 // CDNA4 has no 64x64->128 multiply: the product is built from v_mad_u64_u32 and the
-// reduction uses 2^64 == 2^32-1 and 2^96 == -1 (mod p), i.e. only adds/subs/shifts.
+// reduction uses 2^64 == 2^32-1 and 2^96 == -1 (mod p).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -49,26 +49,58 @@ GL_HD uint64_t add_lazy(uint64_t a, uint64_t b) {
   return s;
 }
 
+// A modular multiplication is 15 VALU instructions on gfx950: 4 v_mad_u64_u32 for the product, 5 for `lo - w3` with its
+// borrow, one more multiply-add for `+ w2 (2^32 - 1)`. Two of the multiply-adds are written as `asm`: their carry-outs are
+// out of the compiler's reach (it zero-extends, adds and compares instead: 19 instructions; measured +6 % on the
+// Poseidon permutation, tools/ubench_poseidon_variants.hip). The `s_nop 1` are the two wait states gfx950 needs between a
+// VALU write of an SGPR and a VALU read of it; the compiler's hazard recogniser does not look inside `asm`.
+
+// lo + top * (2^32 - 1) as a lazy u64 (top * 2^64 == top * (2^32 - 1))
+GL_HD uint64_t fold_top(uint64_t lo, uint32_t top) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // one multiply-add; its carry-out (one wrap of 2^64 == + EPS) selects the repair. The repaired sum cannot wrap again:
+  // lo + top (2^32 - 1) < 2^65 - 2^33, so after one wrap it is below 2^64 - 2^33.
+  uint64_t r, cy;
+  uint32_t m;
+  asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, -1, %1" : "=&v"(r), "=&s"(cy), "=v"(m) : "v"(top), "v"(lo));
+  return r + m;
+#else
+  const u128 s = (u128)lo + (((uint64_t)top << 32) - top);
+  return (uint64_t)s + ((0 - (uint64_t)(s >> 64)) & EPS);
+#endif
+}
+
 // 128-bit (hi:lo) -> lazy u64 (any representative):  lo - hi_hi + hi_lo*(2^32-1),
 // every wrap of 2^64 repaid by -+EPS
 GL_HD uint64_t reduce128_lazy(uint64_t lo, uint64_t hi) {
-  uint32_t w2 = lo32(hi), w3 = hi32(hi);
-  u128 t = (u128)lo - w3;
-  uint64_t t0 = (uint64_t)t - ((uint64_t)(t >> 64) & EPS);
-  u128 s = (u128)t0 + (((uint64_t)w2 << 32) - w2);
-  return (uint64_t)s + ((0 - (uint64_t)(s >> 64)) & EPS);
+  const uint32_t w2 = lo32(hi), w3 = hi32(hi);
+  const u128 t = (u128)lo - w3;
+  const uint64_t t0 = (uint64_t)t - ((uint64_t)(t >> 64) & EPS);
+  return fold_top(t0, w2);
 }
 GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) { return canon(reduce128_lazy(lo, hi)); }
 
 // 64x64 -> 128 as exactly four 32x32+64 multiply-adds (v_mad_u64_u32)
 GL_HD void mul_wide(uint64_t a, uint64_t b, uint64_t &lo, uint64_t &hi) {
-  uint32_t a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
-  uint64_t p00 = (uint64_t)a0 * b0;
-  uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);
-  uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
-  uint64_t p11 = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+  const uint32_t a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+  const uint64_t p00 = (uint64_t)a0 * b0;
+  const uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);  // < 2^64
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the third multiply-add takes the whole second one as its addend; its carry-out replaces two zero-extending moves
+  // and a 64-bit addition
+  uint64_t r, cr;
+  uint32_t cbit;
+  asm("v_mad_u64_u32 %0, %1, %3, %4, %5\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, 1, %1"
+      : "=&v"(r), "=&s"(cr), "=&v"(cbit)
+      : "v"(a1), "v"(b0), "v"(p01));
+  lo = pack(lo32(p00), lo32(r));
+  hi = (uint64_t)a1 * b1 + pack(hi32(r), cbit);
+#else
+  const uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
+  const uint64_t p11 = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);
   lo = pack(lo32(p00), lo32(p10));
   hi = p11;
+#endif
 }
 
 GL_HD uint64_t mul(uint64_t a, uint64_t b) {

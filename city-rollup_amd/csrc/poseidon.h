@@ -6,10 +6,7 @@
 //
 // One lane owns one 12-element state (24 VGPRs): no cross-lane traffic, pure 32-bit integer VALU, bound by instruction
 // issue. What shapes the code (measured on MI355X, profiles/r01_ubench_valu.txt, r02_ubench_poseidon.txt):
-//   * a 64-bit modular multiplication is 15 instructions: 4 `v_mad_u64_u32` for the product (the third takes the whole
-//     second as its addend and hands its carry-out on), 5 for `lo - w3` with its borrow, and ONE more multiply-add for
-//     `+ w2 (2^32 - 1)` whose carry-out selects the repair. The two carry-outs are out of the compiler's reach (it
-//     zero-extends and compares instead: 19 instructions), hence two three-line `asm` blocks in `mul_lazy` / `fold_top`;
+//   * a 64-bit modular multiplication is 15 instructions (gl.h: `mul_wide`, `fold_top` — two carry-outs taken in `asm`);
 //   * the MDS layer (circulant, entries <= 41, + diag 8) uses NO multiplies at all: each element
 //     is split into three 22-bit limbs and the length-12 cyclic convolution is evaluated per limb
 //     in wrap-around 32-bit arithmetic through the CRT split
@@ -61,45 +58,11 @@ GL_HD uint64_t dom_last(int i) {
 }
 
 // ---- lazy field helpers: inputs/outputs are arbitrary u64 congruent to the value ----------
-// lo + top * (2^32 - 1) as a lazy u64 (top * 2^64 == top * (2^32 - 1))
-GL_HD uint64_t fold_top(uint64_t lo, uint32_t top) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  // one multiply-add; its carry-out (one wrap of 2^64 == + EPS) selects the repair. The repaired sum cannot wrap again:
-  // lo + top (2^32 - 1) < 2^65 - 2^33, so after one wrap it is below 2^64 - 2^33.
-  uint64_t r, cy;
-  uint32_t m;
-  asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, -1, %1" : "=&v"(r), "=&s"(cy), "=v"(m) : "v"(top), "v"(lo));
-  return r + m;
-#else
-  const gl::u128 s = (gl::u128)lo + (((uint64_t)top << 32) - top);
-  return (uint64_t)s + ((0 - (uint64_t)(s >> 64)) & gl::EPS);
-#endif
-}
+using gl::fold_top;
 GL_HD uint64_t mul_lazy(uint64_t a, uint64_t b) {
   uint64_t lo, hi;
-#if defined(__HIP_DEVICE_COMPILE__)
-  {
-    // 64x64 -> 128: the third multiply-add takes the whole second one as its addend; its carry-out replaces two
-    // zero-extending moves and a 64-bit addition
-    const uint32_t a0 = gl::lo32(a), a1 = gl::hi32(a), b0 = gl::lo32(b), b1 = gl::hi32(b);
-    const uint64_t p00 = (uint64_t)a0 * b0;
-    const uint64_t q = (uint64_t)a0 * b1 + (p00 >> 32);  // < 2^64
-    uint64_t r, cr;
-    uint32_t cbit;
-    asm("v_mad_u64_u32 %0, %1, %3, %4, %5\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, 1, %1"
-        : "=&v"(r), "=&s"(cr), "=&v"(cbit)
-        : "v"(a1), "v"(b0), "v"(q));
-    lo = gl::pack(gl::lo32(p00), gl::lo32(r));
-    hi = (uint64_t)a1 * b1 + gl::pack(gl::hi32(r), cbit);
-  }
-#else
   gl::mul_wide(a, b, lo, hi);
-#endif
-  // lo - w3 + w2 (2^32 - 1)
-  const uint32_t w2 = gl::lo32(hi), w3 = gl::hi32(hi);
-  const gl::u128 t = (gl::u128)lo - w3;
-  const uint64_t t0 = (uint64_t)t - ((uint64_t)(t >> 64) & gl::EPS);
-  return fold_top(t0, w2);
+  return gl::reduce128_lazy(lo, hi);
 }
 GL_HD uint64_t sbox_lazy(uint64_t x) {
   const uint64_t x2 = mul_lazy(x, x), x4 = mul_lazy(x2, x2), x3 = mul_lazy(x, x2);
