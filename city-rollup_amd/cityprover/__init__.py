@@ -51,6 +51,7 @@ ABI = {
                                   ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint, _vp,
                                   ctypes.c_size_t]),
     "cp_poseidon_permute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    "cp_field_mul": (ctypes.c_int, [_vp, _u64p, _u64p, _u64p, ctypes.c_size_t]),
     "cp_poseidon_permute": (ctypes.c_int, [_vp, _u64p, ctypes.c_size_t]),
     "cp_hash_no_pad": (ctypes.c_int, [_vp, _u64p, ctypes.c_size_t, ctypes.c_size_t, _u64p]),
     "cp_two_to_one": (ctypes.c_int, [_vp, _u64p, _u64p, ctypes.c_size_t, _u64p]),
@@ -265,6 +266,14 @@ class Prover:
             din.free()
             dout.free()
         return out[0] if c.ndim == 1 else out
+
+    def field_mul(self, a, b):
+        """a * b mod p element-wise with the device's multiplication; a, b: any u64 (lazy representatives allowed)."""
+        x, y = _as_u64(a).ravel().copy(), _as_u64(b).ravel().copy()
+        assert x.size == y.size
+        out = np.zeros(x.size, np.uint64)
+        self._check(self.lib.cp_field_mul(self.ctx, _ptr(x), _ptr(y), _ptr(out), x.size))
+        return out
 
     def poseidon_permute(self, states):
         s = _as_u64(states).copy()

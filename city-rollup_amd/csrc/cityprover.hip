@@ -554,6 +554,27 @@ int cp_lde_dev(cp_ctx *ctx, const uint64_t *coeffs, size_t in_stride, int log_n,
                     (flags & CP_NTT_BITREV_OUT) | CP_NTT_COSET, coset_shift);
 } CP_CATCH(ctx)
 
+// ---- field self-test --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_field_mul(const uint64_t *__restrict__ a, const uint64_t *__restrict__ b,
+                                                   uint64_t *__restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = gl::mul(a[i], b[i]);
+}
+
+int cp_field_mul(cp_ctx *ctx, const uint64_t *a_host, const uint64_t *b_host, uint64_t *out_host, size_t count) try {
+  CHECK_CTX(ctx);
+  if (count == 0) return CP_OK;
+  if (!a_host || !b_host || !out_host) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL pointer");
+  if (count > ((size_t)1 << 28)) return set_error(ctx, CP_ERR_INVALID_ARG, "count too large");
+  const size_t bytes = count * sizeof(uint64_t);
+  CP_TRY(ensure_scratch(ctx, 3 * bytes));
+  uint64_t *a = (uint64_t *)ctx->scratch, *b = a + count, *o = b + count;
+  CP_TRY(cp_h2d(ctx, a, a_host, bytes));
+  CP_TRY(cp_h2d(ctx, b, b_host, bytes));
+  LAUNCH(ctx, "field_mul", k_field_mul, dim3(blocks_for(count, 256)), dim3(256), a, b, o, count);
+  return cp_d2h(ctx, out_host, o, bytes);
+} CP_CATCH(ctx)
+
 // ---- Poseidon -------------------------------------------------------------------------------
 
 int cp_poseidon_permute_dev(cp_ctx *ctx, uint64_t *states, size_t count) try {

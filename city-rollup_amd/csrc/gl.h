@@ -49,11 +49,12 @@ GL_HD uint64_t add_lazy(uint64_t a, uint64_t b) {
   return s;
 }
 
-// A modular multiplication is 15 VALU instructions on gfx950: 4 v_mad_u64_u32 for the product, 5 for `lo - w3` with its
-// borrow, one more multiply-add for `+ w2 (2^32 - 1)`. Two of the multiply-adds are written as `asm`: their carry-outs are
-// out of the compiler's reach (it zero-extends, adds and compares instead: 19 instructions; measured +6 % on the
-// Poseidon permutation, tools/ubench_poseidon_variants.hip). The `s_nop 1` are the two wait states gfx950 needs between a
-// VALU write of an SGPR and a VALU read of it; the compiler's hazard recogniser does not look inside `asm`.
+// A modular multiplication is 12 VALU instructions on gfx950: 4 v_mad_u64_u32 for the product (+ 2 moves, 1 select), 2 for
+// `lo - w3`, one more multiply-add for `+ w2 (2^32 - 1)` (+ select, 64-bit add). Three pieces are written as `asm` because
+// carry-outs are out of the compiler's reach (it zero-extends, adds and compares instead: 19 instructions; the permutation
+// measures 2.06 -> 2.48 -> 2.62 G/s with them, tools/ubench_poseidon_variants.hip). The `s_nop 1` are the two wait states
+// gfx950 needs between a VALU write of an SGPR and a VALU read of it; the compiler's hazard recogniser does not look inside
+// `asm`. tests/test_gpu_parity.py drives `cp_field_mul` through every carry / borrow corner on the device.
 
 // lo + top * (2^32 - 1) as a lazy u64 (top * 2^64 == top * (2^32 - 1))
 GL_HD uint64_t fold_top(uint64_t lo, uint32_t top) {
@@ -74,8 +75,23 @@ GL_HD uint64_t fold_top(uint64_t lo, uint32_t top) {
 // every wrap of 2^64 repaid by -+EPS
 GL_HD uint64_t reduce128_lazy(uint64_t lo, uint64_t hi) {
   const uint32_t w2 = lo32(hi), w3 = hi32(hi);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // lo - w3 borrows only when lo < w3 < 2^32 (a 2^-32 event for a product): the repair (- EPS for the 2^64 that was lent)
+  // sits behind a wave-uniform branch instead of costing three instructions on every multiplication
+  uint32_t tl, th, m;
+  uint64_t bm;
+  asm("v_sub_co_u32_e64 %0, %2, %3, %4\n\ts_nop 1\n\tv_subbrev_co_u32_e64 %1, %2, 0, %5, %2"
+      : "=&v"(tl), "=&v"(th), "=&s"(bm)
+      : "v"(lo32(lo)), "v"(w3), "v"(hi32(lo)));
+  uint64_t t0 = pack(tl, th);
+  if (__builtin_expect(bm != 0, 0)) {
+    asm volatile("v_cndmask_b32 %0, 0, -1, %1" : "=v"(m) : "s"(bm));
+    t0 -= m;
+  }
+#else
   const u128 t = (u128)lo - w3;
   const uint64_t t0 = (uint64_t)t - ((uint64_t)(t >> 64) & EPS);
+#endif
   return fold_top(t0, w2);
 }
 GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) { return canon(reduce128_lazy(lo, hi)); }

@@ -133,6 +133,12 @@ int cp_lde_dev(cp_ctx *ctx, const uint64_t *coeffs_dev, size_t in_stride, int lo
                size_t batch, uint64_t coset_shift, unsigned flags, uint64_t *out_dev,
                size_t out_stride);
 
+/* ---- Goldilocks field, element-wise (diagnostic) ------------------------------------------
+ * out[i] = a[i] * b[i] mod p with the device's multiplication (csrc/gl.h `mul`: hand-scheduled carry handling), canonical
+ * out; a, b: ANY u64 (the kernels carry values lazily), host pointers. No call site in the reference — this is the
+ * built-in self-test hook for the one arithmetic primitive every kernel shares (plonky2 `GoldilocksField::mul`). */
+int cp_field_mul(cp_ctx *ctx, const uint64_t *a_host, const uint64_t *b_host, uint64_t *out_host, size_t count);
+
 /* ---- Poseidon-Goldilocks -------------------------------------------------------------
  * Replaces plonky2 `PoseidonPermutation::permute`, `PoseidonHash::{hash_no_pad, two_to_one}`
  * (reference call sites city_crypto/src/hash/traits/hasher.rs:77-159).

@@ -30,6 +30,52 @@ EDGE = np.array([0, 1, 2, P - 1, P - 2, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000
                  0xFFFFFFFE00000001, 1 << 63, (1 << 63) + 1, 0x7FFFFFFF80000000], dtype=np.uint64)
 
 
+# ---- the field multiplication every kernel shares (csrc/gl.h: carries taken in hand-written multiply-adds) ------------
+def test_field_mul_every_carry_and_borrow_corner(prover):
+    """gl::mul on the device against Python integers: lazy (non-canonical) operands, every pair of edge values, and operands
+    constructed so that each rare path is taken — the carry out of the third multiply-add of the product, the borrow of
+    `lo - w3` (needs lo < w3 < 2^32: a 2^-32 event for random inputs, repaired behind a branch), and the wrap of the
+    final `+ w2 (2^32 - 1)`."""
+    rng = np.random.default_rng(11)
+    M = (1 << 64) - 1
+    edge = [0, 1, 2, 3, P - 1, P - 2, P, P + 1, M, M - 1, 0xFFFFFFFF, 0x100000000, 0x100000001, 0xFFFFFFFF00000000, 0xFFFFFFFE00000001,
+            1 << 63, (1 << 63) + 1, 0x7FFFFFFF80000000, 0x8000000080000000, 0xFFFFFFFFFFFF0000, 1 << 48, 3 << 48, 1 << 32, 1 << 33]
+    a = [x for x in edge for _ in edge]
+    b = [y for _ in edge for y in edge]
+    # borrow of lo - w3 (a b = w3 2^96 + w2 2^64 + lo with lo < w3): lo = 0 from two multiples of 2^32 ...
+    for _ in range(2000):
+        u, k = int(rng.integers(1 << 16, 1 << 32)), int(rng.integers(1 << 16, 1 << 32))
+        a.append(u << 32)
+        b.append(k << 32)
+    # ... and a small non-zero lo: a odd, b = t / a mod 2^64 makes the low 64 bits of the product equal t
+    for _ in range(2000):
+        aa = int(rng.integers(1 << 62, 1 << 64, dtype=np.uint64)) | 1
+        t = int(rng.integers(1, 1 << 20))
+        a.append(aa)
+        b.append((t * pow(aa, -1, 1 << 64)) & M)
+    # carry out of the cross terms (a1 b0 + a0 b1 + carry >= 2^64) and wrap of the final multiply-add: large halves
+    hi_vals = [0xFFFFFFFF, 0xFFFFFFFE, 0x80000000, 0xFFFF0000, 1]
+    for a1 in hi_vals:
+        for a0 in hi_vals:
+            for b1 in hi_vals:
+                for b0 in hi_vals:
+                    a.append((a1 << 32) | a0)
+                    b.append((b1 << 32) | b0)
+    ra = rng.integers(0, 1 << 64, 200000, dtype=np.uint64)
+    rb = rng.integers(0, 1 << 64, 200000, dtype=np.uint64)
+    # random operands with a zero or tiny low product: 2-adic structure makes lo small far more often than 2^-32
+    sh = rng.integers(0, 64, 200000)
+    rc = (rng.integers(0, 1 << 64, 200000, dtype=np.uint64) >> sh.astype(np.uint64)) << sh.astype(np.uint64)
+    A = np.concatenate([np.array(a, dtype=np.uint64), ra, rc])
+    B = np.concatenate([np.array(b, dtype=np.uint64), rb, rc[::-1]])
+    got = prover.field_mul(A, B)
+    want = np.array([(int(x) * int(y)) % P for x, y in zip(A, B)], dtype=np.uint64)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, [(hex(int(A[i])), hex(int(B[i])), int(got[i]), int(want[i])) for i in bad[:5]]
+    borrows = sum(1 for x, y in zip(A, B) if ((int(x) * int(y)) & M) < ((int(x) * int(y)) >> 96))
+    assert borrows > 1000            # the rare path was exercised
+
+
 # ---- Poseidon ------------------------------------------------------------------------------
 def test_poseidon_permute_matches_oracle(prover):
     states = felts(12 * 5000, 1).reshape(-1, 12)

@@ -13,8 +13,13 @@
 
 using poseidon::W;
 
+#ifdef WAVES  // occupancy experiment: -DWAVES=5 asks the register allocator for at most 512/5 VGPRs
+#define OCC __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+#else
+#define OCC
+#endif
 template <int VARIANT>  // 0: textbook rounds, 1: poseidon::permute
-__global__ __launch_bounds__(256) void k_chain(uint64_t *out, uint64_t seed, int reps) {
+__global__ __launch_bounds__(256) OCC void k_chain(uint64_t *out, uint64_t seed, int reps) {
   uint64_t s[W];
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 #pragma unroll
