@@ -196,6 +196,19 @@ int merkle_levels(cp_ctx *ctx, uint64_t *D, size_t per_tree, size_t n_leaves, si
     // a launch that cannot fill the chip is bound by the latency of ONE permutation: twelve lanes per state then
     // (poseidon_coop.h); lane-per-state otherwise. CITYPROVER_COOP_MAX overrides the switch (0 = never) for measurements.
     static const size_t coop_max = getenv("CITYPROVER_COOP_MAX") ? strtoull(getenv("CITYPROVER_COOP_MAX"), nullptr, 10) : 32768;
+    static const int fuse_max = getenv("CITYPROVER_COOP_FUSE") ? atoi(getenv("CITYPROVER_COOP_FUSE")) : pcoop::MAX_FUSED;
+    if (np * n_trees <= coop_max && fuse_max >= 1) {
+      // ... and several such levels go into one launch (a workgroup walks a whole subtree): everything up to the cap
+      while (n > cap_n) {
+        int levels = 0;
+        while (levels < fuse_max && levels < pcoop::MAX_FUSED && (n >> levels) > cap_n) levels++;
+        const unsigned waves = ((1u << (levels - 1)) + pcoop::STATES_PER_WAVE - 1) / pcoop::STATES_PER_WAVE;  // for the first, widest step
+        LAUNCH(ctx, "merkle_levels_coop", pcoop::k_levels_coop, dim3((unsigned)(n >> levels), (unsigned)n_trees), dim3(64 * waves), D, off, n,
+               levels, per_tree, caps, cap_n);
+        for (int l = 0; l < levels; l++, n >>= 1) off += n * 4;
+      }
+      break;
+    }
     if (np * n_trees <= coop_max)
       LAUNCH(ctx, "merkle_level_coop", pcoop::k_level_coop, dim3(blocks_for(np, pcoop::STATES_PER_BLOCK), (unsigned)n_trees), dim3(256), child,
              np, parent, per_tree, pstride);

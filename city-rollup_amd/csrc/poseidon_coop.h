@@ -84,6 +84,48 @@ __global__ __launch_bounds__(256) void k_level_coop(const uint64_t *__restrict__
   if (active && e < 4) parent[4 * i + e] = x;
 }
 
+// Up to MAX_FUSED consecutive tree levels in ONE launch: a workgroup owns 2^levels consecutive nodes of the child level —
+// a whole subtree, so nothing crosses workgroups — and walks it upwards, the digests of the level just computed staying in
+// LDS for the next step (every level is also written out: Merkle paths need them). The first step has at most 16 parents
+// (of the 20 slots of a workgroup), the later ones 8, 4, 2, 1: what this buys is launches — the 7 to 11 upper levels of a
+// commitment become 2 or 3 — on levels that are bound by the latency of one permutation, not by throughput.
+// Level l of the tree (l = 0: the child level of this launch, n_child nodes per tree) sits at tree + off_l, off_(l+1) =
+// off_l + 4 (n_child >> l); the level with cap_n nodes goes to caps + tree * 4 cap_n instead.
+// grid = (n_child >> levels, n_trees), block = 64 x the waves the first step needs (ceil(2^(levels-1) / 5) <= 4)
+constexpr int MAX_FUSED = 5;
+__global__ __launch_bounds__(256) void k_levels_coop(uint64_t *__restrict__ D, size_t off_child, size_t n_child, int levels, size_t tree_stride,
+                                                     uint64_t *__restrict__ caps, size_t cap_n) {
+  __shared__ __attribute__((aligned(16))) uint64_t sh[WAVES][STATES_PER_WAVE * GROUP];
+  __shared__ uint64_t node[2][4 << (MAX_FUSED - 1)];  // digests of the level being read / written, ping-pong
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / GROUP, e = lane - g * GROUP;
+  const bool lane_used = g < STATES_PER_WAVE;
+  const int j = wave * STATES_PER_WAVE + (lane_used ? g : 0);  // parent slot of this lane's group
+  uint64_t *tree = D + (size_t)blockIdx.y * tree_stride;
+  uint32_t coef[GROUP];
+#pragma unroll
+  for (int k = 0; k < GROUP; k++) coef[k] = mds_coef(lane_used ? e : 0, k);
+  size_t off = off_child, n = n_child;
+  for (int l = 0; l < levels; l++) {
+    const int m = 1 << (levels - 1 - l);  // parents this workgroup computes at this step (<= 16)
+    const bool active = lane_used && j < m;
+    const size_t np = n >> 1, i = (size_t)blockIdx.x * m + j;
+    if (wave * STATES_PER_WAVE < m) {  // a wave without a parent at this step sits it out (the exchange inside is per wave)
+      uint64_t x = 0;
+      if (active && e < 8) x = l == 0 ? tree[off + 8 * i + e] : node[(l - 1) & 1][8 * j + e];
+      x = permute(x, lane_used ? g : 0, lane_used ? e : 0, lane_used, sh[wave], coef);
+      if (active && e < 4) {
+        node[l & 1][4 * j + e] = x;
+        if (np == cap_n) caps[(size_t)blockIdx.y * 4 * cap_n + 4 * i + e] = x;
+        else tree[off + 4 * n + 4 * i + e] = x;
+      }
+    }
+    off += 4 * n;
+    n = np;
+    __syncthreads();
+  }
+}
+
 // FRI layer leaves for launches that cannot fill the chip (same layout as fri::k_leaf_hash_fri): leaf j = the `arity`
 // extension values at bit-reversed positions [arity*j, arity*(j+1)), flattened (a0, b0, a1, b1, ...), hashed by the
 // overwrite-mode sponge — 2*arity/8 chained permutations, 12 lanes per leaf. vals: [proof][re | im][n_vals].

@@ -44,8 +44,10 @@ if __name__ == "__main__":
     n_trees = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     res = {}
-    for label, coop in (("lane_per_state", "0"), ("cooperative_le_32768", "32768"), ("cooperative_le_65536", "65536"), ("cooperative_le_16384", "16384")):
-        env = dict(os.environ, CITYPROVER_COOP_MAX=coop)
+    for label, coop, fuse in (("lane_per_state", "0", "5"), ("cooperative_one_level_per_launch", "32768", "0"), ("cooperative_fused_2", "32768", "2"),
+                              ("cooperative_fused_3", "32768", "3"), ("cooperative_fused_5", "32768", "5"), ("cooperative_fused_5_le_65536", "65536", "5"),
+                              ("cooperative_fused_5_le_16384", "16384", "5")):
+        env = dict(os.environ, CITYPROVER_COOP_MAX=coop, CITYPROVER_COOP_FUSE=fuse)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n_trees), str(k)], env=env, capture_output=True, text=True)
         if r.returncode != 0:
             sys.exit(r.stderr)
