@@ -361,9 +361,9 @@ def main():
         leaf_ms, _ = kern("leaf_hash_cols")
         cols_ms, cols_l = kern("ntt16_cols")
         rows_ms, rows_l = kern("ntt16_rows")
-        lvl_ms = sum(prof.get(nm, {"total_ms": 0.0})["total_ms"] for nm in ("merkle_level", "merkle_level_coop"))
+        lvl_ms = sum(prof.get(nm, {"total_ms": 0.0})["total_ms"] for nm in ("merkle_level", "merkle_level_coop", "merkle_levels_coop"))
         # Dominant kernel by time: the Poseidon leaf hash (75 % of the step). It moves exactly its algorithmic bytes
-        # (8*R*k read + 32*R written) but is bound by integer-VALU issue, not by HBM: ~23 K VALU
+        # (8*R*k read + 32*R written) but is bound by integer-VALU issue, not by HBM: ~15 K VALU
         # instructions per permutation. `roofline` is therefore priced in lane-operations against the VALU issue peak;
         # the HBM figures stay inside it as `hbm`. Instruction counts and HBM traffic come from separate rocprofv3 --pmc
         # passes of this command (tools/profile_bench.sh -> profiles/r02_pmc_bench.json) and are used only when that file
