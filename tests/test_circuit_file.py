@@ -69,6 +69,27 @@ def test_file_info_and_damaged_files(tmp_path):
     bad[-16:-8] = struct.pack("<Q", O.P)
     bad[-8:] = struct.pack("<Q", files.fnv1a64(bytes(bad[:-8])))
     expect_refused(bytes(bad), "canonical")
+    # header fields overwritten with hostile values and the checksum REPAIRED, so the content checks alone stand between the
+    # file and the loader: every such file is refused with an error or read consistently — no crash, no giant allocation
+    import random
+    rnd = random.Random(9)
+    hdr = min(len(good) - 8, 512)
+    refused = 0
+    for _ in range(300):
+        m = bytearray(good)
+        for _ in range(rnd.randrange(1, 4)):
+            o = 12 + 4 * rnd.randrange((hdr - 12) // 4)
+            m[o:o + 4] = struct.pack("<I", rnd.choice([0, 1, 0x7FFFFFFF, 0xFFFFFFFF, 0x80000000, 1 << 20, 1 << 30, 65, 4097,
+                                                       struct.unpack("<I", good[o:o + 4])[0] ^ (1 << rnd.randrange(32))]))
+        m[-8:] = struct.pack("<Q", files.fnv1a64(bytes(m[:-8])))
+        badp = str(tmp_path / "hostile.cpcirc")
+        open(badp, "wb").write(bytes(m))
+        try:
+            got = cp.circuit_file_info(badp)
+            assert got["n_gates"] <= 4096
+        except cp.CityProverError:
+            refused += 1
+    assert refused >= 50   # (digest words, gate parameters and reserved words are free-form: overwriting them is not an error)
     with pytest.raises(cp.CityProverError, match="cannot open"):
         cp.circuit_file_info(str(tmp_path / "missing.cpcirc"))
     assert cp.circuit_file_info(path)["n_gates"] == len(c["gate_list"])   # the good file still reads

@@ -138,6 +138,43 @@ def test_bad_inputs_fail_loudly(golden_dir, tmp_path):
     assert "--pack" in run(["-i", os.path.join(golden_dir, "qbench_example.bin")], ok=False)
 
 
+def test_mutated_dumps_are_refused_or_replayed_never_crash(golden_dir, tmp_path):
+    """The dump parser against damaged input: truncations at every structural boundary, overwritten length prefixes,
+    flipped bytes in the records' headers, random garbage. Each run must end by itself with exit code 0 (the damage was in
+    bytes the schedule does not read) or 1 (a ParseError / plan mismatch) — never a signal, never a hang."""
+    import random
+    build_harness()
+    raw = open(os.path.join(golden_dir, "qbench_example.bin"), "rb").read()
+    rnd = random.Random(5)
+    cases = []
+    for cut in [0, 1, 7, 8, 9, 15, 16, 24, 31, 32, 40, 100, 1000, len(raw) // 2, len(raw) - 9, len(raw) - 8, len(raw) - 1]:
+        cases.append(raw[:cut])
+    for _ in range(40):                                   # a u64 length prefix somewhere in the first 4 KiB made huge / zero / off by one
+        b = bytearray(raw)
+        o = rnd.randrange(0, 4096) & ~7
+        b[o:o + 8] = struct.pack("<Q", rnd.choice([0, 1, 2 ** 63, 2 ** 64 - 1, 2 ** 32, len(raw), len(raw) + 1,
+                                                   struct.unpack("<Q", raw[o:o + 8])[0] + 1]))
+        cases.append(bytes(b))
+    for _ in range(60):                                   # byte flips: half in the head of the file, half anywhere
+        b = bytearray(raw)
+        for _ in range(rnd.randrange(1, 6)):
+            o = rnd.randrange(0, 2048) if rnd.random() < 0.5 else rnd.randrange(0, len(raw))
+            b[o] ^= 1 << rnd.randrange(8)
+        cases.append(bytes(b))
+    cases.append(bytes(rnd.randrange(256) for _ in range(5000)))
+    cases.append(raw + b"\x00" * 8)
+    p = str(tmp_path / "mutated.bin")
+    seen = {0: 0, 1: 0}
+    for c in cases:
+        open(p, "wb").write(c)
+        r = subprocess.run([EXE, "-i", p, "--dry-run", "--contexts", "2", "--batch", "4"], capture_output=True, text=True, timeout=60)
+        assert r.returncode in (0, 1), (r.returncode, r.stderr[-300:])
+        if r.returncode == 1:
+            assert r.stderr.strip(), "an error exit must say why"
+        seen[r.returncode] += 1
+    assert seen[1] >= 20                                  # truncations and broken length prefixes are noticed; flips inside proof bytes are not read
+
+
 def test_harness_fails_loudly_without_a_gpu(golden_dir, tmp_path):
     import torch
     if torch.cuda.is_available():
