@@ -72,5 +72,21 @@ int main() {
     }
     printf("%s: %.3f ms for %zu permutations -> %.3f G perm/s\n", names[variant], best, n * reps, (double)n * reps / best / 1e6);
   }
-  return bad != 0;
+  // the timed chains started from the same states: 64 permutations deep, any single wrong output would have propagated
+  hipMemcpy(ha.data(), a, n * 8, hipMemcpyDeviceToHost);
+  hipMemcpy(hb.data(), b, n * 8, hipMemcpyDeviceToHost);
+  size_t bad_long = 0;
+  for (size_t i = 0; i < n; i++) bad_long += ha[i] != hb[i];
+  printf("mismatches after %d chained permutations of %zu states: %zu\n", reps, n, bad_long);
+  // more seeds: 16 x 2^20 chains of 32
+  size_t bad_seeds = 0;
+  for (uint64_t seed = 1; seed <= 16; seed++) {
+    hipLaunchKernelGGL(k_chain<0>, dim3(blocks), dim3(256), 0, 0, a, seed * 0x9E3779B97F4A7C15ull, 32);
+    hipLaunchKernelGGL(k_chain<1>, dim3(blocks), dim3(256), 0, 0, b, seed * 0x9E3779B97F4A7C15ull, 32);
+    hipMemcpy(ha.data(), a, n * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(hb.data(), b, n * 8, hipMemcpyDeviceToHost);
+    for (size_t i = 0; i < n; i++) bad_seeds += ha[i] != hb[i];
+  }
+  printf("mismatches over 16 more seeds (%zu permutations): %zu\n", (size_t)16 * n * 32, bad_seeds);
+  return (bad | bad_long | bad_seeds) != 0;
 }
