@@ -21,3 +21,8 @@ $Q -i $D --pack $PACK --contexts 3 --batch 32 -n 8 --blocks-in-flight 8 --groth1
 $Q -i $D --pack $PACK --contexts 3 --batch 32 -n 4 --blocks-in-flight 4 --groth16-log-size 22 | tail -1 >> "$OUT"
 $Q -i $D --pack $PACK --contexts 3 --batch 32 --groth16-log-size 22 | tail -1 >> "$OUT"
 wc -l "$OUT"
+# reference-style workers sharing the GPU: N contexts, each one job at a time (the harness raises GPU_MAX_HW_QUEUES itself)
+for c in 4 8 12; do
+  $Q -i $D --pack $PACK --contexts $c --batch 1 -n 16 --blocks-in-flight 16 | tail -1 >> "$OUT"
+done
+wc -l "$OUT"
