@@ -10,7 +10,8 @@
 // product-scanning Montgomery multiplication is nothing but v_mad_u64_u32 with the accumulator as its own 64-bit
 // addend: no carry propagation and no zero-extension moves between the multiply-adds (a 12 x 32-bit CIOS spends half
 // its instructions on those). ~500 instructions per product instead of ~1300. Values are kept fully reduced (< p, limbs
-// < 2^28); additions and subtractions are plain limb loops with a 28-bit carry.
+// < 2^28) and additions / subtractions are plain limb loops with a 28-bit carry — except inside the bucket accumulation,
+// which runs on bounded, unreduced values ("loose arithmetic" below).
 #pragma once
 #include <stdint.h>
 
@@ -81,7 +82,8 @@ GL_HD Fp fp_dbl(const Fp &a) { return fp_add(a, a); }
 
 // Montgomery product a*b/R mod p, product scanning. Deliberately NOT inlined: a point addition holds 11-16 of these —
 // inlined, one kernel outgrows the instruction cache and the library takes minutes to compile.
-__host__ __device__ __attribute__((noinline)) inline Fp fp_mul(Fp a, Fp b) {  // by value: operands travel in VGPRs, not through scratch
+template <bool FINAL_SUB>
+GL_HD Fp fp_mul_body(const Fp &a, const Fp &b) {
   uint32_t m[NL];
   Fp r;
   uint64_t acc = 0;
@@ -102,13 +104,15 @@ __host__ __device__ __attribute__((noinline)) inline Fp fp_mul(Fp a, Fp b) {  //
     if (k - NL < NL) r.l[k - NL] = (uint32_t)acc & LM;
     acc >>= LB;
   }
-  // result < 2p (both operands < p, R > 4p)
-  fp_cond_sub_p(r);
+  // result < 2p whenever a b < R p (R / p = 2^11.3: e.g. both operands < 32 p), limbs < 2^28
+  if (FINAL_SUB) fp_cond_sub_p(r);
   return r;
 }
+__host__ __device__ __attribute__((noinline)) inline Fp fp_mul(Fp a, Fp b) { return fp_mul_body<true>(a, b); }  // by value: operands travel in VGPRs, not through scratch
 // Montgomery square: the same column scan with every cross product a_i a_j (i < j) computed once and doubled —
 // 105 + 196 multiply-adds instead of 196 + 196. Not inlined, for the same reason.
-__host__ __device__ __attribute__((noinline)) inline Fp fp_sqr_mont(Fp a) {
+template <bool FINAL_SUB>
+GL_HD Fp fp_sqr_body(const Fp &a) {
   uint32_t m[NL];
   Fp r;
   uint64_t acc = 0;
@@ -137,9 +141,10 @@ __host__ __device__ __attribute__((noinline)) inline Fp fp_sqr_mont(Fp a) {
     if (k - NL < NL) r.l[k - NL] = (uint32_t)acc & LM;
     acc >>= LB;
   }
-  fp_cond_sub_p(r);
+  if (FINAL_SUB) fp_cond_sub_p(r);
   return r;
 }
+__host__ __device__ __attribute__((noinline)) inline Fp fp_sqr_mont(Fp a) { return fp_sqr_body<true>(a); }
 GL_HD Fp fp_sqr(const Fp &a) { return fp_sqr_mont(a); }
 
 // 12 little-endian 32-bit words of a canonical value (< p)  <->  Montgomery limbs
@@ -323,6 +328,139 @@ template <class F> GL_HD XyzzT<F> xyzz_add_mixed(const XyzzT<F> &p, const Affine
 template <class F> GL_HD JacT<F> xyzz_to_jac(const XyzzT<F> &p) {
   if (f_is_zero(p.zz)) return jac_inf<F>();
   return {f_mul(p.x, p.zz), f_mul(p.y, p.zzz), p.zz};
+}
+
+// ---- loose arithmetic for the bucket accumulation (k_bucket_sum / k_heavy_sum: all but a few percent of an MSM) ------
+// Keeping every value below p costs a conditional subtraction of p after each product and each addition (56 of the ~100
+// instructions of an addition, 56 of the ~450 of a product), and an F_p^2 product in Karatsuba form is five additions or
+// subtractions around its three products: a third of a G2 mixed addition was spent normalising. Inside the accumulation the
+// values are therefore only BOUNDED, not reduced:
+//   * the Montgomery product without its final subtraction returns < 2p with normalised limbs for ANY operands with
+//     a b < R p (R / p = 2^11.3) and limbs < 2^29 (a column of the product scan then stays below 2^62.3);
+//   * an addition is the limb loop alone (`lz_add`), or not even that when the sum only feeds a product (`lz_add_nc`);
+//   * a - b is a + K p - b for a compile-time K with K p >= b, one signed-carry limb loop (`lz_sub<K>`);
+//   * the bounds of the accumulator coordinates close under the mixed addition (LooseBound below, in units of p and per
+//     F_p component; tests/test_hostsim.py replays them) — for G2 with one weak reduction (x < 16 p) per addition;
+//   * "is this difference zero mod p" (the doubling / cancellation case of the group law) is decided by a three-instruction
+//     necessary condition — x = k p with k < 32 forces (x_0 * p^-1 mod 2^28) < 32 — and only then exactly.
+// Everything that leaves the accumulation (xyzz_to_jac_loose) is canonical again.
+struct FpC { uint32_t l[NL]; };
+constexpr FpC kp_limbs(uint32_t K) {  // K p in normalised limbs; K < 2^11
+  FpC r{};
+  uint64_t c = 0;
+  for (int i = 0; i < NL; i++) {
+    c += (uint64_t)K * BLS_P[i];
+    r.l[i] = (uint32_t)(c & LM);
+    c >>= LB;
+  }
+  return r;
+}
+GL_HD Fp lz_add_nc(const Fp &a, const Fp &b) {  // limbs < 2^29 for normalised a, b: a product operand or a subtrahend only
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + b.l[i];
+  return r;
+}
+GL_HD Fp lz_add(const Fp &a, const Fp &b) {  // normalised limbs; value = a + b (must stay below 2^392)
+  Fp r;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const uint32_t t = a.l[i] + b.l[i] + c;
+    r.l[i] = t & LM;
+    c = t >> LB;
+  }
+  return r;
+}
+template <int K>
+GL_HD Fp lz_sub(const Fp &a, const Fp &b) {  // a + K p - b, normalised limbs; needs b <= K p; limbs of a, b below 2^30
+  constexpr FpC kp = kp_limbs(K);
+  Fp r;
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const int32_t t = (int32_t)(a.l[i] - b.l[i]) + (int32_t)kp.l[i] + c;
+    r.l[i] = (uint32_t)t & LM;
+    c = t >> LB;  // arithmetic: -4 .. 2
+  }
+  return r;
+}
+// a -= K p if a >= K p
+template <int K>
+GL_HD Fp lz_weak(const Fp &a) {
+  constexpr FpC kp = kp_limbs(K);
+  Fp t;
+  uint32_t br = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const uint32_t d = a.l[i] - kp.l[i] - br;
+    t.l[i] = d & LM;
+    br = d >> 31;
+  }
+  return br ? a : t;
+}
+__host__ __device__ __attribute__((noinline)) inline Fp lz_mul(Fp a, Fp b) { return fp_mul_body<false>(a, b); }
+__host__ __device__ __attribute__((noinline)) inline Fp lz_sqr(Fp a) { return fp_sqr_body<false>(a); }
+GL_HD Fp lz_canon(const Fp &a) { return fp_mul(a, fp_one()); }  // loose (< 32 p) -> canonical: a R / R
+GL_HD bool lz_maybe_zero(const Fp &a) {                           // false: a != 0 mod p for sure (a < 32 p)
+  constexpr uint32_t PINV = (0u - BLS_N0) & LM;                   // p^-1 mod 2^28
+  return ((a.l[0] * PINV) & LM) < 32u;
+}
+// F_p^2 (components bounded separately)
+GL_HD Fp2 lz_mul2(const Fp2 &a, const Fp2 &b) {  // components of a, b normalised, (a0 + a1)(b0 + b1) < R p; out: c0 < 4p, c1 < 6p
+  const Fp v0 = lz_mul(a.c0, b.c0), v1 = lz_mul(a.c1, b.c1);
+  const Fp s = lz_mul(lz_add_nc(a.c0, a.c1), lz_add_nc(b.c0, b.c1));
+  return {lz_sub<2>(v0, v1), lz_sub<4>(s, lz_add_nc(v0, v1))};
+}
+template <int K>
+GL_HD Fp2 lz_sqr2(const Fp2 &a) {  // components < K p; out: c0 < 2p, c1 < 4p
+  const Fp t = lz_mul(a.c0, a.c1);
+  return {lz_mul(lz_add_nc(a.c0, a.c1), lz_sub<K>(a.c0, a.c1)), lz_add(t, t)};
+}
+// one vocabulary for both fields
+GL_HD Fp lf_mul(const Fp &a, const Fp &b) { return lz_mul(a, b); }
+GL_HD Fp2 lf_mul(const Fp2 &a, const Fp2 &b) { return lz_mul2(a, b); }
+template <int K> GL_HD Fp lf_sqr(const Fp &a) { return lz_sqr(a); }
+template <int K> GL_HD Fp2 lf_sqr(const Fp2 &a) { return lz_sqr2<K>(a); }
+template <int K> GL_HD Fp lf_sub(const Fp &a, const Fp &b) { return lz_sub<K>(a, b); }
+template <int K> GL_HD Fp2 lf_sub(const Fp2 &a, const Fp2 &b) { return {lz_sub<K>(a.c0, b.c0), lz_sub<K>(a.c1, b.c1)}; }
+GL_HD Fp lf_add_nc(const Fp &a, const Fp &b) { return lz_add_nc(a, b); }
+GL_HD Fp2 lf_add_nc(const Fp2 &a, const Fp2 &b) { return {lz_add_nc(a.c0, b.c0), lz_add_nc(a.c1, b.c1)}; }
+template <int K> GL_HD Fp lf_weak(const Fp &a) { return lz_weak<K>(a); }
+template <int K> GL_HD Fp2 lf_weak(const Fp2 &a) { return {lz_weak<K>(a.c0), lz_weak<K>(a.c1)}; }
+GL_HD Fp lf_canon(const Fp &a) { return lz_canon(a); }
+GL_HD Fp2 lf_canon(const Fp2 &a) { return {lz_canon(a.c0), lz_canon(a.c1)}; }
+GL_HD bool lf_maybe_zero(const Fp &a) { return lz_maybe_zero(a); }
+GL_HD bool lf_maybe_zero(const Fp2 &a) { return lz_maybe_zero(a.c0) && lz_maybe_zero(a.c1); }
+// bounds of the accumulator coordinates and of the intermediates, in units of p per F_p component:
+//   M: a product, S: a square, X / Y: the accumulator's x / y after an addition (zz, zzz are products)
+template <class F> struct LooseBound;
+template <> struct LooseBound<Fp> { static constexpr int M = 2, S = 2, X = 8, Y = 4; static constexpr bool WEAK = false; };
+template <> struct LooseBound<Fp2> { static constexpr int M = 6, S = 4, X = 16, Y = 12; static constexpr bool WEAK = true; };
+template <class F> GL_HD XyzzT<F> xyzz_canon(const XyzzT<F> &p) { return {lf_canon(p.x), lf_canon(p.y), lf_canon(p.zz), lf_canon(p.zzz)}; }
+// p + q with p loose (x < X p, y < Y p, zz, zzz < M p; or infinity: zz = 0 exactly), q affine canonical and not infinity
+template <class F> GL_HD XyzzT<F> xyzz_add_mixed_loose(const XyzzT<F> &p, const AffineT<F> &q) {
+  using B = LooseBound<F>;
+  if (f_is_zero(p.zz)) return {q.x, q.y, Field<F>::one(), Field<F>::one()};
+  const F u2 = lf_mul(q.x, p.zz), s2 = lf_mul(q.y, p.zzz);             // < M
+  const F pp_ = lf_sub<B::X>(u2, p.x);                                  // < M + X
+  if (lf_maybe_zero(pp_) && f_is_zero(lf_canon(pp_)))                   // same x: doubling or cancellation, by the exact formulas
+    return xyzz_add_mixed(xyzz_canon(p), q);
+  const F rr = lf_sub<B::Y>(s2, p.y);                                   // < M + Y
+  const F pp = lf_sqr<B::M + B::X>(pp_), ppp = lf_mul(pp_, pp), qq = lf_mul(p.x, pp);  // < S, M, M
+  XyzzT<F> r;
+  // x = rr^2 - ppp - 2 qq  < S + 3 M  (G1: 8 = X; G2: 22, brought below 16 = X)
+  const F x = lf_sub<3 * B::M>(lf_sqr<B::M + B::Y>(rr), lf_add_nc(ppp, lf_add_nc(qq, qq)));
+  r.x = B::WEAK ? lf_weak<B::X>(x) : x;
+  // y = rr (qq - x) - y1 ppp  < 2 M = Y
+  r.y = lf_sub<B::M>(lf_mul(rr, lf_sub<B::X>(qq, r.x)), lf_mul(p.y, ppp));
+  r.zz = lf_mul(p.zz, pp);
+  r.zzz = lf_mul(p.zzz, ppp);
+  return r;
+}
+template <class F> GL_HD JacT<F> xyzz_to_jac_loose(const XyzzT<F> &p) {
+  if (f_is_zero(p.zz)) return jac_inf<F>();
+  return xyzz_to_jac(xyzz_canon(p));  // the canonical functions want canonical operands
 }
 
 template <class F> GL_HD JacT<F> jac_neg(const JacT<F> &p) { return {p.x, f_sub(Field<F>::zero(), p.y), p.z}; }

@@ -234,8 +234,8 @@ __global__ __launch_bounds__(128) void k_bucket_sum(const AffineT<F> *__restrict
   const uint32_t cnt = counts[b];  // 0 for digit 0 (k_hist skips it)
   if (cnt > (HEAVY << hs)) return;  // k_heavy_sum writes this one
   const uint32_t *idx = sorted + w * n + offsets[b];
-  for (uint32_t i = 0; i < cnt; i++) acc = bls::xyzz_add_mixed(acc, entry_point(pts, idx[i]));
-  buckets[b] = bls::xyzz_to_jac(acc);
+  for (uint32_t i = 0; i < cnt; i++) acc = bls::xyzz_add_mixed_loose(acc, entry_point(pts, idx[i]));
+  buckets[b] = bls::xyzz_to_jac_loose(acc);
 }
 
 // Skewed scalars (few distinct digits in a window; witness vectors full of 0 / 1: gnark witnesses are mostly bits) put
@@ -271,8 +271,8 @@ __global__ __launch_bounds__(256) void k_heavy_sum(const AffineT<F> *__restrict_
   const size_t w = ch.bucket / nbs;
   const uint32_t *idx = sorted + w * n + offsets[ch.bucket] + ch.first;
   bls::XyzzT<F> acc = bls::xyzz_inf<F>();
-  for (uint32_t t = threadIdx.x; t < ch.count; t += HEAVY_LANES<F>) acc = bls::xyzz_add_mixed(acc, entry_point(pts, idx[t]));
-  part[threadIdx.x] = bls::xyzz_to_jac(acc);
+  for (uint32_t t = threadIdx.x; t < ch.count; t += HEAVY_LANES<F>) acc = bls::xyzz_add_mixed_loose(acc, entry_point(pts, idx[t]));
+  part[threadIdx.x] = bls::xyzz_to_jac_loose(acc);
   __syncthreads();
   for (int half = HEAVY_LANES<F> / 2; half >= 1; half >>= 1) {
     if ((int)threadIdx.x < half) part[threadIdx.x] = bls::jac_add(part[threadIdx.x], part[threadIdx.x + half]);

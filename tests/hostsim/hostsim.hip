@@ -113,6 +113,38 @@ static int hs_group_op(int op, const uint32_t *p_xy, int p_inf, const uint32_t *
   }
   return bls::jac_to_affine_canonical(r, out_xy) ? 1 : 0;
 }
+// the bucket accumulation on loose (bounded, unreduced) values: sum of n affine points (xy: n x 2 x WORDS canonical words,
+// none at infinity) through xyzz_add_mixed_loose, result canonical affine; returns 1 for infinity. max_bound_p (optional):
+// the largest coordinate component seen, in units of p rounded up — what LooseBound promises is checked by the caller.
+template <class F>
+static int hs_bucket_chain(const uint32_t *xy, size_t n, uint32_t *out_xy) {
+  constexpr int W = bls::Field<F>::WORDS;
+  bls::XyzzT<F> acc = bls::xyzz_inf<F>();
+  for (size_t i = 0; i < n; i++) acc = bls::xyzz_add_mixed_loose(acc, bls::affine_from_canonical<F>(xy + 2 * W * i));
+  return bls::jac_to_affine_canonical(bls::xyzz_to_jac_loose(acc), out_xy) ? 1 : 0;
+}
+extern "C" {
+int hs_bls_g1_chain(const uint32_t *xy, size_t n, uint32_t *out_xy) { return hs_bucket_chain<bls::Fp>(xy, n, out_xy); }
+int hs_bls_g2_chain(const uint32_t *xy, size_t n, uint32_t *out_xy) { return hs_bucket_chain<bls::Fp2>(xy, n, out_xy); }
+// loose field primitives against Python integers: op 0 lz_mul, 1 lz_add, 2 lz_sub<8>, 3 lz_weak<16>, 4 lz_canon; a, b: 14 raw limbs
+void hs_bls_lz_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *out) {
+  bls::Fp x, y, r;
+  for (int i = 0; i < bls::NL; i++) x.l[i] = a[i], y.l[i] = b[i];
+  switch (op) {
+    case 0: r = bls::lz_mul(x, y); break;
+    case 1: r = bls::lz_add(x, y); break;
+    case 2: r = bls::lz_sub<8>(x, y); break;
+    case 3: r = bls::lz_weak<16>(x); break;
+    default: r = bls::lz_canon(x); break;
+  }
+  for (int i = 0; i < bls::NL; i++) out[i] = r.l[i];
+}
+int hs_bls_lz_maybe_zero(const uint32_t *a) {
+  bls::Fp x;
+  for (int i = 0; i < bls::NL; i++) x.l[i] = a[i];
+  return bls::lz_maybe_zero(x) ? 1 : 0;
+}
+}
 extern "C" {
 int hs_bls_g1_op(int op, const uint32_t *p_xy, int p_inf, const uint32_t *q_xy, int q_inf, uint32_t k, uint32_t *out_xy) {
   return hs_group_op<bls::Fp>(op, p_xy, p_inf, q_xy, q_inf, k, out_xy);

@@ -215,6 +215,111 @@ def test_bls_field_ops_match_python_integers(hs):
         assert _from_w32(out) == a * a % p, hex(a)
 
 
+def _limbs28(v):
+    return (ctypes.c_uint32 * 14)(*[(int(v) >> (28 * i)) & ((1 << 28) - 1) for i in range(14)])
+
+
+def _from_limbs28(w):
+    return sum(int(x) << (28 * i) for i, x in enumerate(w))
+
+
+def test_bls_loose_field_primitives(hs):
+    """The bounded-but-unreduced arithmetic of the bucket accumulation (bls12_381.h "loose arithmetic"): each primitive
+    returns normalised limbs, the value it promises (an exact integer for add / sub / weak, a residue below 2p for the
+    product), for operands anywhere below 32 p — and for the product also with limbs up to 2^29."""
+    p, r, G = O.bls_constants()
+    R = 1 << 392
+    rng = np.random.default_rng(14)
+    out = (ctypes.c_uint32 * 14)()
+    M28 = (1 << 28) - 1
+
+    def call(op, a, b=0):
+        hs.hs_bls_lz_op(op, _limbs28(a) if isinstance(a, int) else a, _limbs28(b) if isinstance(b, int) else b, out)
+        assert all(x <= M28 for x in out), "limbs not normalised"
+        return _from_limbs28(out)
+    vals = [0, 1, p - 1, p, p + 1, 2 * p - 1, 8 * p, 16 * p - 1, 16 * p, 22 * p - 1, 31 * p, 32 * p - 1]
+    vals += [int.from_bytes(rng.bytes(49), "little") % (32 * p) for _ in range(40)]
+    Rinv = pow(R, -1, p)
+    for a in vals:
+        for b in vals[::3]:
+            if a * b < R * p:
+                got = call(0, a, b)
+                assert got < 2 * p and got % p == a * b * Rinv % p, (hex(a), hex(b))
+            if a + b < R:
+                assert call(1, a, b) == a + b
+            if b <= 8 * p:
+                assert call(2, a, b) == a + 8 * p - b
+        assert call(3, a) == (a - 16 * p if a >= 16 * p else a)
+        assert call(4, a) == a % p                                  # a R / R: the canonical value of a
+        if a % p == 0:
+            assert hs.hs_bls_lz_maybe_zero(_limbs28(a)) == 1
+    # the zero filter: every multiple of p below 32 p passes; random values pass with probability 2^-23
+    assert all(hs.hs_bls_lz_maybe_zero(_limbs28(k * p)) == 1 for k in range(32))
+    assert sum(hs.hs_bls_lz_maybe_zero(_limbs28(int.from_bytes(rng.bytes(49), "little") % (32 * p))) for _ in range(2000)) <= 1
+    # product operands with unnormalised limbs (< 2^29: a carry-free sum of two normalised values)
+    for _ in range(50):
+        x = [int(v) for v in rng.integers(0, 1 << 28, 14)]
+        y = [int(v) for v in rng.integers(0, 1 << 28, 14)]
+        z = [int(v) for v in rng.integers(0, 1 << 28, 14)]
+        x[13] = y[13] = z[13] = 0x1000            # keep the values below a few p
+        s = (ctypes.c_uint32 * 14)(*[u + v for u, v in zip(x, y)])
+        zz = (ctypes.c_uint32 * 14)(*z)
+        sv, zv = _from_limbs28(s), _from_limbs28(zz)
+        if sv * zv < R * p:
+            got = call(0, s, zz)
+            assert got < 2 * p and got % p == sv * zv * Rinv % p
+
+
+def test_bls_loose_bucket_accumulation(hs):
+    """xyzz_add_mixed_loose chained like k_bucket_sum does, G1 and G2: sums of random points, runs that hit the doubling
+    branch (the same point twice in a row, and a point equal to the running sum), and cancellation to infinity and on."""
+    p, r, G = O.bls_constants()
+    G2 = O.bls_g2_generator()
+    rng = np.random.default_rng(15)
+
+    def flat1(P):
+        return list(_w32(P[0])) + list(_w32(P[1]))
+
+    def flat2(P):
+        return list(_w32(P[0][0])) + list(_w32(P[0][1])) + list(_w32(P[1][0])) + list(_w32(P[1][1]))
+
+    def chain1(pts):
+        xy = (ctypes.c_uint32 * (24 * len(pts)))(*[w for P in pts for w in flat1(P)])
+        out = (ctypes.c_uint32 * 24)()
+        inf = hs.hs_bls_g1_chain(xy, len(pts), out)
+        return None if inf else (_from_w32(out[:12]), _from_w32(out[12:]))
+
+    def chain2(pts):
+        xy = (ctypes.c_uint32 * (48 * len(pts)))(*[w for P in pts for w in flat2(P)])
+        out = (ctypes.c_uint32 * 48)()
+        inf = hs.hs_bls_g2_chain(xy, len(pts), out)
+        return None if inf else ((_from_w32(out[:12]), _from_w32(out[12:24])), (_from_w32(out[24:36]), _from_w32(out[36:])))
+
+    def total(add, pts):
+        acc = None
+        for P in pts:
+            acc = P if acc is None else add(acc, P)
+        return acc
+    ks = [int.from_bytes(rng.bytes(32), "little") % r for _ in range(40)]
+    g1 = [O.bls_g1_mul(G, k) for k in ks]
+    assert chain1(g1) == total(O.bls_g1_add, g1)
+    assert chain1(g1[:1]) == g1[0]
+    A, B = g1[0], g1[1]
+    assert chain1([A, A]) == O.bls_g1_mul(A, 2)                                  # doubling as the second addition
+    assert chain1([A, B, O.bls_g1_add(A, B), g1[2]]) == O.bls_g1_add(O.bls_g1_mul(O.bls_g1_add(A, B), 2), g1[2])   # x equal to the running sum's
+    negA = (A[0], p - A[1])
+    assert chain1([A, negA]) is None                                             # cancellation
+    assert chain1([A, negA, B, g1[3]]) == O.bls_g1_add(B, g1[3])                 # ... and on from infinity
+    g2 = [O.bls_g2_mul(G2, k) for k in ks[:24]]
+    assert chain2(g2) == total(O.bls_g2_add, g2)
+    C, D = g2[0], g2[1]
+    assert chain2([C, C]) == O.bls_g2_mul(C, 2)
+    assert chain2([C, D, O.bls_g2_add(C, D), g2[2]]) == O.bls_g2_add(O.bls_g2_mul(O.bls_g2_add(C, D), 2), g2[2])
+    negC = (C[0], ((p - C[1][0]) % p, (p - C[1][1]) % p))
+    assert chain2([C, negC]) is None
+    assert chain2([C, negC, D, g2[3]]) == O.bls_g2_add(D, g2[3])
+
+
 def test_bls_group_law_matches_oracle(hs):
     p, r, G = O.bls_constants()
     rng = np.random.default_rng(5)
