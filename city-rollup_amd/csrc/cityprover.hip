@@ -61,6 +61,49 @@ int get_prescale_table(cp_ctx *ctx, int log_n, int rate_bits, uint64_t shift, co
   return CP_OK;
 }
 
+// Power-on self-test of the arithmetic that is written below the compiler (gl.h: three `asm` blocks with hand-placed wait
+// states): a dozen products through every carry / borrow path and one permutation, against the same headers compiled for the
+// host (portable C paths). Run once per context; a device that disagrees never gets to prove anything.
+__global__ void k_self_test(const uint64_t *__restrict__ a, const uint64_t *__restrict__ b, uint64_t *__restrict__ out, int n_mul) {
+  const int i = threadIdx.x;
+  if (i < n_mul) out[i] = gl::mul(a[i], b[i]);
+  if (i == 63) {
+    uint64_t s[poseidon::W];
+    for (int k = 0; k < poseidon::W; k++) s[k] = a[k];
+    poseidon::permute(s);
+    for (int k = 0; k < poseidon::W; k++) out[n_mul + k] = s[k];
+  }
+}
+int power_on_self_test(cp_ctx *ctx) {
+  constexpr int N = 16;
+  const uint64_t M = ~0ull, P = gl::P;
+  // canonical and lazy operands; (2^48, 3 2^48), (2^32 u, 2^32 k) and a small low product take the borrow of lo - w3
+  const uint64_t a[N] = {0, 1, P - 1, P - 1, M, M, 1ull << 48, 0xFFFFFFFFull << 32, 0x123456789ABCDEF1ull, 0xFFFFFFFF00000000ull,
+                         0x8000000080000000ull, 0xFFFFFFFEFFFFFFFFull, 0xdeadbeefull << 32, 0x9E3779B97F4A7C15ull, 3, P + 5};
+  const uint64_t b[N] = {M, M, P - 1, 2, M, P, 3ull << 48, 0xFFFFFFFFull << 32, 0xF0E1D2C3B4A59687ull, 0xFFFFFFFF00000001ull,
+                         0x8000000080000000ull, 0xFFFFFFFEFFFFFFFFull, 0xfeedfaceull << 32, 0xD1B54A32D192ED03ull, M / 3, M - 7};
+  uint64_t want[N + poseidon::W], got[N + poseidon::W];
+  for (int i = 0; i < N; i++) want[i] = gl::mul(a[i], b[i]);
+  {
+    uint64_t s[poseidon::W];
+    for (int k = 0; k < poseidon::W; k++) s[k] = a[k];
+    poseidon::permute(s);
+    for (int k = 0; k < poseidon::W; k++) want[N + k] = s[k];
+  }
+  CP_TRY(ensure_scratch(ctx, (3 * N + poseidon::W) * sizeof(uint64_t)));
+  uint64_t *da = (uint64_t *)ctx->scratch, *db = da + N, *dout = db + N;
+  CP_TRY(cp_h2d(ctx, da, a, sizeof a));
+  CP_TRY(cp_h2d(ctx, db, b, sizeof b));
+  LAUNCH(ctx, "self_test", k_self_test, dim3(1), dim3(64), da, db, dout, N);
+  CP_TRY(cp_d2h(ctx, got, dout, sizeof got));
+  if (hostu::fault_fires(CP_FAULT_SELFTEST)) got[7] ^= 1;  // cp_fault_inject: what a mis-executing device would look like
+  for (int i = 0; i < N + poseidon::W; i++)
+    if (got[i] != want[i])
+      return set_error(ctx, CP_ERR_INTERNAL, "device arithmetic self-test failed (%s %d): this GPU does not execute the field kernels correctly",
+                       i < N ? "product" : "permutation word", i < N ? i : i - N);
+  return CP_OK;
+}
+
 int upload_constants(cp_ctx *ctx) {
   HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_RC), POSEIDON_RC, sizeof POSEIDON_RC));
   HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DK), POSEIDON_DOM_K, sizeof POSEIDON_DOM_K));
@@ -259,7 +302,7 @@ extern "C" {
 int cp_abi_version(void) { return CP_ABI_VERSION; }
 
 int cp_fault_inject(int kind, long after) {
-  if (kind != CP_FAULT_THREAD && kind != CP_FAULT_ALLOC) return set_error(nullptr, CP_ERR_INVALID_ARG, "unknown fault kind %d", kind);
+  if (kind != CP_FAULT_THREAD && kind != CP_FAULT_ALLOC && kind != CP_FAULT_SELFTEST) return set_error(nullptr, CP_ERR_INVALID_ARG, "unknown fault kind %d", kind);
   hostu::fault_counter(kind).store(after < 0 ? -1 : after);
   return CP_OK;
 }
@@ -298,7 +341,7 @@ cp_ctx *cp_ctx_create(int device) try {
   if (e != hipSuccess) return fail("hipSetDevice", e);
   e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) return fail("hipStreamCreate", e);
-  if (upload_constants(ctx) != CP_OK) {
+  if (upload_constants(ctx) != CP_OK || power_on_self_test(ctx) != CP_OK) {
     std::string msg = ctx->error;
     hipStreamDestroy(ctx->stream);
     delete ctx;

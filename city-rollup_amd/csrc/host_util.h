@@ -13,8 +13,8 @@ namespace hostu {
 
 // cp_fault_inject: counters of events still to pass before one fails; < 0 = disarmed
 inline std::atomic<long> &fault_counter(int kind) {
-  static std::atomic<long> c[2] = {{-1}, {-1}};
-  return c[kind & 1];
+  static std::atomic<long> c[4] = {{-1}, {-1}, {-1}, {-1}};
+  return c[kind & 3];
 }
 inline bool fault_fires(int kind) {
   std::atomic<long> &c = fault_counter(kind);

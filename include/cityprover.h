@@ -77,8 +77,11 @@ const char *cp_last_error(cp_ctx *ctx);
  * the worker process must turn every failure into a status): the `after`-th (0 = the next) event of `kind` in this
  * process fails once - CP_FAULT_THREAD: creation of an internal worker thread (the library must carry on on the calling
  * thread: same results); CP_FAULT_ALLOC: a host allocation checkpoint inside a proving / verifying call throws
- * std::bad_alloc (the call must return CP_ERR_OOM and leave the context usable). after < 0 disarms. */
-enum { CP_FAULT_THREAD = 0, CP_FAULT_ALLOC = 1 };
+ * std::bad_alloc (the call must return CP_ERR_OOM and leave the context usable); CP_FAULT_SELFTEST: the power-on self-test
+ * of the device arithmetic that cp_ctx_create runs (a dozen field products through every carry path and one Poseidon
+ * permutation, against the host's portable code) sees a wrong answer - cp_ctx_create must return NULL with the reason.
+ * after < 0 disarms. */
+enum { CP_FAULT_THREAD = 0, CP_FAULT_ALLOC = 1, CP_FAULT_SELFTEST = 2 };
 int cp_fault_inject(int kind, long after);
 
 /* ---- device memory & stream ---------------------------------------------------------- */

@@ -126,6 +126,22 @@ def test_verify_rejects_noncanonical_elements_and_extended_public_inputs(prover)
     circ.close()
 
 
+def test_power_on_self_test_guards_context_creation():
+    """cp_ctx_create runs the device arithmetic self-test (field products through every carry path + one permutation against
+    the host's portable code). A device that answers wrongly — simulated by cp_fault_inject — gets no context."""
+    import cityprover as cp
+    lib = cp.load_library()
+    assert lib.cp_fault_inject(2, 0) == 0
+    try:
+        with pytest.raises(cp.CityProverError, match="self-test failed"):
+            cp.Prover(0)
+    finally:
+        lib.cp_fault_inject(2, -1)
+    p = cp.Prover(0)          # and the next context is fine
+    assert (p.field_mul([3], [5]) == [15]).all()
+    p.close()
+
+
 def test_fault_injection_threads_and_allocations(prover):
     """include/cityprover.h: "NEVER abort or throw". A worker thread that cannot be created is done without (same
     bytes); a std::bad_alloc inside a proving / verifying call comes back as CP_ERR_OOM and the context stays usable."""
