@@ -19,6 +19,16 @@
 
 namespace msm {
 
+// the bucket accumulation runs on bounded, unreduced field values (bls12_381.h "loose arithmetic");
+// -DBLS_CANONICAL_ACCUMULATION keeps every value reduced, for A/B measurements
+#if defined(BLS_CANONICAL_ACCUMULATION)
+template <class F> GL_HD bls::XyzzT<F> bucket_add(const bls::XyzzT<F> &p, const bls::AffineT<F> &q) { return bls::xyzz_add_mixed(p, q); }
+template <class F> GL_HD bls::JacT<F> bucket_out(const bls::XyzzT<F> &p) { return bls::xyzz_to_jac(p); }
+#else
+template <class F> GL_HD bls::XyzzT<F> bucket_add(const bls::XyzzT<F> &p, const bls::AffineT<F> &q) { return bls::xyzz_add_mixed_loose(p, q); }
+template <class F> GL_HD bls::JacT<F> bucket_out(const bls::XyzzT<F> &p) { return bls::xyzz_to_jac_loose(p); }
+#endif
+
 using bls::AffineT;
 using bls::Field;
 using bls::JacT;
@@ -234,8 +244,8 @@ __global__ __launch_bounds__(128) void k_bucket_sum(const AffineT<F> *__restrict
   const uint32_t cnt = counts[b];  // 0 for digit 0 (k_hist skips it)
   if (cnt > (HEAVY << hs)) return;  // k_heavy_sum writes this one
   const uint32_t *idx = sorted + w * n + offsets[b];
-  for (uint32_t i = 0; i < cnt; i++) acc = bls::xyzz_add_mixed_loose(acc, entry_point(pts, idx[i]));
-  buckets[b] = bls::xyzz_to_jac_loose(acc);
+  for (uint32_t i = 0; i < cnt; i++) acc = bucket_add(acc, entry_point(pts, idx[i]));
+  buckets[b] = bucket_out(acc);
 }
 
 // Skewed scalars (few distinct digits in a window; witness vectors full of 0 / 1: gnark witnesses are mostly bits) put
@@ -271,8 +281,8 @@ __global__ __launch_bounds__(256) void k_heavy_sum(const AffineT<F> *__restrict_
   const size_t w = ch.bucket / nbs;
   const uint32_t *idx = sorted + w * n + offsets[ch.bucket] + ch.first;
   bls::XyzzT<F> acc = bls::xyzz_inf<F>();
-  for (uint32_t t = threadIdx.x; t < ch.count; t += HEAVY_LANES<F>) acc = bls::xyzz_add_mixed_loose(acc, entry_point(pts, idx[t]));
-  part[threadIdx.x] = bls::xyzz_to_jac_loose(acc);
+  for (uint32_t t = threadIdx.x; t < ch.count; t += HEAVY_LANES<F>) acc = bucket_add(acc, entry_point(pts, idx[t]));
+  part[threadIdx.x] = bucket_out(acc);
   __syncthreads();
   for (int half = HEAVY_LANES<F> / 2; half >= 1; half >>= 1) {
     if ((int)threadIdx.x < half) part[threadIdx.x] = bls::jac_add(part[threadIdx.x], part[threadIdx.x + half]);
