@@ -253,16 +253,19 @@ def main():
     out += "// partial-round constants pushed forward through the MDS (gen_tables.plane_constants)\n"
     out += c_array("POSEIDON_PLANE_K", PK)
     out += c_array("POSEIDON_PLANE_LAST", PLAST)
-    # for the transformed-domain partial rounds (poseidon.h): every partial round has only its scalar; the limb sums there are
-    # signed, so 2^30 is added to each of the three 22-bit limbs before the 96-bit recombination and taken out of the constant here
+    # for the transformed-domain partial rounds (poseidon.h): every partial round has only its scalar
     DK, DLAST = plane_constants(RC, first_too=True)
     for _ in range(4):
         s = [rnd.randrange(P) for _ in range(W)]
         assert perm_planes(s, RC, DK, DLAST, first_too=True) == perm_naive(s, RC)
-    bias = (1 << 30) * (1 + (1 << 22) + (1 << 44)) % P
-    out += "// the same with the first partial round treated like the others, minus the limb bias 2^30 (1 + 2^22 + 2^44)\n"
-    out += c_array("POSEIDON_DOM_K", [(k - bias) % P for k in DK])
-    out += c_array("POSEIDON_DOM_LAST", [(k - bias) % P for k in DLAST])
+    # the layers run on two 32-bit limb planes in double precision: the limbs are turned into integers by adding 1.5 * 2^52,
+    # which leaves limb + 2^51 in the mantissa
+    biasd = (1 << 51) * (1 + (1 << 32)) % P
+    out += "// constants minus 2^51 (1 + 2^32), the offset of the double -> integer conversion of two 32-bit limbs: the round\n"
+    out += "// constants (+ one entry for \"none\"), and the partial-round constants pushed forward with the first round treated like the others\n"
+    out += c_array("POSEIDON_RCD", [(k - biasd) % P for k in RC] + [(-biasd) % P])  # round constants for mds_layer_d; [360] = no constant
+    out += c_array("POSEIDON_DOMD_K", [(k - biasd) % P for k in DK])
+    out += c_array("POSEIDON_DOMD_LAST", [(k - biasd) % P for k in DLAST])
     out += "// primitive 2^k-th roots of unity, k = 0..32 (7^((p-1)/2^k))\n"
     out += c_array("GL_ROOTS", roots)
     out += c_array("GL_ROOTS_INV", [pow(r, P - 2, P) for r in roots])

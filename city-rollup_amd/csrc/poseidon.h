@@ -7,14 +7,14 @@
 // One lane owns one 12-element state (24 VGPRs): no cross-lane traffic, pure 32-bit integer VALU, bound by instruction
 // issue. What shapes the code (measured on MI355X, profiles/r01_ubench_valu.txt, r02_ubench_poseidon.txt):
 //   * a 64-bit modular multiplication is 15 instructions (gl.h: `mul_wide`, `fold_top` — two carry-outs taken in `asm`);
-//   * the MDS layer (circulant, entries <= 41, + diag 8) uses NO multiplies at all: each element
-//     is split into three 22-bit limbs and the length-12 cyclic convolution is evaluated per limb
-//     in wrap-around 32-bit arithmetic through the CRT split
+//   * the MDS layer (circulant, entries <= 41, + diag 8) uses NO integer multiplies at all: the length-12 cyclic
+//     convolution is evaluated per limb plane through the CRT split
 //         x^12-1 = (x^6-1)(x^6+1),  x^6-1 = (x^3-1)(x^3+1)
-//     whose transformed kernels are all +-powers of two ([16,16,32], [-1,-8,2], [2,-4,16,1,-1,-1])
-//     -> ~90 shift-adds per limb instead of 288 quarter-rate mads per state;
+//     whose transformed kernels are all +-powers of two ([16,16,32], [-1,-8,2], [2,-4,16,1,-1,-1]): ~90 operations per plane
+//     instead of 288 multiply-adds per state — on two 32-bit limb planes in DOUBLE PRECISION (exact: everything stays below
+//     2^53; `mds_layer_d`), which beat the three 22-bit integer planes of `mds_limb` by 15 % on the whole permutation;
 //   * state is carried lazily (any u64 congruent to the value); the next round's constant is
-//     folded into the 96-bit recombination, and only the final output is canonicalised;
+//     folded into the recombination, and only the final output is canonicalised;
 //   * the 22 partial rounds never leave the transformed domain of that CRT split (see `permute_until`).
 #pragma once
 #include "gl.h"
@@ -38,25 +38,33 @@ GL_HD uint64_t rc(int i) {
   return POSEIDON_RC[i];
 #endif
 }
-// partial-round constants pushed forward through the MDS (gen_tables.plane_constants): one scalar per partial round on
-// element 0, one vector after the last; both minus the limb bias of the signed recombination (DOM_BIAS)
-__constant__ uint64_t d_DK[PARTIAL];
-__constant__ uint64_t d_DLAST[W];
-GL_HD uint64_t dom_k(int i) {
+// Constants of the double-precision layers, all minus 2^51 (1 + 2^32) — the offset of their limb -> integer conversion
+// (`recombine_d`): RCD = the round constants (+ one entry for "no constant"); DDK / DDLAST = the partial-round constants pushed
+// forward through the MDS (gen_tables.plane_constants: one scalar per partial round on element 0, one vector after the last).
+__constant__ uint64_t d_RCD[ROUNDS * W + 1];
+GL_HD uint64_t rcd(int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return d_DK[i];
+  return d_RCD[i];
 #else
-  return POSEIDON_DOM_K[i];
+  return POSEIDON_RCD[i];
 #endif
 }
-GL_HD uint64_t dom_last(int i) {
+__constant__ uint64_t d_DDK[PARTIAL];
+__constant__ uint64_t d_DDLAST[W];
+GL_HD uint64_t domd_k(int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return d_DLAST[i];
+  return d_DDK[i];
 #else
-  return POSEIDON_DOM_LAST[i];
+  return POSEIDON_DOMD_K[i];
 #endif
 }
-
+GL_HD uint64_t domd_last(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return d_DDLAST[i];
+#else
+  return POSEIDON_DOMD_LAST[i];
+#endif
+}
 // ---- lazy field helpers: inputs/outputs are arbitrary u64 congruent to the value ----------
 using gl::fold_top;
 GL_HD uint64_t mul_lazy(uint64_t a, uint64_t b) {
@@ -187,42 +195,111 @@ GL_HD void permute_textbook(uint64_t (&s)[W]) {
   for (int i = 0; i < W; i++) s[i] = gl::canon(s[i]);
 }
 
-// ---- partial rounds in the transformed domain of the circulant --------------------------------------------
-// Only element 0 meets an S-box in a partial round; the other eleven go from one MDS straight into the next, and they
-// need no round constants at all — those are pushed forward through the MDS offline (gen_tables.plane_constants: one
-// scalar per round on element 0, one vector at the end). Between two MDS layers T . T^-1' is only a scaling: if
-// o = (E, F, v) are the products of one layer, the next layer's transformed input is T(y) = (4E, 4F, 2v). So the state
-// stays in the domain for all 22 rounds, as three limb planes of field elements mod p with SIGNED limbs:
-//   * per round and plane the 36 butterfly additions are gone; the scaling is folded into the carry normalisation
-//     (`renorm_scaled`), which also replaces recombine-to-u64 + split-again;
-//   * element 0 of the state is read off the products as E0 + F0 + v0 + 8 * (previous S-box output) — exact integer
-//     limbs — recombined, S-boxed, split; the difference to what the domain holds for it is added to aa0, ab0, b0 (T of the
-//     unit vector) before those three components are normalised;
-//   * a negative top limb folds like a positive one (2^64 == 2^32 - 1: + top 2^10 on plane 1, - top on plane 0), so the
-//     normalisation needs no borrow handling.
-// Magnitudes: normalised limbs lie in (-2^19, 2^22 + 2^19) (top limb [0, 2^20)); |products| <= 64 x that < 2^28.2, times 4
-// < 2^30.2; the element-0 components before their normalisation < 2^30.2 + 2^28.3 + 2^25 < 2^31. Entering from the full
-// rounds (limbs < 2^22, so aa < 2^24 would give products up to 2^30) the three aa components are normalised first.
-// tests/test_hostsim.py checks the bounds with interval arithmetic and the permutation against the oracle.
-constexpr uint32_t DOM_BIAS = 1u << 30;  // makes the signed element-0 limbs (|.| < 2^29) non-negative for `recombine`
-// signed carry normalisation in place: |y*| <= 2^31 - 2^10, same value mod p
-GL_HD void renorm_s(uint32_t &y0, uint32_t &y1, uint32_t &y2) {
-  const int32_t t1 = (int32_t)y1 + ((int32_t)y0 >> 22);
-  const int32_t t2 = (int32_t)y2 + (t1 >> 22);
-  const int32_t top = t2 >> 20;
-  y0 = (y0 & 0x3FFFFFu) - (uint32_t)top;
-  y1 = ((uint32_t)t1 & 0x3FFFFFu) + ((uint32_t)top << 10);
-  y2 = (uint32_t)t2 & 0xFFFFFu;
+// ---- the linear layers on TWO 32-bit limb planes in double precision -------------------------------------------------
+// v_fma_f64 issues at the rate of the integer VOP3 forms (4.3 cycles per wave64, profiles/r01_ubench_valu.txt) and a double
+// holds 53 bits exactly: a 32-bit limb has room for TWO layers of growth (2 x 8 bits) plus two fractional bits, so the MDS
+// needs two planes instead of the three 22-bit integer planes of `mds_limb`, the products by +-2^k are single fused
+// multiply-adds with the sign in the constant, and a carry normalisation is needed every second layer only. All arithmetic
+// is exact (integers and quarter-integers below 2^53; multiplications by powers of two): no rounding ever happens, the
+// result is bit-identical to the integer formulation (`permute_textbook` keeps that one; tests compare the two).
+//
+// Partial rounds in the transformed domain of the circulant. Only element 0 meets an S-box in a partial round; the other
+// eleven go from one MDS straight into the next, and they need no round constants at all — those are pushed forward through
+// the MDS offline. Between two layers T . T^-1' is only a scaling: if o = (E, F, v) are the products of one layer, the next
+// layer's transformed input is T(y) = (4E, 4F, 2v). So the state never leaves the domain for all 22 rounds:
+//   * the state is kept as W = (E, F, v), the products of the last layer, i.e. the transformed state divided by (4, 4, 2) —
+//     the scaling T . T^-1' = diag(4, 4, 2) goes into the constants of the next layer's products (64, 64, 128 / 4, 32, 8 /
+//     4, 8, 32, 2, 2, 2), and replacing element 0 by its S-box output adds (new - z) / 4 to aa0 and ab0 and (new - z) / 2 to b0:
+//     exact quarter-integers;
+//   * limb -> integer is (limb + 1.5 * 2^52), whose mantissa holds limb + 2^51 (the offsets are taken out of the constant
+//     offline); carry extraction is (x + 1.5 * 2^84) - 1.5 * 2^84, the multiple of 2^32 nearest to x (balanced remainders).
+// Magnitudes (tests/test_hostsim.py replays them): a normalised limb is within 2^31 + 2^20 of zero; a layer multiplies by at
+// most 256 (aa), 44 (ab), 50 (b); element 0 is E0 + F0 + v0 < 350 x the layer's input; two layers after a normalisation every
+// limb is below 2^48.6 with two fractional bits — 51 of the 53 bits — and the limb -> integer conversion is good to 2^51.
+// Index layout of a plane as before: [0..2] = aa, [3..5] = ab, [6..11] = b. SCALED: the input is W; else the transformed state.
+template <bool SCALED>
+GL_HD void dom_mul_d(const double (&u)[W], double (&o)[W]) {
+  constexpr double A = SCALED ? 64.0 : 16.0;
+  const double t = (u[0] + u[1] + u[2]) * A;
+  o[0] = __builtin_fma(u[2], A, t);
+  o[1] = __builtin_fma(u[0], A, t);
+  o[2] = __builtin_fma(u[1], A, t);
+  constexpr double B1 = SCALED ? 4.0 : 1.0, B2 = SCALED ? 8.0 : 2.0, B8 = SCALED ? 32.0 : 8.0;
+  o[3] = __builtin_fma(u[5], B8, __builtin_fma(u[3], -B1, u[4] * -B2));
+  o[4] = __builtin_fma(u[3], -B8, __builtin_fma(u[4], -B1, u[5] * -B2));
+  o[5] = __builtin_fma(u[3], B2, __builtin_fma(u[4], -B8, u[5] * -B1));
+  constexpr double S = SCALED ? 2.0 : 1.0;
+  constexpr double c[6][6] = {{2, 1, 1, -1, -16, 4},  {-4, 2, 1, 1, -1, -16}, {16, -4, 2, 1, 1, -1},
+                              {1, 16, -4, 2, 1, 1},   {-1, 1, 16, -4, 2, 1},  {-1, -1, 1, 16, -4, 2}};
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double acc = u[6] * (S * c[k][0]);
+#pragma unroll
+    for (int i = 1; i < 6; i++) acc = __builtin_fma(u[6 + i], S * c[k][i], acc);
+    o[6 + k] = acc;
+  }
 }
-// the same for 2^S * (o0, o1, o2), 2^S |o*| <= 2^31 - 2^10, without forming the scaled limbs
-template <int S>
-GL_HD void renorm_scaled(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t &l0, uint32_t &l1, uint32_t &l2) {
-  const int32_t t1 = (int32_t)(o1 << S) + ((int32_t)o0 >> (22 - S));
-  const int32_t t2 = (int32_t)(o2 << S) + (t1 >> 22);
-  const int32_t top = t2 >> 20;
-  l0 = ((o0 << S) & 0x3FFFFFu) - (uint32_t)top;
-  l1 = ((uint32_t)t1 & 0x3FFFFFu) + ((uint32_t)top << 10);
-  l2 = (uint32_t)t2 & 0xFFFFFu;
+GL_HD void dom_enter_d(const double (&s)[W], double (&u)[W]) {
+  double a[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    a[i] = s[i] + s[i + 6];
+    u[6 + i] = s[i] - s[i + 6];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    u[i] = a[i] + a[i + 3];
+    u[3 + i] = a[i] - a[i + 3];
+  }
+}
+GL_HD void dom_leave_d(const double (&o)[W], double (&y)[W]) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double p = o[i] + o[3 + i], q = o[i] - o[3 + i];
+    y[i] = p + o[6 + i];
+    y[i + 6] = p - o[6 + i];
+    y[i + 3] = q + o[9 + i];
+    y[i + 9] = q - o[9 + i];
+  }
+}
+// value l + 2^32 h: both limbs to within 2^31 (+ the folded top) of zero, same value mod p
+GL_HD void renorm_d(double &l, double &h) {
+  constexpr double MAGIC = 0x1.8p84, INV = 0x1p-32;  // (x + MAGIC) - MAGIC: x rounded to a multiple of 2^32
+  const double c = (l + MAGIC) - MAGIC;
+  l -= c;
+  h = __builtin_fma(c, INV, h);
+  const double t = (h + MAGIC) - MAGIC;  // t / 2^32 units of 2^64 == 2^32 - 1
+  h -= t;
+  h = __builtin_fma(t, INV, h);
+  l = __builtin_fma(t, -INV, l);
+}
+// integer limbs |l|, |h| < 2^51 -> lazy u64 congruent to l + 2^32 h + c + 2^51 (1 + 2^32)
+GL_HD uint64_t recombine_d(double l, double h, uint64_t c) {
+  constexpr double M52 = 0x1.8p52;
+  const uint64_t a0 = __builtin_bit_cast(uint64_t, l + M52) & 0xFFFFFFFFFFFFFull;
+  const uint64_t a1 = __builtin_bit_cast(uint64_t, h + M52) & 0xFFFFFFFFFFFFFull;
+  const gl::u128 acc = (gl::u128)c + a0 + ((gl::u128)a1 << 32);
+  return fold_top((uint64_t)acc, (uint32_t)(acc >> 64));
+}
+
+// s <- MDS * s + next_rc on two double-precision limb planes (next_rc_base < 0: no constant)
+GL_HD void mds_layer_d(uint64_t (&s)[W], int next_rc_base) {
+  double ll[W], lh[W], u[W], o[W], yl[W], yh[W];
+#pragma unroll
+  for (int i = 0; i < W; i++) {
+    ll[i] = (double)(uint32_t)s[i];
+    lh[i] = (double)(uint32_t)(s[i] >> 32);
+  }
+  dom_enter_d(ll, u);
+  dom_mul_d<false>(u, o);
+  dom_leave_d(o, yl);
+  yl[0] = __builtin_fma(ll[0], 8.0, yl[0]);
+  dom_enter_d(lh, u);
+  dom_mul_d<false>(u, o);
+  dom_leave_d(o, yh);
+  yh[0] = __builtin_fma(lh[0], 8.0, yh[0]);
+#pragma unroll
+  for (int i = 0; i < W; i++) s[i] = recombine_d(yl[i], yh[i], rcd(next_rc_base >= 0 ? next_rc_base + i : ROUNDS * W));
 }
 
 // `stop` is polled between rounds (every full round, every fourth partial round); when it answers true the permutation is
@@ -237,73 +314,62 @@ GL_HD bool permute_until(uint64_t (&s)[W], Stop stop) {
     if (stop()) return false;
 #pragma unroll
     for (int i = 0; i < W; i++) s[i] = sbox_lazy(s[i]);
-    mds_layer(s, (r + 1) * W);
+    mds_layer_d(s, (r + 1) * W);
   }
   {
     // the last full round before the partial rounds: S-boxes, then straight into the domain (no constants: all pushed forward)
-    uint32_t u0[W], u1[W], u2[W], o0[W], o1[W], o2[W];
-    uint32_t n0, n1, n2;  // limbs of the latest S-box output on element 0
+    double wl[W], wh[W], ol[W], oh[W];
+    double nl, nh;  // limbs of the latest S-box output on element 0
     {
-      uint32_t l0[W], l1[W], l2[W];
+      double ll[W], lh[W];
 #pragma unroll
       for (int k = 0; k < W; k++) {
         s[k] = sbox_lazy(s[k]);
-        split3(s[k], l0[k], l1[k], l2[k]);
+        ll[k] = (double)(uint32_t)s[k];
+        lh[k] = (double)(uint32_t)(s[k] >> 32);
       }
-      n0 = l0[0], n1 = l1[0], n2 = l2[0];
-      dom_enter(l0, u0);
-      dom_enter(l1, u1);
-      dom_enter(l2, u2);
-#pragma unroll
-      for (int k = 0; k < 3; k++) renorm_s(u0[k], u1[k], u2[k]);
-      dom_mul(u0, o0);
-      dom_mul(u1, o1);
-      dom_mul(u2, o2);
+      nl = ll[0], nh = lh[0];
+      dom_enter_d(ll, wl);
+      dom_enter_d(lh, wh);
+      dom_mul_d<false>(wl, ol);
+      dom_mul_d<false>(wh, oh);
     }
 #pragma unroll 1
     for (int i = 0; i < PARTIAL; i++) {
       if ((i & 3) == 0 && stop()) return false;
       // element 0 of the state: E0 + F0 + v0 + the diagonal 8 of the MDS on the previous S-box output
-      const uint32_t z0 = o0[0] + o0[3] + o0[6], z1 = o1[0] + o1[3] + o1[6], z2 = o2[0] + o2[3] + o2[6];
-      const uint64_t x = recombine(z0 + (n0 << 3) + DOM_BIAS, z1 + (n1 << 3) + DOM_BIAS, z2 + (n2 << 3) + DOM_BIAS, dom_k(i));
-      split3(sbox_lazy(x), n0, n1, n2);
-      // the nine components that do not see element 0 directly: scale and normalise
+      const double zl = ol[0] + ol[3] + ol[6], zh = oh[0] + oh[3] + oh[6];
+      const uint64_t x = sbox_lazy(recombine_d(__builtin_fma(nl, 8.0, zl), __builtin_fma(nh, 8.0, zh), domd_k(i)));
+      nl = (double)(uint32_t)x;
+      nh = (double)(uint32_t)(x >> 32);
+      // W = (E, F, v) with element 0 replaced: + (new - z) / 4 on aa0, ab0, / 2 on b0
+      const double dl = nl - zl, dh = nh - zh;
 #pragma unroll
-      for (int k = 1; k < 3; k++) {
-        renorm_scaled<2>(o0[k], o1[k], o2[k], u0[k], u1[k], u2[k]);
-        renorm_scaled<2>(o0[3 + k], o1[3 + k], o2[3 + k], u0[3 + k], u1[3 + k], u2[3 + k]);
-      }
+      for (int k = 0; k < W; k++) wl[k] = ol[k], wh[k] = oh[k];
+      wl[0] = __builtin_fma(dl, 0.25, ol[0]), wh[0] = __builtin_fma(dh, 0.25, oh[0]);
+      wl[3] = __builtin_fma(dl, 0.25, ol[3]), wh[3] = __builtin_fma(dh, 0.25, oh[3]);
+      wl[6] = __builtin_fma(dl, 0.5, ol[6]), wh[6] = __builtin_fma(dh, 0.5, oh[6]);
+      if (i & 1) {
 #pragma unroll
-      for (int k = 7; k < W; k++) renorm_scaled<1>(o0[k], o1[k], o2[k], u0[k], u1[k], u2[k]);
-      // aa0, ab0, b0: scaled products + diagonal + (new element 0 - old element 0) = scaled products + new - z
-      {
-        const uint32_t d0 = n0 - z0, d1 = n1 - z1, d2 = n2 - z2;
-        u0[0] = (o0[0] << 2) + d0, u0[3] = (o0[3] << 2) + d0, u0[6] = (o0[6] << 1) + d0;
-        u1[0] = (o1[0] << 2) + d1, u1[3] = (o1[3] << 2) + d1, u1[6] = (o1[6] << 1) + d1;
-        u2[0] = (o2[0] << 2) + d2, u2[3] = (o2[3] << 2) + d2, u2[6] = (o2[6] << 1) + d2;
-        renorm_s(u0[0], u1[0], u2[0]);
-        renorm_s(u0[3], u1[3], u2[3]);
-        renorm_s(u0[6], u1[6], u2[6]);
+        for (int k = 0; k < W; k++) renorm_d(wl[k], wh[k]);
       }
-      dom_mul(u0, o0);
-      dom_mul(u1, o1);
-      dom_mul(u2, o2);
+      dom_mul_d<true>(wl, ol);
+      dom_mul_d<true>(wh, oh);
     }
-    // leave the domain: natural limbs (signed, |.| < 2^29), + what is pending of the constants
-    uint32_t y0[W], y1[W], y2[W];
-    dom_leave(o0, y0);
-    dom_leave(o1, y1);
-    dom_leave(o2, y2);
-    y0[0] += n0 << 3, y1[0] += n1 << 3, y2[0] += n2 << 3;
+    // leave the domain: natural limbs, + what is pending of the constants
+    double yl[W], yh[W];
+    dom_leave_d(ol, yl);
+    dom_leave_d(oh, yh);
+    yl[0] = __builtin_fma(nl, 8.0, yl[0]), yh[0] = __builtin_fma(nh, 8.0, yh[0]);
 #pragma unroll
-    for (int k = 0; k < W; k++) s[k] = recombine(y0[k] + DOM_BIAS, y1[k] + DOM_BIAS, y2[k] + DOM_BIAS, dom_last(k));
+    for (int k = 0; k < W; k++) s[k] = recombine_d(yl[k], yh[k], domd_last(k));
   }
 #pragma unroll 1
   for (int r = HALF_FULL + PARTIAL; r < ROUNDS; r++) {
     if (stop()) return false;
 #pragma unroll
     for (int i = 0; i < W; i++) s[i] = sbox_lazy(s[i]);
-    mds_layer(s, r + 1 < ROUNDS ? (r + 1) * W : -1);
+    mds_layer_d(s, r + 1 < ROUNDS ? (r + 1) * W : -1);
   }
 #pragma unroll
   for (int i = 0; i < W; i++) s[i] = gl::canon(s[i]);

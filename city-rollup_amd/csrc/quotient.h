@@ -182,14 +182,14 @@ __global__ __launch_bounds__(256) void k_quot_gate(Args a, int gi, int t0) {
       }
 #pragma unroll
       for (int k = 0; k < 12; k++) st[k] = poseidon::sbox_lazy(st[k]);
-      poseidon::mds_layer(st, (rnd + 1) * 12);
+      poseidon::mds_layer_d(st, (rnd + 1) * 12);
     }
 #pragma unroll 1
     for (int r = 0; r < 22; r++, rnd++) {
       uint64_t in = w[(size_t)(65 + r) * N];
       add_term(gl::sub(gl::canon(st[0]), in), c++);
       st[0] = poseidon::sbox_lazy(in);
-      poseidon::mds_layer(st, (rnd + 1) * 12);
+      poseidon::mds_layer_d(st, (rnd + 1) * 12);
     }
 #pragma unroll 1
     for (int r = 0; r < 4; r++, rnd++) {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_quot_gate(Args a, int gi, int t0) {
       }
 #pragma unroll
       for (int k = 0; k < 12; k++) st[k] = poseidon::sbox_lazy(st[k]);
-      poseidon::mds_layer(st, rnd + 1 < poseidon::ROUNDS ? (rnd + 1) * 12 : -1);
+      poseidon::mds_layer_d(st, rnd + 1 < poseidon::ROUNDS ? (rnd + 1) * 12 : -1);
     }
 #pragma unroll
     for (int k = 0; k < 12; k++) add_term(gl::sub(gl::canon(st[k]), w[(size_t)(12 + k) * N]), c++);

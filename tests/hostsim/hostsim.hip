@@ -21,22 +21,26 @@ void hs_poseidon_permute_textbook(uint64_t *states, size_t n) {
     for (int k = 0; k < 12; k++) states[12 * i + k] = s[k];
   }
 }
-// signed carry normalisations of the transformed-domain partial rounds: return the limbs; the value must be preserved mod p
-void hs_renorm(const uint32_t *y, uint32_t *l) {
-  l[0] = y[0], l[1] = y[1], l[2] = y[2];
-  poseidon::renorm_s(l[0], l[1], l[2]);
+// double-precision layers (poseidon.h): carry normalisation of a two-limb value; one plane through T / K / T^-1'
+void hs_renorm_d(const double *in, double *out) {
+  out[0] = in[0], out[1] = in[1];
+  poseidon::renorm_d(out[0], out[1]);
 }
-void hs_renorm_scaled(int s, const uint32_t *y, uint32_t *l) {
-  if (s == 2) poseidon::renorm_scaled<2>(y[0], y[1], y[2], l[0], l[1], l[2]);
-  else poseidon::renorm_scaled<1>(y[0], y[1], y[2], l[0], l[1], l[2]);
-}
-void hs_dom(int op, const uint32_t *s, uint32_t *y) {  // 0: dom_enter, 1: dom_mul, 2: dom_leave
-  uint32_t a[12], b[12];
+void hs_dom_d(int op, const double *s, double *y) {  // 0: dom_enter_d, 1: dom_mul_d<false>, 2: dom_mul_d<true>, 3: dom_leave_d
+  double a[12], b[12];
   for (int i = 0; i < 12; i++) a[i] = s[i];
-  if (op == 0) poseidon::dom_enter(a, b);
-  else if (op == 1) poseidon::dom_mul(a, b);
-  else poseidon::dom_leave(a, b);
+  if (op == 0) poseidon::dom_enter_d(a, b);
+  else if (op == 1) poseidon::dom_mul_d<false>(a, b);
+  else if (op == 2) poseidon::dom_mul_d<true>(a, b);
+  else poseidon::dom_leave_d(a, b);
   for (int i = 0; i < 12; i++) y[i] = b[i];
+}
+uint64_t hs_recombine_d(double l, double h, uint64_t c) { return poseidon::recombine_d(l, h, c); }
+void hs_mds_layer(uint64_t *s, int which) {  // 0: integer planes (mds_layer), 1: double-precision planes (mds_layer_d); no constant
+  uint64_t t[12];
+  for (int i = 0; i < 12; i++) t[i] = s[i];
+  if (which) poseidon::mds_layer_d(t, -1); else poseidon::mds_layer(t, -1);
+  for (int i = 0; i < 12; i++) s[i] = gl::canon(t[i]);
 }
 uint64_t hs_mul(uint64_t a, uint64_t b) { return gl::mul(a, b); }
 uint64_t hs_mul_lazy(uint64_t a, uint64_t b) { return poseidon::mul_lazy(a, b); }

@@ -112,80 +112,93 @@ def test_plane_resident_permute_equals_textbook(hs):
     assert (a == O.permute_many(st).reshape(-1, 12)).all()
 
 
-def _s32(v):
-    v &= 0xFFFFFFFF
-    return v - (1 << 32) if v >> 31 else v
-
-
-def test_signed_renorms_preserve_the_value_and_bounds(hs):
-    """Carry normalisations of the transformed-domain partial rounds (signed limbs): limbs within their bounds, value
-    congruent mod p — plain and with the scaling by 4 / 2 folded in — for extreme and random inputs."""
-    p32 = ctypes.POINTER(ctypes.c_uint32)
-    hs.hs_renorm.argtypes = [p32] * 2
-    hs.hs_renorm_scaled.argtypes = [ctypes.c_int, p32, p32]
+def test_double_precision_carry_normalisation(hs):
+    """renorm_d (poseidon.h): a value l + 2^32 h on two double-precision limbs — integers or quarter-integers up to 2^51 —
+    keeps its residue mod p exactly and comes back with both limbs within 2^31 + 2^20 of zero."""
+    from fractions import Fraction
+    pd = ctypes.POINTER(ctypes.c_double)
+    hs.hs_renorm_d.argtypes = [pd, pd]
     rng = np.random.default_rng(3)
-    B = (1 << 31) - (1 << 10)                            # the contract: |y*| <= 2^31 - 2^10 (the carries added stay in range)
-    cases = [(0, 0, 0), (B, B, B), (-B, -B, -B), (B, -B, B), (-B, B, -B), (0, 0, 1 << 20), (5, 0, -(1 << 20)), (-1, 0, 0), (0, -1, 0),
-             (0, 0, -1), ((1 << 22) - 1, (1 << 22) - 1, (1 << 20) - 1), (1 << 22, 0, 0)]
-    cases += [tuple(int(v) for v in rng.integers(-B, B, 3)) for _ in range(3000)]
-    lim = (1 << 22) + (1 << 21) + (1 << 12)
-    for y in cases:
-        for scale in (0, 1, 2):
-            yy = tuple(v >> scale for v in y) if scale else y          # |o| < 2^(31 - S)
-            arr = (ctypes.c_uint32 * 3)(*[v & 0xFFFFFFFF for v in yy])
-            ll = (ctypes.c_uint32 * 3)()
-            if scale:
-                hs.hs_renorm_scaled(scale, arr, ll)
-            else:
-                hs.hs_renorm(arr, ll)
-            l0, l1, l2 = _s32(ll[0]), _s32(ll[1]), _s32(ll[2])
-            assert -(1 << 12) < l0 < (1 << 22) + (1 << 12) and -lim < l1 < lim and 0 <= l2 < (1 << 20), (y, scale, l0, l1, l2)
-            assert (l0 + (l1 << 22) + (l2 << 44)) % P == ((yy[0] + (yy[1] << 22) + (yy[2] << 44)) << scale) % P, (y, scale)
+    B = 1 << 51
+    cases = [(0, 0), (B - 1, B - 1), (-B + 1, -B + 1), (B - 1, -B + 1), (1, 0), (0, 1), (-1, 0), (0, -1), ((1 << 32), 0), (0, 1 << 32),
+             ((1 << 31), (1 << 31)), (-(1 << 31), -(1 << 31))]
+    cases += [tuple(int(v) for v in rng.integers(-B, B, 2)) for _ in range(3000)]
+    for l, h in cases:
+        for q in (0, 1, 2, 3):                      # the fractional part the low limb carries: quarters
+            lf = Fraction(4 * l + q, 4)
+            if abs(lf) >= B:
+                continue
+            arr = (ctypes.c_double * 2)(float(lf), float(h))
+            out = (ctypes.c_double * 2)()
+            hs.hs_renorm_d(arr, out)
+            ol, oh = Fraction(out[0]), Fraction(out[1])
+            assert abs(ol) <= (1 << 31) + (1 << 20) and abs(oh) <= (1 << 31) + (1 << 20), (l, h, q, out[0], out[1])
+            d = (ol + (1 << 32) * oh) - (lf + (1 << 32) * h)
+            assert d.denominator == 1 and d.numerator % P == 0, (l, h, q)
 
 
-def test_transformed_domain_identities(hs):
-    """T^-1' . K . T is the MDS without its diagonal, and T . T^-1' scales by (4, 4, 2): what the partial rounds rest on."""
-    p32 = ctypes.POINTER(ctypes.c_uint32)
-    hs.hs_dom.argtypes = [ctypes.c_int, p32, p32]
+def test_double_precision_layer_identities(hs):
+    """T^-1' . K . T is the MDS without its diagonal, T . T^-1' scales by (4, 4, 2) and the scaled products take the state
+    divided by (4, 4, 2): what the transformed-domain partial rounds rest on. Then one whole layer: the double-precision
+    planes against the integer planes on lazy u64 states."""
+    pd = ctypes.POINTER(ctypes.c_double)
+    hs.hs_dom_d.argtypes = [ctypes.c_int, pd, pd]
     C = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
     rng = np.random.default_rng(4)
 
     def dom(op, v):
-        a = (ctypes.c_uint32 * 12)(*[int(x) & 0xFFFFFFFF for x in v])
-        b = (ctypes.c_uint32 * 12)()
-        hs.hs_dom(op, a, b)
-        return [_s32(x) for x in b]
+        a = (ctypes.c_double * 12)(*[float(x) for x in v])
+        b = (ctypes.c_double * 12)()
+        hs.hs_dom_d(op, a, b)
+        return [x for x in b]
     for _ in range(200):
-        s = [int(x) for x in rng.integers(-(1 << 19), 1 << 19, 12)]   # T(y) below sums four outputs: keep them in 32 bits
-        o = dom(1, dom(0, s))
-        y = dom(2, o)
-        assert y == [sum(C[i] * s[(i + r) % 12] for i in range(12)) for r in range(12)]
-        t = dom(0, y)
-        assert t == [4 * v for v in o[:6]] + [2 * v for v in o[6:]]
+        s = [int(x) for x in rng.integers(-(1 << 40), 1 << 40, 12)]
+        u = dom(0, s)
+        o = dom(1, u)
+        y = dom(3, o)
+        assert y == [float(sum(C[i] * s[(i + r) % 12] for i in range(12))) for r in range(12)]
+        assert dom(0, y) == [4.0 * v for v in o[:6]] + [2.0 * v for v in o[6:]]
         assert y[0] == o[0] + o[3] + o[6]
+        w = [v / 4.0 for v in u[:6]] + [v / 2.0 for v in u[6:]]           # the stored form: quarter / half integers, exact
+        assert dom(2, w) == o
+    p64 = ctypes.POINTER(ctypes.c_uint64)
+    hs.hs_mds_layer.argtypes = [p64, ctypes.c_int]
+    M = (1 << 64) - 1
+    states = [[0] * 12, [M] * 12, [P - 1] * 12, [M, 0] * 6] + [[int(x) for x in rng.integers(0, 1 << 64, 12, dtype=np.uint64)] for _ in range(300)]
+    for st in states:
+        a, b = (ctypes.c_uint64 * 12)(*st), (ctypes.c_uint64 * 12)(*st)
+        hs.hs_mds_layer(a, 0)
+        hs.hs_mds_layer(b, 1)
+        want = [(sum(C[i] * st[(i + r) % 12] for i in range(12)) + (8 * st[0] if r == 0 else 0)) % P for r in range(12)]
+        assert list(a) == want and list(b) == want
 
 
-def test_transformed_domain_magnitudes():
-    """Worst-case magnitudes of the partial rounds (poseidon.h `permute_until`) by interval arithmetic: nothing leaves the
-    signed 32-bit range, and the element-0 limbs stay below the bias of the recombination."""
-    top_max = (1 << 9)                                    # |t2| < 2^28.3 + carry  ->  |top| <= 2^8.3 + 1
-    L0 = (1 << 22) + top_max                              # normalised limb 0: (-top, 2^22 + top)
-    L1 = (1 << 22) + (top_max << 10)                      # normalised limb 1
-    L = max(L0, L1)
-    prod = {"aa": 64 * L, "ab": 11 * L, "b": 25 * L}      # |dom_mul| per class: sums of |kernel| x max input
-    assert max(prod.values()) < 1 << 29                   # renorm_scaled<2> needs |o| < 2^29, <1> needs < 2^30
-    z = prod["aa"] + prod["ab"] + prod["b"]               # E0 + F0 + v0
-    assert z + 8 * (1 << 22) < 1 << 30                    # element-0 limbs + diagonal: below DOM_BIAS, so + bias < 2^31
-    n = 1 << 22
-    for cls, sh in (("aa", 2), ("ab", 2), ("b", 1)):
-        assert (prod[cls] << sh) + n + z < 1 << 31        # aa0 / ab0 / b0 before their normalisation
-    # the top limb plane: inputs in [0, 2^20), so |t2| and the fold stay as small as assumed above
-    t2 = 4 * 64 * (1 << 20) + (1 << 10)
-    assert (t2 >> 20) + 1 <= top_max
-    # entry from the full rounds: limbs < 2^22; aa (sums of four) is normalised before the first products
-    assert 64 * L < 1 << 29 and 11 * (2 << 22) < 1 << 29 and 25 * (1 << 22) < 1 << 30
-    # leaving: natural limbs |E + F + v| + 8 n, again below the bias
-    assert z + 8 * n < 1 << 30
+def test_double_precision_magnitudes(hs):
+    """Worst-case magnitudes of the double-precision layers (poseidon.h `permute_until`, `mds_layer_d`) by interval
+    arithmetic: between two carry normalisations every limb — with its two fractional bits — stays inside the 53 bits a
+    double holds exactly, and inside the 2^51 the limb -> integer conversion of `recombine_d` is good for."""
+    hs.hs_recombine_d.restype = ctypes.c_uint64
+    hs.hs_recombine_d.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_uint64]
+    lim = (1 << 31) + (1 << 20)                    # a normalised limb (test above)
+    grow = max(64 + 64 + 128, 4 + 32 + 8, 2 * (2 + 4 + 16 + 1 + 1 + 1))    # one scaled layer: aa 256, ab 44, b 50
+    zsum = 256 + 44 + 50                           # element 0 = E0 + F0 + v0
+    n = 1 << 32                                    # a limb of an S-box output
+    # entry from the full rounds: limbs < 2^32, T sums four, the unscaled products multiply by at most 64
+    x = 64 * 4 * n
+    for rnd in range(22):                          # x bounds the limbs of W = (E, F, v) at the top of round `rnd`
+        z = zsum * (x // grow) + 8 * n             # element 0 from the layer's INPUT bound (x = grow * input) + the diagonal
+        assert z < 1 << 51                         # recombine_d
+        w = x + (n + z)                            # + (new - z) / 4 (bounded by |new - z|)
+        assert w * 4 < 1 << 53                     # two fractional bits
+        if rnd & 1:
+            w = lim
+        x = grow * w
+    assert x * 4 < 1 << 53 and 4 * x + 8 * n < 1 << 51       # leaving: natural limbs (T^-1' adds four products) + diagonal
+    # the conversion itself at its limits, against exact integers
+    for l, h, c in ((0, 0, 0), ((1 << 51) - 1, (1 << 51) - 1, P - 1), (-(1 << 51) + 1, -(1 << 51) + 1, 5), (-1, 0, 0), (0, -1, 0),
+                    (123456789012345, -98765432109876, 0xFFFFFFFF00000000)):
+        got = hs.hs_recombine_d(float(l), float(h), c)
+        assert got % P == (l + (h << 32) + c + (1 << 51) * (1 + (1 << 32))) % P, (l, h, c)
 
 
 # ---- BLS12-381 device formulas (csrc/bls12_381.h) on the host ------------------------------------------------

@@ -128,6 +128,9 @@ int main() {
     FIRST2[r] = f;
   }
   hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_RC), POSEIDON_RC, sizeof POSEIDON_RC);
+  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_RCD), POSEIDON_RCD, sizeof POSEIDON_RCD);
+  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DDK), POSEIDON_DOMD_K, sizeof POSEIDON_DOMD_K);
+  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DDLAST), POSEIDON_DOMD_LAST, sizeof POSEIDON_DOMD_LAST);
   hipMemcpyToSymbol(HIP_SYMBOL(sp::d_DOT), DOT, sizeof DOT);
   hipMemcpyToSymbol(HIP_SYMBOL(sp::d_VS), VS, sizeof VS);
   hipMemcpyToSymbol(HIP_SYMBOL(sp::d_K), K, sizeof K);
@@ -139,8 +142,6 @@ int main() {
   uint64_t *a, *b;
   hipMalloc(&a, n * 8);
   hipMalloc(&b, n * 8);
-  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DK), POSEIDON_DOM_K, sizeof POSEIDON_DOM_K);
-  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DLAST), POSEIDON_DOM_LAST, sizeof POSEIDON_DOM_LAST);
   uint64_t *c;
   hipMalloc(&c, n * 8);
   hipLaunchKernelGGL(sp::k_chain<0>, dim3(blocks), dim3(256), 0, 0, a, 12345ull, 3);

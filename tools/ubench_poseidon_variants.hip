@@ -39,8 +39,9 @@ __global__ __launch_bounds__(256) OCC void k_chain(uint64_t *out, uint64_t seed,
 
 int main() {
   hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_RC), POSEIDON_RC, sizeof POSEIDON_RC);
-  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DK), POSEIDON_DOM_K, sizeof POSEIDON_DOM_K);
-  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DLAST), POSEIDON_DOM_LAST, sizeof POSEIDON_DOM_LAST);
+  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_RCD), POSEIDON_RCD, sizeof POSEIDON_RCD);
+  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DDK), POSEIDON_DOMD_K, sizeof POSEIDON_DOMD_K);
+  hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DDLAST), POSEIDON_DOMD_LAST, sizeof POSEIDON_DOMD_LAST);
   const int blocks = 256 * 16, reps = 64;
   const size_t n = (size_t)blocks * 256;
   uint64_t *a, *b;
