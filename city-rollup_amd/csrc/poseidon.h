@@ -334,27 +334,31 @@ GL_HD bool permute_until(uint64_t (&s)[W], Stop stop) {
       dom_mul_d<false>(wl, ol);
       dom_mul_d<false>(wh, oh);
     }
-#pragma unroll 1
-    for (int i = 0; i < PARTIAL; i++) {
-      if ((i & 3) == 0 && stop()) return false;
+    // one partial round: read element 0 off the products (a), S-box it, put it back (W = (E, F, v) + (new - z) / (4, 4, 2) on
+    // aa0, ab0, b0, in place), optionally normalise, next products (a -> b). Two rounds per trip, ping-pong, so nothing is copied.
+    auto round = [&](int i, double (&al)[W], double (&ah)[W], double (&bl)[W], double (&bh)[W], bool normalise) {
+      const double zl = al[0] + al[3] + al[6], zh = ah[0] + ah[3] + ah[6];
       // element 0 of the state: E0 + F0 + v0 + the diagonal 8 of the MDS on the previous S-box output
-      const double zl = ol[0] + ol[3] + ol[6], zh = oh[0] + oh[3] + oh[6];
       const uint64_t x = sbox_lazy(recombine_d(__builtin_fma(nl, 8.0, zl), __builtin_fma(nh, 8.0, zh), domd_k(i)));
       nl = (double)(uint32_t)x;
       nh = (double)(uint32_t)(x >> 32);
-      // W = (E, F, v) with element 0 replaced: + (new - z) / 4 on aa0, ab0, / 2 on b0
       const double dl = nl - zl, dh = nh - zh;
+      al[0] = __builtin_fma(dl, 0.25, al[0]), ah[0] = __builtin_fma(dh, 0.25, ah[0]);
+      al[3] = __builtin_fma(dl, 0.25, al[3]), ah[3] = __builtin_fma(dh, 0.25, ah[3]);
+      al[6] = __builtin_fma(dl, 0.5, al[6]), ah[6] = __builtin_fma(dh, 0.5, ah[6]);
+      if (normalise) {
 #pragma unroll
-      for (int k = 0; k < W; k++) wl[k] = ol[k], wh[k] = oh[k];
-      wl[0] = __builtin_fma(dl, 0.25, ol[0]), wh[0] = __builtin_fma(dh, 0.25, oh[0]);
-      wl[3] = __builtin_fma(dl, 0.25, ol[3]), wh[3] = __builtin_fma(dh, 0.25, oh[3]);
-      wl[6] = __builtin_fma(dl, 0.5, ol[6]), wh[6] = __builtin_fma(dh, 0.5, oh[6]);
-      if (i & 1) {
-#pragma unroll
-        for (int k = 0; k < W; k++) renorm_d(wl[k], wh[k]);
+        for (int k = 0; k < W; k++) renorm_d(al[k], ah[k]);
       }
-      dom_mul_d<true>(wl, ol);
-      dom_mul_d<true>(wh, oh);
+      dom_mul_d<true>(al, bl);
+      dom_mul_d<true>(ah, bh);
+    };
+    static_assert(PARTIAL % 2 == 0, "two rounds per trip");
+#pragma unroll 1
+    for (int i = 0; i < PARTIAL; i += 2) {
+      if ((i & 3) == 0 && stop()) return false;
+      round(i, ol, oh, wl, wh, false);
+      round(i + 1, wl, wh, ol, oh, true);  // a limb holds two layers of growth: normalise every second round
     }
     // leave the domain: natural limbs, + what is pending of the constants
     double yl[W], yh[W];
