@@ -217,6 +217,9 @@ GL_HD void permute_textbook(uint64_t (&s)[W]) {
 // most 256 (aa), 44 (ab), 50 (b); element 0 is E0 + F0 + v0 < 350 x the layer's input; two layers after a normalisation every
 // limb is below 2^48.6 with two fractional bits — 51 of the 53 bits — and the limb -> integer conversion is good to 2^51.
 // Index layout of a plane as before: [0..2] = aa, [3..5] = ab, [6..11] = b. SCALED: the input is W; else the transformed state.
+#if defined(__FAST_MATH__) || defined(__FINITE_MATH_ONLY__) && __FINITE_MATH_ONLY__
+#error "poseidon.h: the double-precision layers rely on IEEE semantics ((x + M) - M is a rounding, not x): do not build with -ffast-math"
+#endif
 template <bool SCALED>
 GL_HD void dom_mul_d(const double (&u)[W], double (&o)[W]) {
   constexpr double A = SCALED ? 64.0 : 16.0;
