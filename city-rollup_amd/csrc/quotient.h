@@ -206,21 +206,21 @@ __global__ __launch_bounds__(256) void k_quot_gate(Args a, int gi, int t0) {
 #pragma unroll
     for (int k = 0; k < 12; k++) add_term(gl::sub(gl::canon(st[k]), w[(size_t)(12 + k) * N]), c++);
   } else if constexpr (TYPE == gates::POSEIDON_MDS) {
-    // PoseidonMdsGate: 24 coalesced loads up front, then the circulant with its small coefficients in 128-bit
-    // integer arithmetic (sum < 2^64 * 264: one lazy reduction per output) — same values as gates.h's generic form
-    uint64_t in[24];
+    // PoseidonMdsGate: the MDS on 12 extension elements = the base-field MDS on their a-components and on their
+    // b-components: two double-precision layers (poseidon.h `mds_layer_d`) — same values as gates.h's generic form
+    uint64_t sa[12], sb[12];
 #pragma unroll
-    for (int k = 0; k < 24; k++) in[k] = w[(size_t)k * N];
+    for (int k = 0; k < 12; k++) {
+      sa[k] = w[(size_t)(2 * k) * N];
+      sb[k] = w[(size_t)(2 * k + 1) * N];
+    }
+    poseidon::mds_layer_d(sa, -1);
+    poseidon::mds_layer_d(sb, -1);
 #pragma unroll
-    for (int r = 0; r < 12; r++)
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        gl::u128 sum = r == 0 ? (gl::u128)in[h] * 8u : (gl::u128)0;
-#pragma unroll
-        for (int k = 0; k < 12; k++) sum += (gl::u128)in[((k + r) % 12) * 2 + h] * (uint32_t)POSEIDON_MDS_CIRC[k];
-        const uint64_t computed = gl::reduce128((uint64_t)sum, (uint64_t)(sum >> 64));
-        add_term(gl::sub(w[(size_t)(24 + 2 * r + h) * N], computed), 2 * r + h);
-      }
+    for (int r = 0; r < 12; r++) {
+      add_term(gl::sub(w[(size_t)(24 + 2 * r) * N], gl::canon(sa[r])), 2 * r);
+      add_term(gl::sub(w[(size_t)(24 + 2 * r + 1) * N], gl::canon(sb[r])), 2 * r + 1);
+    }
   } else {  // the generic constraint code shared with the host verifier (gates.h)
     const uint64_t *consts = cs + (size_t)a.num_selectors * N;
     const uint64_t *pih = a.pi_hash + proof * 4;
