@@ -1,11 +1,11 @@
 // Lane-cooperative Poseidon permutation for the latency-bound small launches (the upper levels of the Merkle trees).
 //
-// With one lane per state (poseidon.h) a permutation is a chain of ~23 K instructions: a wave that is alone on its SIMD
-// issues one instruction per 4 cycles, so a launch with fewer states than the chip has lanes takes ~40 us however small
-// it is — ten such levels per tree. Here TWELVE lanes share one state, one element each: the twelve S-boxes of a full
+// With one lane per state (poseidon.h) a permutation is a chain of ~13 K instructions: a wave that is alone on its SIMD
+// issues one instruction per 4-6 cycles, so a launch with fewer states than the chip has lanes takes ~30-40 us however
+// small it is — ten such levels per tree. Here TWELVE lanes share one state, one element each: the twelve S-boxes of a full
 // round run side by side, and the MDS row of every element is a 12-term dot product over the state, which the group
 // exchanges through LDS (one ds_write_b64 + six ds_read_b128 per lane and round; five states per wave, lanes 60..63 idle).
-// ~4 K instructions per lane and permutation instead of 23 K: a small level takes ~10 us instead of ~40 us, at ~2x the
+// ~3-4 K instructions per lane and permutation instead of 13 K: a small level takes ~10 us instead of ~30-40 us, at ~3x the
 // total lane-instructions — which is why only launches that cannot fill the chip use it (merkle_levels in cityprover.hip).
 // Textbook round structure (constants, S-box, MDS), bit-exact with poseidon::permute.
 #pragma once
