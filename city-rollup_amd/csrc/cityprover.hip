@@ -239,7 +239,7 @@ int merkle_levels(cp_ctx *ctx, uint64_t *D, size_t per_tree, size_t n_leaves, si
     else { parent = D + off + n * 4; pstride = per_tree; }
     // a launch that cannot fill the chip is bound by the latency of ONE permutation: twelve lanes per state then
     // (poseidon_coop.h); lane-per-state otherwise. CITYPROVER_COOP_MAX overrides the switch (0 = never) for measurements.
-    static const size_t coop_max = getenv("CITYPROVER_COOP_MAX") ? strtoull(getenv("CITYPROVER_COOP_MAX"), nullptr, 10) : 32768;
+    static const size_t coop_max = getenv("CITYPROVER_COOP_MAX") ? strtoull(getenv("CITYPROVER_COOP_MAX"), nullptr, 10) : 16384;
     static const int fuse_max = getenv("CITYPROVER_COOP_FUSE") ? atoi(getenv("CITYPROVER_COOP_FUSE")) : pcoop::MAX_FUSED;
     if (np * n_trees <= coop_max && fuse_max >= 1) {
       // ... and several such levels go into one launch (a workgroup walks a whole subtree): everything up to the cap
