@@ -4,9 +4,9 @@
 // reference; call sites: city_crypto/src/hash/traits/hasher.rs:77-159 and every Merkle tree /
 // challenger use inside `CircuitData::prove`).
 //
-// One lane owns one 12-element state (24 VGPRs): no cross-lane traffic, pure 32-bit integer VALU, bound by instruction
+// One lane owns one 12-element state (24 VGPRs): no cross-lane traffic, integer and fp64 VALU only, bound by instruction
 // issue. What shapes the code (measured on MI355X, profiles/r01_ubench_valu.txt, r02_ubench_poseidon.txt):
-//   * a 64-bit modular multiplication is 15 instructions (gl.h: `mul_wide`, `fold_top` — two carry-outs taken in `asm`);
+//   * a 64-bit modular multiplication is 12 instructions (gl.h: `mul_wide`, `reduce128_lazy`, `fold_top` — three pieces in `asm`);
 //   * the MDS layer (circulant, entries <= 41, + diag 8) uses NO integer multiplies at all: the length-12 cyclic
 //     convolution is evaluated per limb plane through the CRT split
 //         x^12-1 = (x^6-1)(x^6+1),  x^6-1 = (x^3-1)(x^3+1)
