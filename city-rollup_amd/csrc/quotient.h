@@ -53,6 +53,7 @@ struct Args {
   size_t N;
   int log_N, rb;
   int ncst, R, W, nc, npp, chunk, n_gates, num_selectors, n_terms;
+  int flip;                       // 1: odd gate launches walk the batch backwards (see k_quot_gate)
   Gate gates[MAX_GATES];
 };
 
@@ -132,9 +133,13 @@ __global__ __launch_bounds__(256) void k_quot_perm(Args a) {
 // grid = (N/256, B). Gate `gi` (of type TYPE): acc[c] += filter * sum_k alpha_c^(t0+k) * constraint_k
 template <int TYPE>
 __global__ __launch_bounds__(256) void k_quot_gate(Args a, int gi, int t0) {
-  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+  // Fourteen of these kernels stream the same wire columns one after the other. Every other launch (odd gi) walks the
+  // batch backwards — last proof first, last rows first — so that it starts on what the previous launch touched last and
+  // finds it in the memory-side cache instead of HBM (CITYPROVER_QUOT_FLIP=0 turns it off for measurements).
+  const bool flip = (gi & 1) && a.flip;
+  const size_t s = (size_t)(flip ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * 256 + threadIdx.x;
   if (s >= a.N) return;
-  const size_t proof = blockIdx.y;
+  const size_t proof = flip ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
   const size_t N = a.N;
   const uint64_t *cs = a.cs_lde[proof] + s;
   const uint64_t *w = a.wires_lde + proof * a.wires_stride + s;
