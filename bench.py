@@ -172,7 +172,7 @@ def native_qbench(device, rank, pack):
                 raise RuntimeError("cityprover_qbench failed: " + r.stderr[-500:])
             return json.loads(r.stdout.strip().splitlines()[-1])
         out_json = os.path.join(tmp, "out.json")
-        many = run(["-i", dump, "-o", out_json, "-n", "32", "--blocks-in-flight", "32", "--contexts", "3", "--batch", "32", "--check-plan"])
+        many = run(["-i", dump, "-o", out_json, "-n", "128", "--blocks-in-flight", "32", "--contexts", "3", "--batch", "32", "--check-plan"])
         per_job = json.load(open(out_json))
         one = run(["-i", dump, "--contexts", "3", "--batch", "32"])
         serial = run(["-i", dump, "--contexts", "1", "--batch", "1"])
@@ -183,7 +183,7 @@ def native_qbench(device, rank, pack):
             "one_block_latency_ms": one["mean_block_latency_ms"],
             "reference_loop_block_ms": serial["mean_block_latency_ms"],
             "throughput_mode_proofs_per_s": thr["proofs_per_s"], "contexts_per_gpu": 3, "max_batch": 32,
-            "harness": "tools/cityprover_qbench -i tests/golden/qbench_example.bin (the reference's own q-bench dump) -n 32 "
+            "harness": "tools/cityprover_qbench -i tests/golden/qbench_example.bin (the reference's own q-bench dump) -n 128 "
                        "--blocks-in-flight 32 --contexts 3 --batch 32; one_block = the same dump alone; reference_loop = one "
                        "context, one job at a time (the reference's single-threaded loop)",
             "workload": "the example block's 46 jobs = 64 plonky2 proofs per block on synthetic shape-equivalent circuits (n = 2^12, 135 "
