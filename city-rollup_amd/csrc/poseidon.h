@@ -305,6 +305,67 @@ GL_HD void mds_layer_d(uint64_t (&s)[W], int next_rc_base) {
   for (int i = 0; i < W; i++) s[i] = recombine_d(yl[i], yh[i], rcd(next_rc_base >= 0 ? next_rc_base + i : ROUNDS * W));
 }
 
+// The 22 partial rounds with the MDS layers on either side of them. s in: the S-box OUTPUTS of the last full round before
+// them (round 3); s out: the state entering the S-boxes of the first full round after them (round 26), constants included.
+// `input(i, x)` sees the S-box input x (lazy u64) of partial round i on element 0 and returns what goes into the S-box — x
+// itself for the permutation; the PoseidonGate constrains x against a wire and continues with the wire. `stop` as below.
+template <typename Input, typename Stop>
+GL_HD bool partial_rounds(uint64_t (&s)[W], Input input, Stop stop) {
+  // straight into the domain (no constants: all pushed forward)
+  double wl[W], wh[W], ol[W], oh[W];
+  double nl, nh;  // limbs of the latest S-box output on element 0
+  {
+    double ll[W], lh[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      ll[k] = (double)(uint32_t)s[k];
+      lh[k] = (double)(uint32_t)(s[k] >> 32);
+    }
+    nl = ll[0], nh = lh[0];
+    dom_enter_d(ll, wl);
+    dom_enter_d(lh, wh);
+    dom_mul_d<false>(wl, ol);
+    dom_mul_d<false>(wh, oh);
+  }
+  // one partial round: read element 0 off the products (a), S-box it, put it back (W = (E, F, v) + (new - z) / (4, 4, 2) on
+  // aa0, ab0, b0, in place), optionally normalise, next products (a -> b). Two rounds per trip, ping-pong, so nothing is copied.
+  auto round = [&](int i, double (&al)[W], double (&ah)[W], double (&bl)[W], double (&bh)[W], bool normalise) {
+    const double zl = al[0] + al[3] + al[6], zh = ah[0] + ah[3] + ah[6];
+    // element 0 of the state: E0 + F0 + v0 + the diagonal 8 of the MDS on the previous S-box output
+    const uint64_t x = sbox_lazy(input(i, recombine_d(__builtin_fma(nl, 8.0, zl), __builtin_fma(nh, 8.0, zh), domd_k(i))));
+    nl = (double)(uint32_t)x;
+    nh = (double)(uint32_t)(x >> 32);
+    const double dl = nl - zl, dh = nh - zh;
+    al[0] = __builtin_fma(dl, 0.25, al[0]), ah[0] = __builtin_fma(dh, 0.25, ah[0]);
+    al[3] = __builtin_fma(dl, 0.25, al[3]), ah[3] = __builtin_fma(dh, 0.25, ah[3]);
+    al[6] = __builtin_fma(dl, 0.5, al[6]), ah[6] = __builtin_fma(dh, 0.5, ah[6]);
+    if (normalise) {
+#pragma unroll
+      for (int k = 0; k < W; k++) renorm_d(al[k], ah[k]);
+    }
+    dom_mul_d<true>(al, bl);
+    dom_mul_d<true>(ah, bh);
+  };
+  static_assert(PARTIAL % 2 == 0, "two rounds per trip");
+#pragma unroll 1
+  for (int i = 0; i < PARTIAL; i += 2) {
+    if ((i & 3) == 0 && stop()) return false;
+    round(i, ol, oh, wl, wh, false);
+    round(i + 1, wl, wh, ol, oh, true);  // a limb holds two layers of growth: normalise every second round
+  }
+  // leave the domain: natural limbs, + what is pending of the constants
+  double yl[W], yh[W];
+  dom_leave_d(ol, yl);
+  dom_leave_d(oh, yh);
+  yl[0] = __builtin_fma(nl, 8.0, yl[0]), yh[0] = __builtin_fma(nh, 8.0, yh[0]);
+#pragma unroll
+  for (int k = 0; k < W; k++) s[k] = recombine_d(yl[k], yh[k], domd_last(k));
+  return true;
+}
+struct SameInput {
+  GL_HD uint64_t operator()(int, uint64_t x) const { return x; }
+};
+
 // `stop` is polled between rounds (every full round, every fourth partial round); when it answers true the permutation is
 // abandoned and false returned. It must answer the same for every lane of a wave. The proof-of-work search uses it to drop
 // candidates that can no longer be the smallest witness.
@@ -319,58 +380,9 @@ GL_HD bool permute_until(uint64_t (&s)[W], Stop stop) {
     for (int i = 0; i < W; i++) s[i] = sbox_lazy(s[i]);
     mds_layer_d(s, (r + 1) * W);
   }
-  {
-    // the last full round before the partial rounds: S-boxes, then straight into the domain (no constants: all pushed forward)
-    double wl[W], wh[W], ol[W], oh[W];
-    double nl, nh;  // limbs of the latest S-box output on element 0
-    {
-      double ll[W], lh[W];
 #pragma unroll
-      for (int k = 0; k < W; k++) {
-        s[k] = sbox_lazy(s[k]);
-        ll[k] = (double)(uint32_t)s[k];
-        lh[k] = (double)(uint32_t)(s[k] >> 32);
-      }
-      nl = ll[0], nh = lh[0];
-      dom_enter_d(ll, wl);
-      dom_enter_d(lh, wh);
-      dom_mul_d<false>(wl, ol);
-      dom_mul_d<false>(wh, oh);
-    }
-    // one partial round: read element 0 off the products (a), S-box it, put it back (W = (E, F, v) + (new - z) / (4, 4, 2) on
-    // aa0, ab0, b0, in place), optionally normalise, next products (a -> b). Two rounds per trip, ping-pong, so nothing is copied.
-    auto round = [&](int i, double (&al)[W], double (&ah)[W], double (&bl)[W], double (&bh)[W], bool normalise) {
-      const double zl = al[0] + al[3] + al[6], zh = ah[0] + ah[3] + ah[6];
-      // element 0 of the state: E0 + F0 + v0 + the diagonal 8 of the MDS on the previous S-box output
-      const uint64_t x = sbox_lazy(recombine_d(__builtin_fma(nl, 8.0, zl), __builtin_fma(nh, 8.0, zh), domd_k(i)));
-      nl = (double)(uint32_t)x;
-      nh = (double)(uint32_t)(x >> 32);
-      const double dl = nl - zl, dh = nh - zh;
-      al[0] = __builtin_fma(dl, 0.25, al[0]), ah[0] = __builtin_fma(dh, 0.25, ah[0]);
-      al[3] = __builtin_fma(dl, 0.25, al[3]), ah[3] = __builtin_fma(dh, 0.25, ah[3]);
-      al[6] = __builtin_fma(dl, 0.5, al[6]), ah[6] = __builtin_fma(dh, 0.5, ah[6]);
-      if (normalise) {
-#pragma unroll
-        for (int k = 0; k < W; k++) renorm_d(al[k], ah[k]);
-      }
-      dom_mul_d<true>(al, bl);
-      dom_mul_d<true>(ah, bh);
-    };
-    static_assert(PARTIAL % 2 == 0, "two rounds per trip");
-#pragma unroll 1
-    for (int i = 0; i < PARTIAL; i += 2) {
-      if ((i & 3) == 0 && stop()) return false;
-      round(i, ol, oh, wl, wh, false);
-      round(i + 1, wl, wh, ol, oh, true);  // a limb holds two layers of growth: normalise every second round
-    }
-    // leave the domain: natural limbs, + what is pending of the constants
-    double yl[W], yh[W];
-    dom_leave_d(ol, yl);
-    dom_leave_d(oh, yh);
-    yl[0] = __builtin_fma(nl, 8.0, yl[0]), yh[0] = __builtin_fma(nh, 8.0, yh[0]);
-#pragma unroll
-    for (int k = 0; k < W; k++) s[k] = recombine_d(yl[k], yh[k], domd_last(k));
-  }
+  for (int k = 0; k < W; k++) s[k] = sbox_lazy(s[k]);  // the last full round before the partial rounds
+  if (!partial_rounds(s, SameInput(), stop)) return false;
 #pragma unroll 1
   for (int r = HALF_FULL + PARTIAL; r < ROUNDS; r++) {
     if (stop()) return false;

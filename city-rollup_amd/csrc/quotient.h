@@ -187,15 +187,20 @@ __global__ __launch_bounds__(256) void k_quot_gate(Args a, int gi, int t0) {
       }
 #pragma unroll
       for (int k = 0; k < 12; k++) st[k] = poseidon::sbox_lazy(st[k]);
-      poseidon::mds_layer_d(st, (rnd + 1) * 12);
+      if (r < 3) poseidon::mds_layer_d(st, (rnd + 1) * 12);
     }
-#pragma unroll 1
-    for (int r = 0; r < 22; r++, rnd++) {
-      uint64_t in = w[(size_t)(65 + r) * N];
-      add_term(gl::sub(gl::canon(st[0]), in), c++);
-      st[0] = poseidon::sbox_lazy(in);
-      poseidon::mds_layer_d(st, (rnd + 1) * 12);
-    }
+    // the 22 partial rounds in the transformed domain (poseidon.h): the S-box input of each is constrained against its wire
+    // and the wire goes on into the S-box
+    poseidon::partial_rounds(
+        st,
+        [&](int r, uint64_t x) {
+          const uint64_t in = w[(size_t)(65 + r) * N];
+          add_term(gl::sub(gl::canon(x), in), c + r);
+          return in;
+        },
+        poseidon::NeverStop());
+    c += 22;
+    rnd += 22;
 #pragma unroll 1
     for (int r = 0; r < 4; r++, rnd++) {
 #pragma unroll
