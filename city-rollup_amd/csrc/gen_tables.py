@@ -261,11 +261,22 @@ def main():
     # the layers run on two 32-bit limb planes in double precision: the limbs are turned into integers by adding 1.5 * 2^52,
     # which leaves limb + 2^51 in the mantissa
     biasd = (1 << 51) * (1 + (1 << 32)) % P
-    out += "// constants minus 2^51 (1 + 2^32), the offset of the double -> integer conversion of two 32-bit limbs: the round\n"
-    out += "// constants (+ one entry for \"none\"), and the partial-round constants pushed forward with the first round treated like the others\n"
-    out += c_array("POSEIDON_RCD", [(k - biasd) % P for k in RC] + [(-biasd) % P])  # round constants for mds_layer_d; [360] = no constant
-    out += c_array("POSEIDON_DOMD_K", [(k - biasd) % P for k in DK])
-    out += c_array("POSEIDON_DOMD_LAST", [(k - biasd) % P for k in DLAST])
+    out += "// constants minus 2^51 (1 + 2^32), the offset of the double -> integer conversion of two 32-bit limbs, each as the bit\n"
+    out += "// patterns of the doubles 1.5 * 2^52 + lo32 and 1.5 * 2^52 + hi32: the round constants (+ one entry for \"none\"), and\n"
+    out += "// the partial-round constants pushed forward with the first round treated like the others\n"
+    # each constant c' = c - 2^51 (1 + 2^32) is stored as the two doubles (bit patterns) 1.5 * 2^52 + lo32(c') and
+    # 1.5 * 2^52 + hi32(c'): adding them to the limbs converts AND adds the constant in one operation (exact: below 2^53)
+    import struct
+
+    def magic_pairs(cs):
+        o = []
+        for c in cs:
+            for half in (c & 0xFFFFFFFF, c >> 32):
+                o.append(struct.unpack("<Q", struct.pack("<d", 6755399441055744.0 + half))[0])
+        return o
+    out += c_array("POSEIDON_RCD", magic_pairs([(k - biasd) % P for k in RC] + [(-biasd) % P]))  # [2 * 360 ..] = no constant
+    out += c_array("POSEIDON_DOMD_K", magic_pairs([(k - biasd) % P for k in DK]))
+    out += c_array("POSEIDON_DOMD_LAST", magic_pairs([(k - biasd) % P for k in DLAST]))
     out += "// primitive 2^k-th roots of unity, k = 0..32 (7^((p-1)/2^k))\n"
     out += c_array("GL_ROOTS", roots)
     out += c_array("GL_ROOTS_INV", [pow(r, P - 2, P) for r in roots])

@@ -38,31 +38,33 @@ GL_HD uint64_t rc(int i) {
   return POSEIDON_RC[i];
 #endif
 }
-// Constants of the double-precision layers, all minus 2^51 (1 + 2^32) — the offset of their limb -> integer conversion
-// (`recombine_d`): RCD = the round constants (+ one entry for "no constant"); DDK / DDLAST = the partial-round constants pushed
+// Constants of the double-precision layers (`recombine_d`): each constant c, minus 2^51 (1 + 2^32), as the two doubles
+// 1.5 * 2^52 + lo32 and 1.5 * 2^52 + hi32 — added to a limb they convert it to an integer AND add the constant in one
+// operation. RCD = the round constants (+ one entry for "no constant"); DDK / DDLAST = the partial-round constants pushed
 // forward through the MDS (gen_tables.plane_constants: one scalar per partial round on element 0, one vector after the last).
-__constant__ uint64_t d_RCD[ROUNDS * W + 1];
-GL_HD uint64_t rcd(int i) {
+struct Magic { double m0, m1; };
+__constant__ uint64_t d_RCD[2 * (ROUNDS * W + 1)];
+__constant__ uint64_t d_DDK[2 * PARTIAL];
+__constant__ uint64_t d_DDLAST[2 * W];
+GL_HD Magic rcd(int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return d_RCD[i];
+  return {__builtin_bit_cast(double, d_RCD[2 * i]), __builtin_bit_cast(double, d_RCD[2 * i + 1])};
 #else
-  return POSEIDON_RCD[i];
+  return {__builtin_bit_cast(double, POSEIDON_RCD[2 * i]), __builtin_bit_cast(double, POSEIDON_RCD[2 * i + 1])};
 #endif
 }
-__constant__ uint64_t d_DDK[PARTIAL];
-__constant__ uint64_t d_DDLAST[W];
-GL_HD uint64_t domd_k(int i) {
+GL_HD Magic domd_k(int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return d_DDK[i];
+  return {__builtin_bit_cast(double, d_DDK[2 * i]), __builtin_bit_cast(double, d_DDK[2 * i + 1])};
 #else
-  return POSEIDON_DOMD_K[i];
+  return {__builtin_bit_cast(double, POSEIDON_DOMD_K[2 * i]), __builtin_bit_cast(double, POSEIDON_DOMD_K[2 * i + 1])};
 #endif
 }
-GL_HD uint64_t domd_last(int i) {
+GL_HD Magic domd_last(int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return d_DDLAST[i];
+  return {__builtin_bit_cast(double, d_DDLAST[2 * i]), __builtin_bit_cast(double, d_DDLAST[2 * i + 1])};
 #else
-  return POSEIDON_DOMD_LAST[i];
+  return {__builtin_bit_cast(double, POSEIDON_DOMD_LAST[2 * i]), __builtin_bit_cast(double, POSEIDON_DOMD_LAST[2 * i + 1])};
 #endif
 }
 // ---- lazy field helpers: inputs/outputs are arbitrary u64 congruent to the value ----------
@@ -276,12 +278,12 @@ GL_HD void renorm_d(double &l, double &h) {
   h = __builtin_fma(t, INV, h);
   l = __builtin_fma(t, -INV, l);
 }
-// integer limbs |l|, |h| < 2^51 -> lazy u64 congruent to l + 2^32 h + c + 2^51 (1 + 2^32)
-GL_HD uint64_t recombine_d(double l, double h, uint64_t c) {
-  constexpr double M52 = 0x1.8p52;
-  const uint64_t a0 = __builtin_bit_cast(uint64_t, l + M52) & 0xFFFFFFFFFFFFFull;
-  const uint64_t a1 = __builtin_bit_cast(uint64_t, h + M52) & 0xFFFFFFFFFFFFFull;
-  const gl::u128 acc = (gl::u128)c + a0 + ((gl::u128)a1 << 32);
+// integer limbs |l|, |h| < 2^51 - 2^32 -> lazy u64 congruent to l + 2^32 h + c, for the constant c that `m` encodes: the
+// mantissa of l + m.m0 is l + lo32(c') + 2^51 and that of h + m.m1 is h + hi32(c') + 2^51, with c' = c - 2^51 (1 + 2^32)
+GL_HD uint64_t recombine_d(double l, double h, Magic m) {
+  const uint64_t a0 = __builtin_bit_cast(uint64_t, l + m.m0) & 0xFFFFFFFFFFFFFull;
+  const uint64_t a1 = __builtin_bit_cast(uint64_t, h + m.m1) & 0xFFFFFFFFFFFFFull;
+  const gl::u128 acc = (gl::u128)a0 + ((gl::u128)a1 << 32);
   return fold_top((uint64_t)acc, (uint32_t)(acc >> 64));
 }
 

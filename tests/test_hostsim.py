@@ -195,10 +195,10 @@ def test_double_precision_magnitudes(hs):
         x = grow * w
     assert x * 4 < 1 << 53 and 4 * x + 8 * n < 1 << 51       # leaving: natural limbs (T^-1' adds four products) + diagonal
     # the conversion itself at its limits, against exact integers
-    for l, h, c in ((0, 0, 0), ((1 << 51) - 1, (1 << 51) - 1, P - 1), (-(1 << 51) + 1, -(1 << 51) + 1, 5), (-1, 0, 0), (0, -1, 0),
+    for l, h, c in ((0, 0, 0), ((1 << 51) - (1 << 32) - 1, (1 << 51) - (1 << 32) - 1, P - 1), (-(1 << 51) + 1, -(1 << 51) + 1, 5), (-1, 0, 0), (0, -1, 0),
                     (123456789012345, -98765432109876, 0xFFFFFFFF00000000)):
         got = hs.hs_recombine_d(float(l), float(h), c)
-        assert got % P == (l + (h << 32) + c + (1 << 51) * (1 + (1 << 32))) % P, (l, h, c)
+        assert got % P == (l + (h << 32) + c + (1 << 51) * (1 + (1 << 32))) % P, (l, h, c)   # c is stored minus that offset
 
 
 # ---- BLS12-381 device formulas (csrc/bls12_381.h) on the host ------------------------------------------------
