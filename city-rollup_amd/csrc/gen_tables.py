@@ -260,7 +260,9 @@ def main():
         assert perm_planes(s, RC, DK, DLAST, first_too=True) == perm_naive(s, RC)
     # the layers run on two 32-bit limb planes in double precision: the limbs are turned into integers by adding 1.5 * 2^52,
     # which leaves limb + 2^51 in the mantissa
-    biasd = (1 << 51) * (1 + (1 << 32)) % P
+    # ... and the exponent field 0x433 of the double stays in place too (no masking): what is taken out of every constant is
+    # (0x433 * 2^52 + 2^51) (1 + 2^32), the whole bit pattern of 1.5 * 2^52 at both limb positions
+    biasd = ((0x433 << 52) + (1 << 51)) * (1 + (1 << 32)) % P
     out += "// constants minus 2^51 (1 + 2^32), the offset of the double -> integer conversion of two 32-bit limbs, each as the bit\n"
     out += "// patterns of the doubles 1.5 * 2^52 + lo32 and 1.5 * 2^52 + hi32: the round constants (+ one entry for \"none\"), and\n"
     out += "// the partial-round constants pushed forward with the first round treated like the others\n"

@@ -38,9 +38,9 @@ GL_HD uint64_t rc(int i) {
   return POSEIDON_RC[i];
 #endif
 }
-// Constants of the double-precision layers (`recombine_d`): each constant c, minus 2^51 (1 + 2^32), as the two doubles
-// 1.5 * 2^52 + lo32 and 1.5 * 2^52 + hi32 — added to a limb they convert it to an integer AND add the constant in one
-// operation. RCD = the round constants (+ one entry for "no constant"); DDK / DDLAST = the partial-round constants pushed
+// Constants of the double-precision layers (`recombine_d`): each constant c, minus the bit pattern of 1.5 * 2^52 at both limb
+// positions, as the two doubles 1.5 * 2^52 + lo32 and 1.5 * 2^52 + hi32 — added to a limb they convert it to an integer AND
+// add the constant in one operation. RCD = the round constants (+ one entry for "no constant"); DDK / DDLAST = the partial-round constants pushed
 // forward through the MDS (gen_tables.plane_constants: one scalar per partial round on element 0, one vector after the last).
 struct Magic { double m0, m1; };
 __constant__ uint64_t d_RCD[2 * (ROUNDS * W + 1)];
@@ -278,13 +278,15 @@ GL_HD void renorm_d(double &l, double &h) {
   h = __builtin_fma(t, INV, h);
   l = __builtin_fma(t, -INV, l);
 }
-// integer limbs |l|, |h| < 2^51 - 2^32 -> lazy u64 congruent to l + 2^32 h + c, for the constant c that `m` encodes: the
-// mantissa of l + m.m0 is l + lo32(c') + 2^51 and that of h + m.m1 is h + hi32(c') + 2^51, with c' = c - 2^51 (1 + 2^32)
+// integer limbs |l|, |h| < 2^51 - 2^32 -> lazy u64 congruent to l + 2^32 h + c, for the constant c that `m` encodes. The bit
+// pattern of l + m.m0 is B + l + lo32(c') and that of h + m.m1 is B + h + hi32(c'), B = 0x433 * 2^52 + 2^51 being the pattern
+// of 1.5 * 2^52 (exponent field included: nothing is masked) and c' = c - B (1 + 2^32): the two patterns are added as
+// integers at their limb positions, and what overflows 2^64 (up to 2^31) is folded like any top word.
 GL_HD uint64_t recombine_d(double l, double h, Magic m) {
-  const uint64_t a0 = __builtin_bit_cast(uint64_t, l + m.m0) & 0xFFFFFFFFFFFFFull;
-  const uint64_t a1 = __builtin_bit_cast(uint64_t, h + m.m1) & 0xFFFFFFFFFFFFFull;
-  const gl::u128 acc = (gl::u128)a0 + ((gl::u128)a1 << 32);
-  return fold_top((uint64_t)acc, (uint32_t)(acc >> 64));
+  const uint64_t a0 = __builtin_bit_cast(uint64_t, l + m.m0), a1 = __builtin_bit_cast(uint64_t, h + m.m1);
+  uint32_t w1;
+  const uint32_t carry = __builtin_add_overflow(gl::hi32(a0), gl::lo32(a1), &w1);
+  return fold_top(gl::pack(gl::lo32(a0), w1), gl::hi32(a1) + carry);
 }
 
 // s <- MDS * s + next_rc on two double-precision limb planes (next_rc_base < 0: no constant)

@@ -35,7 +35,7 @@ void hs_dom_d(int op, const double *s, double *y) {  // 0: dom_enter_d, 1: dom_m
   else poseidon::dom_leave_d(a, b);
   for (int i = 0; i < 12; i++) y[i] = b[i];
 }
-uint64_t hs_recombine_d(double l, double h, uint64_t c) {  // c: the constant already minus 2^51 (1 + 2^32), as the tables hold it
+uint64_t hs_recombine_d(double l, double h, uint64_t c) {  // c: the constant already minus B (1 + 2^32), as the tables hold it
   return poseidon::recombine_d(l, h, poseidon::Magic{0x1.8p52 + (double)(uint32_t)c, 0x1.8p52 + (double)(uint32_t)(c >> 32)});
 }
 void hs_mds_layer(uint64_t *s, int which) {  // 0: integer planes (mds_layer), 1: double-precision planes (mds_layer_d); no constant

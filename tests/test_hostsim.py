@@ -198,7 +198,7 @@ def test_double_precision_magnitudes(hs):
     for l, h, c in ((0, 0, 0), ((1 << 51) - (1 << 32) - 1, (1 << 51) - (1 << 32) - 1, P - 1), (-(1 << 51) + 1, -(1 << 51) + 1, 5), (-1, 0, 0), (0, -1, 0),
                     (123456789012345, -98765432109876, 0xFFFFFFFF00000000)):
         got = hs.hs_recombine_d(float(l), float(h), c)
-        assert got % P == (l + (h << 32) + c + (1 << 51) * (1 + (1 << 32))) % P, (l, h, c)   # c is stored minus that offset
+        assert got % P == (l + (h << 32) + c + ((0x433 << 52) + (1 << 51)) * (1 + (1 << 32))) % P, (l, h, c)   # c is stored minus that offset
 
 
 # ---- BLS12-381 device formulas (csrc/bls12_381.h) on the host ------------------------------------------------
