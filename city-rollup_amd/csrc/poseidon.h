@@ -273,9 +273,8 @@ GL_HD void renorm_d(double &l, double &h) {
   const double c = (l + MAGIC) - MAGIC;
   l -= c;
   h = __builtin_fma(c, INV, h);
-  const double t = (h + MAGIC) - MAGIC;  // t / 2^32 units of 2^64 == 2^32 - 1
-  h -= t;
-  h = __builtin_fma(t, INV, h);
+  const double t = (h + MAGIC) - MAGIC;       // t / 2^32 units of 2^64 == 2^32 - 1:  h <- h - t + t / 2^32,  l <- l - t / 2^32
+  h = __builtin_fma(t, -(1.0 - INV), h);      // one rounding of an exactly representable result (t (1 - 2^-32) is an integer < 2^51)
   l = __builtin_fma(t, -INV, l);
 }
 // integer limbs |l|, |h| < 2^51 - 2^32 -> lazy u64 congruent to l + 2^32 h + c, for the constant c that `m` encodes. The bit
