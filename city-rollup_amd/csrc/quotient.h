@@ -116,9 +116,11 @@ __global__ __launch_bounds__(256) void k_quot_perm(Args a) {
       uint64_t next = k == a.npp ? zsb[(size_t)c * N + s_next] : zsb[((size_t)nc + (size_t)c * a.npp + k) * N + s];
       uint64_t pn = 1, pd = 1;
       for (int j = k * a.chunk; j < a.R && j < (k + 1) * a.chunk; j++) {
-        uint64_t base = gl::add(w[(size_t)j * N], gamma);
-        pn = gl::mul(pn, gl::add(base, gl::mul(bx, a.k_is[j])));
-        pd = gl::mul(pd, gl::add(base, gl::mul(beta, cs[(size_t)(a.ncst + j) * N])));
+        // lazy values inside the running products (any u64 congruent to the value; the term below canonicalises):
+        // w + gamma + beta k x and w + gamma + beta sigma as one multiply-add each
+        const uint64_t base = gl::add(w[(size_t)j * N], gamma);
+        pn = poseidon::mul_lazy(pn, gl::mul_add_lazy(bx, a.k_is[j], base));
+        pd = poseidon::mul_lazy(pd, gl::mul_add_lazy(beta, cs[(size_t)(a.ncst + j) * N], base));
       }
       add_term(gl::sub(gl::mul(prev, pn), gl::mul(next, pd)), t++);
       prev = next;
