@@ -426,7 +426,7 @@ def main():
             "metric": "ms/NTT at 2^20 Goldilocks (commit-shaped step: 135-column 2^20-row NTT + Poseidon Merkle cap)",
             "value": value, "unit": "ms/NTT", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 (Goldilocks mod 2^64-2^32+1)", "data": "synthetic",
+            "dtype": "u64 (Goldilocks mod 2^64-2^32+1; the Poseidon MDS layers are evaluated exactly on 32-bit limbs held in f64)", "data": "synthetic",
             "config": {"workload": "configs[1]: 2^%d-row x %d-column trace, forward NTT per column "
                                    "(natural->bit-reversed) + Poseidon Merkle cap height %d" % (log_n, k, CAP_H),
                        "log_n": log_n, "columns": k, "cap_height": CAP_H, "sharding": "independent traces per GPU"},
