@@ -53,3 +53,52 @@ def test_fast_partial_rounds_equal_naive_permutation():
     assert parse_table("POSEIDON_FAST_VS") == [x for r in vs for x in r]
     assert parse_table("POSEIDON_FAST_WHATS") == [x for r in whats for x in r]
     assert parse_table("POSEIDON_FAST_INIT") == [x for r in init for x in r]
+
+
+def test_double_precision_constants_encode_the_round_constants():
+    """POSEIDON_RCD / DOMD_*: every constant is stored as the bit patterns of 1.5 * 2^52 + lo32(c') and 1.5 * 2^52 + hi32(c')
+    with c' = c - B (1 + 2^32), B the bit pattern of 1.5 * 2^52 (poseidon.h `recombine_d`). Decoding them gives back the
+    round constants, and the generated header is what gen_tables.py writes today."""
+    import struct
+    P = O.P
+    B = (0x433 << 52) + (1 << 51)
+    rc = parse_table("POSEIDON_RC")
+    rcd = parse_table("POSEIDON_RCD")
+    assert len(rcd) == 2 * (len(rc) + 1)
+
+    def decode(pair):
+        halves = []
+        for bits in pair:
+            d = struct.unpack("<d", struct.pack("<Q", bits))[0]
+            h = d - 6755399441055744.0
+            assert h == int(h) and 0 <= h < (1 << 32)
+            halves.append(int(h))
+        return halves[0] + (halves[1] << 32)
+    for i, c in enumerate(rc + [0]):
+        assert (decode(rcd[2 * i:2 * i + 2]) + B * (1 + (1 << 32))) % P == c
+    sys.path.insert(0, CSRC)
+    import gen_tables
+    dk, dlast = gen_tables.plane_constants(gen_tables.round_constants(), first_too=True)
+    for name, want in (("POSEIDON_DOMD_K", dk), ("POSEIDON_DOMD_LAST", dlast)):
+        got = parse_table(name)
+        assert [(decode(got[2 * i:2 * i + 2]) + B * (1 + (1 << 32))) % P for i in range(len(want))] == want
+
+
+def test_kernel_source_hash_ignores_comments_not_code(tmp_path, monkeypatch):
+    """bench.py stamps the stored PMC counters with a hash of the kernel sources' CODE: a reworded comment keeps the
+    counters valid, a changed instruction does not."""
+    sys.path.insert(0, ROOT)
+    import shutil
+    import bench
+    fake = tmp_path / "city-rollup_amd" / "csrc"
+    fake.mkdir(parents=True)
+    for f in bench.KERNEL_SOURCES:
+        shutil.copy(os.path.join(CSRC, f), fake / f)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    h0 = bench.kernel_source_hash()
+    p = fake / "gl.h"
+    src = p.read_text()
+    p.write_text("// another first line\n" + src.replace("// Goldilocks field arithmetic", "//  Goldilocks  field arithmetic, reworded") + "\n/* trailing\n   comment */\n")
+    assert bench.kernel_source_hash() == h0
+    p.write_text(src.replace("constexpr uint64_t EPS = 0xFFFFFFFFULL;", "constexpr uint64_t EPS = 0xFFFFFFFEULL;"))
+    assert bench.kernel_source_hash() != h0
