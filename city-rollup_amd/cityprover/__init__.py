@@ -599,6 +599,57 @@ def prove(circuit, wires, public_inputs, pow_override=None):
     return res
 
 
+class BatcherStats(ctypes.Structure):
+    """cp_batcher_stats"""
+    _fields_ = [("calls", ctypes.c_uint64), ("batches", ctypes.c_uint64), ("proofs", ctypes.c_uint64),
+                ("largest_batch", ctypes.c_uint64), ("retried_singly", ctypes.c_uint64)]
+
+
+ABI["cp_batcher_create"] = (_vp, [_vp, ctypes.c_size_t, ctypes.c_uint])
+ABI["cp_batcher_prove"] = (ctypes.c_int, [_vp, _vp, _u64p, _u64p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64,
+                                          ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)), ctypes.POINTER(ctypes.c_size_t)])
+ABI["cp_batcher_get_stats"] = (ctypes.c_int, [_vp, ctypes.POINTER(BatcherStats)])
+ABI["cp_batcher_destroy"] = (None, [_vp])
+
+
+class Batcher:
+    """cp_batcher: merges the concurrent one-proof calls of several threads (the reference's worker loops,
+    city_rollup_core_worker/src/actors/simple.rs:32-56) into cp_prove_batch_host launches. `prove` is thread-safe
+    and blocking (ctypes releases the GIL for the call)."""
+
+    def __init__(self, prover, max_batch=32, linger_us=0):
+        self.prover = prover
+        self.handle = prover.lib.cp_batcher_create(prover.ctx, max_batch, linger_us)
+        if not self.handle:
+            raise CityProverError(prover.lib.cp_last_error(None).decode())
+
+    def prove(self, circuit, wires, public_inputs, pow_override=None):
+        lib = self.prover.lib
+        w, pi = _as_u64(wires), _as_u64(public_inputs)
+        if w.size != circuit.shape.num_wires << circuit.shape.degree_bits:
+            raise ValueError("wires must be [num_wires][n]")
+        out = ctypes.POINTER(ctypes.c_uint8)()
+        n = ctypes.c_size_t()
+        rc = lib.cp_batcher_prove(self.handle, circuit.handle, _ptr(w), _ptr(pi) if pi.size else None, pi.size,
+                                  0 if pow_override is None else 1, 0 if pow_override is None else pow_override,
+                                  ctypes.byref(out), ctypes.byref(n))
+        if rc != 0:  # the message is the calling thread's, not the context's
+            raise CityProverError(f"[{rc}] " + lib.cp_last_error(None).decode())
+        res = ctypes.string_at(out, n.value)
+        lib.cp_free(out)
+        return res
+
+    def stats(self):
+        st = BatcherStats()
+        self.prover._check(self.prover.lib.cp_batcher_get_stats(self.handle, ctypes.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in BatcherStats._fields_}
+
+    def close(self):
+        if self.handle:
+            self.prover.lib.cp_batcher_destroy(self.handle)
+            self.handle = None
+
+
 ABI["cp_verify"] = (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t])
 
 

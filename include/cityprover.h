@@ -352,6 +352,32 @@ int cp_prove_batch_zk_host(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circ
                            const uint64_t *const *wires_values_host, const uint64_t *const *salts_host,
                            const int *use_pow_override, const uint64_t *pow_override, uint8_t **proofs_out,
                            size_t *proof_lens);
+/* Group commit for callers that prove ONE job at a time. The reference's worker loop does exactly that
+ * (`SimpleActorWorker::process_next_job`, city_rollup_core_worker/src/actors/simple.rs:32-56 -> `prove_base` ->
+ * `CircuitData::prove`) and scales by running more loops; when several loops live in one process as threads, a batcher
+ * merges their concurrent calls: cp_batcher_prove is thread-safe and BLOCKING, the first caller to find the device free
+ * leads — it proves its own request together with every pending request of the same shape and gate set (at most
+ * max_batch) in one cp_prove_batch_host — and calls that arrive while a batch runs form the next one. Proof bytes are
+ * those of cp_prove. A failing request (cp_prove's status and message, the latter through cp_last_error(NULL) of the
+ * calling thread) does not fail the requests it was batched with: they are proved again singly.
+ * linger_us > 0 lets a leader that found fewer than max_batch requests wait that long for more (0: never wait).
+ * With cp_ctx_set_lanes(ctx, L > 1) BEFORE cp_batcher_create, up to L batches run at once, one per lane, so that the host
+ * phases of one overlap the kernels of another. While a batcher exists, nothing else may prove on its context.
+ * cp_batcher_destroy waits for running batches; calling it with callers still inside cp_batcher_prove is an error. */
+typedef struct cp_batcher cp_batcher;
+typedef struct cp_batcher_stats {
+  uint64_t calls;          /* cp_batcher_prove calls accepted */
+  uint64_t batches;        /* cp_prove_batch_host launches they were merged into */
+  uint64_t proofs;         /* requests that went through those batches (== calls once all have returned) */
+  uint64_t largest_batch;
+  uint64_t retried_singly; /* batches that failed as a whole and were proved request by request */
+} cp_batcher_stats;
+cp_batcher *cp_batcher_create(cp_ctx *ctx, size_t max_batch, unsigned linger_us);
+int cp_batcher_prove(cp_batcher *batcher, cp_circuit *circuit, const uint64_t *wires_values_host,
+                     const uint64_t *public_inputs_host, size_t n_public_inputs, int use_pow_override,
+                     uint64_t pow_override, uint8_t **proof_out, size_t *proof_len);
+int cp_batcher_get_stats(cp_batcher *batcher, cp_batcher_stats *out);
+void cp_batcher_destroy(cp_batcher *batcher);
 /* plonky2 `CircuitData::verify` (reference call site: city_common_circuit/src/proof_minifier/
  * pm_chain.rs:264-268): transcript, vanishing identity at zeta, proof of work, every query round's
  * Merkle paths, fri_combine_initial, fold chain and final polynomial. Runs on the host (a few thousand

@@ -202,6 +202,63 @@ impl Drop for Circuit {
     }
 }
 
+/// Group commit for worker loops that prove one job per call (`SimpleActorWorker::process_next_job`,
+/// city_rollup_core_worker/src/actors/simple.rs:32-56) when several of them run as THREADS of one process: their
+/// concurrent `prove` calls are merged into `cp_prove_batch_host` launches (`cp_batcher_*` in include/cityprover.h).
+/// `Sync`: `prove` may be called from any number of threads; it blocks until the proof is there. Same bytes as
+/// [`Context::prove_batch`]. Call `Context::set_lanes` first to let several batches overlap. While a `Batcher`
+/// exists nothing else may prove on its context, and it must not outlive the context or the circuits it is handed.
+pub struct Batcher {
+    raw: *mut ffi::CpBatcher,
+}
+unsafe impl Send for Batcher {}
+unsafe impl Sync for Batcher {}
+
+impl Batcher {
+    /// `linger_us`: how long a caller that found the device free waits for company (0 = never; a few hundred pays
+    /// once there are more callers than `max_batch`).
+    pub fn new(ctx: &Context, max_batch: usize, linger_us: u32) -> Result<Self> {
+        let raw = unsafe { ffi::cp_batcher_create(ctx.raw, max_batch, linger_us) };
+        if raw.is_null() {
+            bail!("cp_batcher_create: {}", last_error(ptr::null_mut()));
+        }
+        Ok(Self { raw })
+    }
+
+    pub fn prove(&self, circuit: &Circuit, wires: &[u64], public_inputs: &[u64], pow_witness: Option<u64>) -> Result<Vec<u8>> {
+        let want = (circuit.shape.num_wires as usize) << circuit.shape.degree_bits;
+        if wires.len() != want {
+            bail!("Batcher::prove: wire matrix of {} elements, the circuit needs {want}", wires.len());
+        }
+        let (mut out, mut len) = (ptr::null_mut::<u8>(), 0usize);
+        let rc = unsafe {
+            ffi::cp_batcher_prove(
+                self.raw, circuit.raw, wires.as_ptr(), public_inputs.as_ptr(), public_inputs.len(),
+                pow_witness.is_some() as c_int, pow_witness.unwrap_or(0), &mut out, &mut len,
+            )
+        };
+        if rc != ffi::CP_OK {
+            // the message is the calling thread's: the context's buffer belongs to whoever runs a batch on it
+            bail!("cityprover[{rc}]: {}", last_error(ptr::null_mut()));
+        }
+        let v = unsafe { std::slice::from_raw_parts(out, len) }.to_vec();
+        unsafe { ffi::cp_free(out.cast()) };
+        Ok(v)
+    }
+
+    pub fn stats(&self) -> ffi::CpBatcherStats {
+        let mut st: ffi::CpBatcherStats = unsafe { std::mem::zeroed() };
+        unsafe { ffi::cp_batcher_get_stats(self.raw, &mut st) };
+        st
+    }
+}
+
+impl Drop for Batcher {
+    fn drop(&mut self) {
+        unsafe { ffi::cp_batcher_destroy(self.raw) }
+    }
+}
+
 /// `CityGroth16ProofData` bytes (pi_a | pi_b_a0 | pi_b_a1 | pi_c, 4 x 48) from affine coordinates
 /// (city_rollup_common/src/block_template/data.rs:27-34).
 pub fn groth16_pack_city(a_xy: &[u64; 12], b_xy: &[u64; 24], c_xy: &[u64; 12]) -> Result<[u8; 192]> {

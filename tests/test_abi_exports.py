@@ -36,6 +36,19 @@ def test_abi_version_and_no_gpu_fails_loudly():
             cityprover.Prover()
 
 
+def test_batcher_entry_points_reject_null_without_a_gpu():
+    """cp_batcher_*: no context, no batcher — a status and a message, never a crash."""
+    import ctypes
+    lib = cityprover.load_library()
+    assert not lib.cp_batcher_create(None, 8, 0)
+    assert b"ctx is NULL" in lib.cp_last_error(None)
+    out, n = ctypes.POINTER(ctypes.c_uint8)(), ctypes.c_size_t()
+    assert lib.cp_batcher_prove(None, None, None, None, 0, 0, 0, ctypes.byref(out), ctypes.byref(n)) != 0
+    assert b"NULL" in lib.cp_last_error(None)
+    assert lib.cp_batcher_get_stats(None, None) != 0
+    lib.cp_batcher_destroy(None)
+
+
 def test_product_does_not_reference_oracle():
     # the product path must never import / link / call the oracle
     pkg = os.path.join(ROOT, "city-rollup_amd")

@@ -34,7 +34,8 @@
 //
 // Every proof is compared byte for byte with the proof recorded in its witness file (the CPU oracle's, or the Rust
 // prover's under nonce injection) when one is recorded. --dry-run runs the whole schedule without proving anything and
-// without a GPU (tests of the planner and the queue semantics); --mode throughput is the raw proofs/s measurement.
+// without a GPU (tests of the planner and the queue semantics); --mode throughput is the raw proofs/s measurement;
+// --mode callers measures one-job-per-call threads (--callers T) merged by a cp_batcher (--batch = its max_batch, --linger-us).
 // Build: g++ -O2 -std=c++17 -Iinclude tools/cityprover_qbench.cpp -Lcity-rollup_amd -lcityprover_hip
 //            -Wl,-rpath,'$ORIGIN/../city-rollup_amd' -lpthread -o tools/cityprover_qbench
 #include <algorithm>
@@ -70,7 +71,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 struct Options {
   std::vector<std::string> inputs;
   std::string output, network = "dogeregtest", pack_dir, mode = "qbench", trace_path;
-  int iterations = 1, contexts = 3, batch = 32, blocks_in_flight = 1, lanes = 1, iters = 8;
+  int iterations = 1, contexts = 3, batch = 32, blocks_in_flight = 1, lanes = 1, iters = 8, callers = 32, linger_us = 0;
   int groth16_log = 0;  // > 0: the Groth16 job runs cp_groth16_prove_bls12381 on a synthetic key of 2^groth16_log constraints
   std::vector<int> devices;  // empty: all visible
   bool dry_run = false, ref_counters = false, check_plan = false;
@@ -658,6 +659,93 @@ int run_throughput(const Options &opt) {
   return 0;
 }
 
+// one-job-at-a-time callers: --callers threads, each proving --iters single proofs through a cp_batcher (one per context) —
+// the reference's worker loops (actors/simple.rs:32-56) as threads of one process sharing a GPU
+int run_callers(const Options &opt) {
+  if (opt.pack_dir.empty()) die("--pack DIR is required");
+  const int n_dev = cp_device_count();
+  if (n_dev <= 0) die("no HIP device visible: this library has no CPU fallback");
+  std::vector<int> devices = opt.devices;
+  if (devices.empty())
+    for (int d = 0; d < n_dev; d++) devices.push_back(d);
+  qb::Pack pack;
+  try {
+    pack = qb::load_pack(opt.pack_dir);
+  } catch (const std::exception &e) {
+    die(std::string("circuit pack: ") + e.what());
+  }
+  std::vector<qb::Binding> bindings;
+  for (const auto &kv : pack.by_type)
+    for (const auto &b : kv.second) bindings.push_back(b);
+  std::vector<Worker> workers(devices.size() * (size_t)opt.contexts);
+  std::vector<cp_batcher *> batchers(workers.size(), nullptr);
+  try {
+    for (size_t w = 0; w < workers.size(); w++) {
+      workers[w].index = (int)w;
+      workers[w].open(pack, devices[w / (size_t)opt.contexts], opt.lanes);
+      batchers[w] = cp_batcher_create(workers[w].ctx, (size_t)opt.batch, (unsigned)opt.linger_us);
+      if (!batchers[w]) throw std::runtime_error(std::string("cp_batcher_create: ") + cp_last_error(nullptr));
+    }
+  } catch (const std::exception &e) {
+    die(e.what());
+  }
+  std::mutex m;
+  std::string error;
+  std::atomic<size_t> parity{0};
+  auto caller = [&](size_t t, int iters) {
+    Worker &wk = workers[t % workers.size()];
+    try {
+      for (int it = 0; it < iters; it++) {
+        const qb::Binding &b = bindings[(t + (size_t)it) % bindings.size()];
+        const qb::Witness &wt = *pack.witnesses[b.witness];
+        uint8_t *out = nullptr;
+        size_t len = 0;
+        if (cp_batcher_prove(batchers[t % workers.size()], wk.circuits[b.circuit], wk.wires[b.witness], wt.public_inputs.data(),
+                             wt.public_inputs.size(), 0, 0, &out, &len) != CP_OK)
+          throw std::runtime_error(std::string("cp_batcher_prove: ") + cp_last_error(nullptr));
+        const bool same = wt.expected_proof.empty() || (len == wt.expected_proof.size() && memcmp(out, wt.expected_proof.data(), len) == 0);
+        cp_free(out);
+        if (!same) throw std::runtime_error("proof bytes differ from the bytes recorded in the witness file");
+        if (!wt.expected_proof.empty()) parity++;
+      }
+    } catch (const std::exception &e) {
+      std::lock_guard<std::mutex> l(m);
+      error = e.what();
+    }
+  };
+  auto run = [&](int iters) {
+    std::vector<std::thread> threads;
+    for (size_t t = 0; t < (size_t)opt.callers; t++) threads.emplace_back(caller, t, iters);
+    for (auto &t : threads) t.join();
+    if (!error.empty()) die(error);
+  };
+  run((int)bindings.size());  // warm-up: every caller through every binding (allocations, staging buffers of the batch sizes met)
+  std::vector<cp_batcher_stats> before(workers.size());
+  for (size_t w = 0; w < workers.size(); w++) cp_batcher_get_stats(batchers[w], &before[w]);
+  parity = 0;
+  const double t0 = now_s();
+  run(opt.iters);
+  const double dt = now_s() - t0;
+  uint64_t calls = 0, batches = 0, largest = 0, retried = 0;
+  for (size_t w = 0; w < workers.size(); w++) {
+    cp_batcher_stats st;
+    cp_batcher_get_stats(batchers[w], &st);
+    calls += st.calls - before[w].calls;
+    batches += st.batches - before[w].batches;
+    retried += st.retried_singly - before[w].retried_singly;
+    if (st.largest_batch > largest) largest = st.largest_batch;
+    cp_batcher_destroy(batchers[w]);
+  }
+  printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"callers\", \"devices\": %zu, \"contexts_per_device\": %d, \"lanes_per_context\": %d, "
+         "\"callers\": %d, \"max_batch\": %d, \"linger_us\": %d, \"proofs\": %llu, \"batches\": %llu, \"mean_batch\": %.2f, \"largest_batch\": %llu, "
+         "\"retried_singly\": %llu, \"wall_s\": %.6f, \"proofs_per_s\": %.2f, \"blocks_per_s\": %.3f, \"proofs_byte_checked\": %zu, "
+         "\"wires\": \"host (page-locked), PCIe-inclusive; every caller proves one job per call\"}\n",
+         devices.size(), opt.contexts, opt.lanes, opt.callers, opt.batch, opt.linger_us, (unsigned long long)calls, (unsigned long long)batches,
+         batches ? (double)calls / batches : 0.0, (unsigned long long)largest, (unsigned long long)retried, dt, calls / dt, calls / dt / 64.0, parity.load());
+  for (auto &w : workers) w.close();
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -678,6 +766,8 @@ int main(int argc, char **argv) {
     else if (a == "--iters") opt.iters = atoi(val().c_str());
     else if (a == "--blocks-in-flight") opt.blocks_in_flight = atoi(val().c_str());
     else if (a == "--lanes") opt.lanes = atoi(val().c_str());
+    else if (a == "--callers") opt.callers = atoi(val().c_str());
+    else if (a == "--linger-us") opt.linger_us = atoi(val().c_str());
     else if (a == "--trace") opt.trace_path = val();
     else if (a == "--groth16-log-size") opt.groth16_log = atoi(val().c_str());
     else if (a == "--dry-run") opt.dry_run = true;
@@ -697,19 +787,21 @@ int main(int argc, char **argv) {
     } else die("unknown argument " + a);
   }
   if (opt.groth16_log != 0 && (opt.groth16_log < 4 || opt.groth16_log > 26)) die("--groth16-log-size must be 0 (off) or 4..26");
-  if (opt.iterations < 1 || opt.contexts < 1 || opt.batch < 1 || opt.blocks_in_flight < 1 || opt.iters < 1 || opt.lanes < 1) die("bad argument value");
+  if (opt.iterations < 1 || opt.contexts < 1 || opt.batch < 1 || opt.blocks_in_flight < 1 || opt.iters < 1 || opt.lanes < 1 || opt.callers < 1 || opt.linger_us < 0) die("bad argument value");
   // Every context owns a HIP stream, and the runtime multiplexes the streams of ONE process onto GPU_MAX_HW_QUEUES hardware
   // queues (default 4): with more contexts than that, kernels of different contexts queue behind each other instead of
   // overlapping (measured: 8 contexts x batch 1 = 656 proofs/s on 4 queues, 930 on 8, 1 020 with 12 x 12). The reference's
   // deployment — one worker PROCESS per job stream — has a runtime and queues per process and does not meet this limit;
   // a pool of threads in one process does. Ask for as many queues as contexts (up to 12) unless the caller set the variable;
   // it is read when the HIP runtime initialises, i.e. at the first cp_* call below.
-  if (opt.contexts > 4 && !opt.dry_run) setenv("GPU_MAX_HW_QUEUES", std::to_string(opt.contexts < 12 ? opt.contexts : 12).c_str(), 0);
+  const int streams = opt.contexts * (opt.lanes > 1 ? opt.lanes + 1 : 1);  // a lane is a context of its own, beside its parent
+  if (streams > 4 && !opt.dry_run) setenv("GPU_MAX_HW_QUEUES", std::to_string(streams < 12 ? streams : 12).c_str(), 0);
   try {
     if (opt.mode == "qbench") return run_qbench(opt);
     if (opt.mode == "throughput") return run_throughput(opt);
+    if (opt.mode == "callers") return run_callers(opt);
   } catch (const std::exception &e) {
     die(e.what());
   }
-  die("--mode must be qbench or throughput");
+  die("--mode must be qbench, throughput or callers");
 }
