@@ -213,6 +213,14 @@ def test_one_block_end_to_end_with_byte_parity(golden_dir, tmp_path):
     res = run(["-i", dump, "-n", "2", "--blocks-in-flight", "2", "--pack", pack, "--devices", "0,0", "--contexts", "2", "--batch", "8",
                "--check-plan"])
     assert res["blocks_complete"] == 2 and res["workers"] == 4 and res["devices"] == [0, 0] and res["proofs_byte_checked"] >= 128
+    # reference-style loops as THREADS of one process: twelve of them on one context with two lanes, each popping one job and
+    # proving one proof per call, merged by a cp_batcher — same jobs, same bytes; and the raw callers loop
+    res = run(["-i", dump, "-n", "2", "--blocks-in-flight", "2", "--pack", pack, "--contexts", "1", "--lanes", "2", "--callers", "12",
+               "--batch", "8", "--linger-us", "200"])
+    assert res["blocks_complete"] == 2 and res["workers"] == 12 and res["callers_per_context"] == 12 and res["proofs_byte_checked"] >= 128
+    res = run(["--mode", "callers", "--pack", pack, "--contexts", "1", "--lanes", "2", "--callers", "12", "--batch", "8", "--iters", "6"])
+    assert res["proofs"] == 72 and res["proofs_byte_checked"] == 72 and res["batches"] < 72 and res["retried_singly"] == 0
+    assert "one caller per context" in run(["-i", dump, "--pack", pack, "--callers", "4", "--groth16-log-size", "10"], ok=False)
     # a tampered witness file (recorded proof altered) is caught by the byte comparison
     wit = os.path.join(pack, "synthetic_0.cpwit")
     from cityprover import files

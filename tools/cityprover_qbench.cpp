@@ -35,7 +35,8 @@
 // Every proof is compared byte for byte with the proof recorded in its witness file (the CPU oracle's, or the Rust
 // prover's under nonce injection) when one is recorded. --dry-run runs the whole schedule without proving anything and
 // without a GPU (tests of the planner and the queue semantics); --mode throughput is the raw proofs/s measurement;
-// --mode callers measures one-job-per-call threads (--callers T) merged by a cp_batcher (--batch = its max_batch, --linger-us).
+// --mode callers measures one-job-per-call threads (--callers T) merged by a cp_batcher (--batch = its max_batch, --linger-us);
+// --callers T in the default mode drains the DAG with T such threads per context instead of one batching thread.
 // Build: g++ -O2 -std=c++17 -Iinclude tools/cityprover_qbench.cpp -Lcity-rollup_amd -lcityprover_hip
 //            -Wl,-rpath,'$ORIGIN/../city-rollup_amd' -lpthread -o tools/cityprover_qbench
 #include <algorithm>
@@ -71,7 +72,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 struct Options {
   std::vector<std::string> inputs;
   std::string output, network = "dogeregtest", pack_dir, mode = "qbench", trace_path;
-  int iterations = 1, contexts = 3, batch = 32, blocks_in_flight = 1, lanes = 1, iters = 8, callers = 32, linger_us = 0;
+  int iterations = 1, contexts = 3, batch = 32, blocks_in_flight = 1, lanes = 1, iters = 8, callers = 0, linger_us = 0;
   int groth16_log = 0;  // > 0: the Groth16 job runs cp_groth16_prove_bls12381 on a synthetic key of 2^groth16_log constraints
   std::vector<int> devices;  // empty: all visible
   bool dry_run = false, ref_counters = false, check_plan = false;
@@ -105,8 +106,10 @@ struct Scheduler {
 
   void enqueue(Instance *inst, const std::vector<JobId> &jobs) {
     std::lock_guard<std::mutex> l(m);
-    for (const JobId &j : jobs) queue.push_back({inst, j});
-    cv.notify_all();
+    for (const JobId &j : jobs) {
+      queue.push_back({inst, j});
+      cv.notify_one();  // one sleeper per job: with a hundred worker threads, waking them all for every job is what costs
+    }
   }
   void fail(const std::string &msg) {
     std::lock_guard<std::mutex> l(m);
@@ -150,7 +153,7 @@ struct Scheduler {
   void finished(size_t n) {
     std::lock_guard<std::mutex> l(m);
     in_flight -= n;
-    cv.notify_all();
+    if (in_flight == 0) cv.notify_all();  // the end of the run (or a DAG that ran dry) is decided by the sleepers
   }
 };
 
@@ -250,6 +253,7 @@ struct Worker {
   size_t parity_checked = 0, proofs = 0, groth16_proofs = 0;
   Groth16Stage groth16;
   bool has_groth16 = false;
+  cp_batcher *batcher = nullptr;  // --callers: several threads share this worker and prove one job per call through it
 
   void check(int rc, const char *what) const {
     if (rc != CP_OK) throw std::runtime_error(std::string(what) + ": " + cp_last_error(ctx));
@@ -287,23 +291,33 @@ struct Worker {
     std::vector<const uint64_t *> pis(count, wt.public_inputs.data()), ws(count, wires[b.witness]);
     std::vector<size_t> npi(count, wt.public_inputs.size()), lens(count);
     std::vector<uint8_t *> out(count, nullptr);
-    check(cp_prove_batch_host(ctx, count, cc.data(), pis.data(), npi.data(), ws.data(), nullptr, nullptr, out.data(), lens.data()),
-          "cp_prove_batch_host");
+    if (batcher) {  // the calling thread is one of several sharing this worker: its message is the thread's, not the context's
+      for (size_t i = 0; i < count; i++)
+        if (cp_batcher_prove(batcher, cc[i], ws[i], pis[i], npi[i], 0, 0, &out[i], &lens[i]) != CP_OK)
+          throw std::runtime_error(std::string("cp_batcher_prove: ") + cp_last_error(nullptr));
+    } else {
+      check(cp_prove_batch_host(ctx, count, cc.data(), pis.data(), npi.data(), ws.data(), nullptr, nullptr, out.data(), lens.data()),
+            "cp_prove_batch_host");
+    }
     std::vector<std::vector<uint8_t>> res(count);
     bool bad = false;
+    size_t checked = 0;
     for (size_t i = 0; i < count; i++) {
       res[i].assign(out[i], out[i] + lens[i]);
       cp_free(out[i]);
       if (!wt.expected_proof.empty()) {
         bad = bad || res[i] != wt.expected_proof;
-        parity_checked++;
+        checked++;
       }
     }
-    proofs += count;
+    __atomic_fetch_add(&parity_checked, checked, __ATOMIC_RELAXED);  // plain counters, several threads with --callers
+    __atomic_fetch_add(&proofs, count, __ATOMIC_RELAXED);
     if (bad) throw std::runtime_error("proof bytes differ from the bytes recorded in the witness file (circuit " + pack->circuit_files[b.circuit] + ")");
     return res;
   }
   void close() {
+    if (batcher) cp_batcher_destroy(batcher);
+    batcher = nullptr;
     if (has_groth16) groth16.close(ctx);
     for (auto *w : wires) cp_host_free(ctx, w);
     for (auto *c : circuits) cp_circuit_destroy(c);
@@ -391,9 +405,9 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const qb::P
   }
 }
 
-void worker_loop(const Options &opt, Scheduler &S, Worker *worker, const qb::Pack *pack) {
+void worker_loop(const Options &opt, Scheduler &S, Worker *worker, const qb::Pack *pack, size_t take) {
   std::vector<QueueEntry> batch;
-  while (S.take((size_t)opt.batch, batch)) {
+  while (S.take(take, batch)) {
     try {
       process_batch(opt, S, worker, pack, batch);
     } catch (const std::exception &e) {
@@ -500,7 +514,16 @@ int run_qbench(const Options &opt) {
       die(e.what());
     }
   }
-  const size_t n_workers = opt.dry_run ? (size_t)std::max(1, opt.contexts) : workers.size();
+  // --callers T: T threads per context, each the reference's loop (one job per pop, one proof per call), merged by a cp_batcher
+  const size_t per_worker = opt.callers > 0 && !opt.dry_run ? (size_t)opt.callers : 1;
+  if (opt.callers > 0 && !opt.dry_run) {
+    if (opt.groth16_log > 0) die("--callers shares a context between threads: the Groth16 stage (one caller per context) cannot run there");
+    for (auto &w : workers) {
+      w.batcher = cp_batcher_create(w.ctx, (size_t)opt.batch, (unsigned)opt.linger_us);
+      if (!w.batcher) die(std::string("cp_batcher_create: ") + cp_last_error(nullptr));
+    }
+  }
+  const size_t n_workers = opt.dry_run ? (size_t)std::max(1, opt.contexts) : workers.size() * per_worker;
 
   Scheduler S;
   const double t_begin = now_s();
@@ -526,7 +549,8 @@ int run_qbench(const Options &opt) {
     std::vector<std::thread> threads;
     for (size_t w = 0; w < n_workers; w++)
       threads.emplace_back([&, w] {
-        worker_loop(opt, S, opt.dry_run ? nullptr : &workers[w], opt.dry_run ? nullptr : &pack);
+        worker_loop(opt, S, opt.dry_run ? nullptr : &workers[w / per_worker], opt.dry_run ? nullptr : &pack,
+                    opt.callers > 0 && !opt.dry_run ? 1 : (size_t)opt.batch);
       });
     for (auto &t : threads) t.join();
     if (opt.ref_counters && !S.failed && !instances[next]->complete) {
@@ -579,12 +603,12 @@ int run_qbench(const Options &opt) {
   printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"%s\", \"dumps\": %zu, \"iterations\": %d, \"blocks\": %zu, \"blocks_complete\": %zu, "
          "\"jobs\": %zu, \"proofs\": %zu, \"jobs_per_block\": %.1f, \"proofs_per_block\": %.1f, \"wall_s\": %.6f, \"blocks_per_s\": %.4f, "
          "\"proofs_per_s\": %.2f, \"mean_block_latency_ms\": %.2f, \"devices\": [%s], \"contexts_per_device\": %d, \"workers\": %zu, "
-         "\"max_batch\": %d, \"blocks_in_flight\": %d, \"proofs_byte_checked\": %zu, \"groth16_proofs\": %zu, \"groth16_log_constraints\": %d, \"pack\": \"%s\", \"timed\": \"from the first enqueue to the "
+         "\"callers_per_context\": %d, \"lanes_per_context\": %d, \"linger_us\": %d, \"max_batch\": %d, \"blocks_in_flight\": %d, \"proofs_byte_checked\": %zu, \"groth16_proofs\": %zu, \"groth16_log_constraints\": %d, \"pack\": \"%s\", \"timed\": \"from the first enqueue to the "
          "last completion; circuits resident, witnesses page-locked on the host (PCIe-inclusive), witness generation excluded\"}\n",
          opt.dry_run ? "dry-run" : "qbench", dumps.size(), opt.iterations, instances.size(), complete, jobs, proofs,
          instances.empty() ? 0.0 : (double)jobs / instances.size(), instances.empty() ? 0.0 : (double)proofs / instances.size(), wall,
          wall > 0 ? complete / wall : 0.0, wall > 0 ? proofs / wall : 0.0, complete ? latency_sum / complete * 1e3 : 0.0, devs.c_str(), opt.contexts,
-         n_workers, opt.batch, opt.blocks_in_flight, parity, groth16_proofs, opt.groth16_log, json_escape(opt.pack_dir).c_str());
+         n_workers, opt.dry_run ? 0 : opt.callers, opt.lanes, opt.linger_us, opt.batch, opt.blocks_in_flight, parity, groth16_proofs, opt.groth16_log, json_escape(opt.pack_dir).c_str());
   for (auto &w : workers) w.close();
   return complete == instances.size() || opt.ref_counters ? 0 : 1;
 }
@@ -661,7 +685,9 @@ int run_throughput(const Options &opt) {
 
 // one-job-at-a-time callers: --callers threads, each proving --iters single proofs through a cp_batcher (one per context) —
 // the reference's worker loops (actors/simple.rs:32-56) as threads of one process sharing a GPU
-int run_callers(const Options &opt) {
+int run_callers(const Options &opt_in) {
+  Options opt = opt_in;
+  if (opt.callers < 1) opt.callers = 32;
   if (opt.pack_dir.empty()) die("--pack DIR is required");
   const int n_dev = cp_device_count();
   if (n_dev <= 0) die("no HIP device visible: this library has no CPU fallback");
@@ -787,7 +813,7 @@ int main(int argc, char **argv) {
     } else die("unknown argument " + a);
   }
   if (opt.groth16_log != 0 && (opt.groth16_log < 4 || opt.groth16_log > 26)) die("--groth16-log-size must be 0 (off) or 4..26");
-  if (opt.iterations < 1 || opt.contexts < 1 || opt.batch < 1 || opt.blocks_in_flight < 1 || opt.iters < 1 || opt.lanes < 1 || opt.callers < 1 || opt.linger_us < 0) die("bad argument value");
+  if (opt.iterations < 1 || opt.contexts < 1 || opt.batch < 1 || opt.blocks_in_flight < 1 || opt.iters < 1 || opt.lanes < 1 || opt.callers < 0 || opt.linger_us < 0) die("bad argument value");
   // Every context owns a HIP stream, and the runtime multiplexes the streams of ONE process onto GPU_MAX_HW_QUEUES hardware
   // queues (default 4): with more contexts than that, kernels of different contexts queue behind each other instead of
   // overlapping (measured: 8 contexts x batch 1 = 656 proofs/s on 4 queues, 930 on 8, 1 020 with 12 x 12). The reference's

@@ -14,4 +14,4 @@ for cfg in "1 1 8 0" "1 1 32 0" "1 1 64 0" "1 3 64 0" "1 3 64 200" "1 3 64 500" 
   set -- $cfg
   $Q --mode callers --pack $PACK --contexts $1 --lanes $2 --callers $3 --batch 32 --linger-us $4 --iters 24 | tail -1 >> "$OUT"
 done
-wc -l "$OUT"
+"$R/tools/qbench_callers_dag.sh" "$OUT"
