@@ -183,6 +183,27 @@ def test_harness_fails_loudly_without_a_gpu(golden_dir, tmp_path):
     assert "no HIP device" in err and "no CPU fallback" in err
 
 
+def test_scheduler_under_thread_sanitizer(golden_dir, tmp_path):
+    """The harness's ready queue and proof stores with 32 worker threads, four blocks in flight, under ThreadSanitizer
+    (--dry-run: the whole schedule, no proving): every block completes and the race detector stays silent."""
+    build_harness()
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    exe = str(tmp_path / "qbench_tsan")
+    r = subprocess.run([clang, "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "tools"), EXE + ".cpp", "-L" + os.path.join(ROOT, "city-rollup_amd"), "-lcityprover_hip",
+                        "-Wl,-rpath," + os.path.join(ROOT, "city-rollup_amd"), "-lpthread", "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no ThreadSanitizer build: " + r.stderr[-300:])
+    dump = os.path.join(golden_dir, "qbench_example.bin")
+    for args in (["--contexts", "32", "--batch", "1", "-n", "16", "--blocks-in-flight", "4"],
+                 ["--contexts", "16", "--batch", "4", "-n", "8", "--blocks-in-flight", "8"]):
+        r = subprocess.run([exe, "-i", dump, "--dry-run"] + args, capture_output=True, text=True, timeout=300)
+        assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+        assert r.returncode == 0, r.stderr[-1000:]
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+        assert res["blocks_complete"] == res["blocks"] == int(args[5])
+
+
 @pytest.mark.gpu
 def test_one_block_end_to_end_with_byte_parity(golden_dir, tmp_path):
     """One example block proved job by job on 2 worker contexts: 46 jobs = 64 proofs, every proof byte-identical to the
