@@ -18,7 +18,7 @@ use std::path::Path;
 use std::sync::{Mutex, OnceLock};
 
 use anyhow::{bail, ensure, Result};
-use cityprover_sys::{Circuit as GpuCircuit, Context, CpGate, CpShape};
+use cityprover_sys::{Batcher, Circuit as GpuCircuit, Context, CpGate, CpShape};
 
 use crate::field::goldilocks_field::GoldilocksField;
 use crate::field::types::{Field, PrimeField64};
@@ -46,6 +46,27 @@ pub fn context() -> Result<&'static Mutex<Context>> {
         ctx.set_lanes(l)?;
     }
     Ok(CTX.get_or_init(|| Mutex::new(ctx)))
+}
+
+/// `CITYPROVER_BATCH=<max_batch>` (with `CITYPROVER_LINGER_US`, default 300): the process runs SEVERAL worker loops as threads
+/// (N x `SimpleActorWorker::run_worker` over one toolbox, city_rollup_core_worker/src/actors/simple.rs:32-56) and their
+/// one-proof `prove` calls are merged into batches by a `cp_batcher` instead of queueing on the context's mutex — measured at
+/// the rate of an explicitly batching worker. The batcher proves on the context's LANES (at least two are
+/// forced: `CITYPROVER_LANES`, default 4), so that the context itself stays free for circuit loads under the mutex.
+pub fn batcher() -> Result<Option<&'static Batcher>> {
+    static B: OnceLock<Option<Batcher>> = OnceLock::new();
+    if let Some(b) = B.get() {
+        return Ok(b.as_ref());
+    }
+    let Some(max_batch) = std::env::var("CITYPROVER_BATCH").ok().and_then(|s| s.parse::<usize>().ok()) else {
+        return Ok(B.get_or_init(|| None).as_ref());
+    };
+    let linger = std::env::var("CITYPROVER_LINGER_US").ok().and_then(|s| s.parse().ok()).unwrap_or(300u32);
+    let ctx = context()?.lock().unwrap();
+    let lanes = std::env::var("CITYPROVER_LANES").ok().and_then(|s| s.parse().ok()).unwrap_or(4usize).max(2);
+    ctx.set_lanes(lanes)?;
+    let b = Batcher::new(&ctx, max_batch, linger)?;
+    Ok(B.get_or_init(|| Some(b)).as_ref())
 }
 
 /// `gate.0.id()` is the Debug form of the gate struct, e.g. "ArithmeticGate { num_ops: 20 }",
@@ -306,11 +327,14 @@ pub fn load_gpu_circuit(
 pub fn prove_gpu(handle: &GpuHandle, witness: &MatrixWitness<F>, public_inputs: &[F], pow_witness: Option<u64>) -> Result<ProofWithPublicInputs<F, C, D>> {
     let wires: Vec<u64> = witness.wire_values.iter().flat_map(|col| col.iter().map(|v| v.to_canonical_u64())).collect();
     let pis: Vec<u64> = public_inputs.iter().map(|v| v.to_canonical_u64()).collect();
-    let ctx = context()?.lock().unwrap();
-    let bytes = ctx
-        .prove_batch(&[&handle.circuit], &[&wires], &[&pis], &[pow_witness])?
-        .pop()
-        .expect("one proof");
+    let bytes = match batcher()? {
+        // several worker threads: no lock — the batcher merges whatever calls are in flight
+        Some(b) => b.prove(&handle.circuit, &wires, &pis, pow_witness)?,
+        None => {
+            let ctx = context()?.lock().unwrap();
+            ctx.prove_batch(&[&handle.circuit], &[&wires], &[&pis], &[pow_witness])?.pop().expect("one proof")
+        }
+    };
     // the bytes ARE the bincode the worker stores (city_redis_store/src/lib.rs:71-83)
     Ok(bincode::deserialize(&bytes)?)
 }
