@@ -92,6 +92,30 @@ constexpr int THREADS = 1 << (LOG_TILE - 4);  // 256
 
 __device__ __forceinline__ int pad(int p) { return p + (p >> 4); }
 
+// The tile crosses LDS one 32-bit HALF at a time: a thread's 16 elements are 128 bytes, and with the whole tile resident
+// (34 KB per workgroup) a CU holds four workgroups — four waves per SIMD, which is what bounded both passes (the passes
+// spend 56-66 % of every wave's cycles waiting on memory; with the LDS of a workgroup grown so that only three fit they run
+// 20-22 % slower). Half the bytes, twice the workgroups (now bounded by registers: eight waves per SIMD); the price is two
+// more barriers and 32-bit LDS accesses. x[m] sits at tile position Pw + (m << Fw) and is needed at Pr + (m << Fr).
+__device__ __forceinline__ void exchange(uint32_t *tile, uint64_t (&x)[16], int Pw, int Fw, int Pr, int Fr) {
+  // P has zeros in bits [F, F + 4) (that is where m goes), so pad(P + (m << F)) = pad(P) + pad(m << F): one address register
+  // per side and sixteen compile-time offsets instead of sixteen computed addresses
+  uint32_t *w = tile + pad(Pw), *r = tile + pad(Pr);
+  uint32_t lo[16];
+#pragma unroll
+  for (int m = 0; m < 16; m++) w[pad(m << Fw)] = gl::lo32(x[m]);
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 16; m++) lo[m] = r[pad(m << Fr)];
+  __syncthreads();  // every low word has been read before a high word takes its place
+#pragma unroll
+  for (int m = 0; m < 16; m++) w[pad(m << Fw)] = gl::hi32(x[m]);
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 16; m++) x[m] = gl::pack(lo[m], r[pad(m << Fr)]);
+  // no barrier here: the next writes of a thread go to the positions it has just read (its own set)
+}
+
 // global element index of tile position `pos`
 template <int L, int C, bool ROWS>
 __device__ __forceinline__ size_t gidx(int pos, uint32_t tile_id, int q) {
@@ -101,10 +125,16 @@ __device__ __forceinline__ size_t gidx(int pos, uint32_t tile_id, int q) {
 }
 
 // One pass, L stages, tile = 2^L rows x 2^C outer indices (L + C == 12).
+// Five waves per SIMD: 96 VGPRs, which both passes fit without spilling (85 / 89) once the LDS and row addresses are a base
+// plus compile-time offsets; at six (80 VGPRs) 10-20 registers spill and the passes are slower again (measured: 0.74 / 0.89 ms
+// per 135-column step at five, 0.79 / 1.02 at six, 0.85 / 1.05 with the whole tile in LDS at four).
+#ifndef NTT16_MIN_WAVES
+#define NTT16_MIN_WAVES 5
+#endif
 template <int L, int C, bool ROWS, bool INV>
-__global__ __launch_bounds__(THREADS) void k_dif_pass16(ntt::PassArgs a) {
+__global__ __launch_bounds__(THREADS, NTT16_MIN_WAVES) void k_dif_pass16(ntt::PassArgs a) {
   static_assert(L + C == LOG_TILE && L >= 4, "tile shape");
-  __shared__ uint64_t tile[(1 << LOG_TILE) + (1 << (LOG_TILE - 4))];
+  __shared__ uint32_t tile[(1 << LOG_TILE) + (1 << (LOG_TILE - 4))];  // one 32-bit half of the tile at a time (exchange)
   constexpr int B0 = ((L - 1) % 4) + 1;       // stages of the first round; the rest are full rounds
   constexpr int NROUNDS = 1 + (L - B0) / 4;
   const int t = threadIdx.x;
@@ -120,11 +150,14 @@ __global__ __launch_bounds__(THREADS) void k_dif_pass16(ntt::PassArgs a) {
     constexpr int f = L - 4;                  // r-bit position of the field
     constexpr int F = ROWS ? f : C + f;       // position in tile-position space
     const int P = ((t >> F) << (F + 4)) | (t & ((1 << F) - 1));
+    // ROWS: the tile is contiguous — a wave-uniform base and a 32-bit position instead of a 64-bit index per element
+    const uint64_t *in_t = ROWS ? in + ((size_t)blockIdx.x << LOG_TILE) : in;
+    const uint64_t *ptab_t = (ROWS && ptab) ? ptab + ((size_t)blockIdx.x << LOG_TILE) : ptab;
 #pragma unroll
     for (int m = 0; m < 16; m++) {
-      size_t idx = gidx<L, C, ROWS>(P + (m << F), blockIdx.x, q);
-      uint64_t v = in[idx];
-      if (ptab) v = gl::mul(v, ptab[idx]);
+      const size_t idx = gidx<L, C, ROWS>(P + (m << F), blockIdx.x, q);
+      uint64_t v = ROWS ? in_t[P + (m << F)] : in[idx];
+      if (ptab) v = gl::mul(v, ROWS ? ptab_t[P + (m << F)] : ptab[idx]);
       else if (a.coset_pre && a.first) v = gl::mul(v, ntt::pow_table(a.stab, idx));
       x[m] = v;
     }
@@ -136,37 +169,28 @@ __global__ __launch_bounds__(THREADS) void k_dif_pass16(ntt::PassArgs a) {
       uint64_t T3 = ntt::pow_table(a.wtab, (uint64_t)r_lo << (a.log_n - f - 4));
       round16<INV, B0, false>(x, T3);
     }
-    if constexpr (NROUNDS > 1) {
-#pragma unroll
-      for (int m = 0; m < 16; m++) tile[pad(P + (m << F))] = x[m];
-    }
   }
   // ---- middle / last rounds -----------------------------------------------------------------
-  int Plast = 0;
   constexpr int Flast = ROWS ? 0 : C;
-  if constexpr (NROUNDS == 1) {
-    constexpr int F = ROWS ? (L - 4) : C + (L - 4);
-    Plast = ((t >> F) << (F + 4)) | (t & ((1 << F) - 1));
-  }
+  constexpr int F0 = ROWS ? (L - 4) : C + (L - 4);
+  int Plast = ((t >> F0) << (F0 + 4)) | (t & ((1 << F0) - 1));  // round 0's positions; the last round's after the loop
+  int Fprev = F0;
 #pragma unroll
   for (int k = 1; k < NROUNDS; k++) {
     const int f = L - B0 - 4 * k;             // compile-time after unrolling
     const int F = ROWS ? f : C + f;
     const int P = ((t >> F) << (F + 4)) | (t & ((1 << F) - 1));
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 16; m++) x[m] = tile[pad(P + (m << F))];
+    exchange(tile, x, Plast, Fprev, P, F);
     if (f == 0) {
       round16<INV, 4, true>(x, 1);
-      Plast = P;
     } else {
       const int r = ROWS ? (P & ((1 << L) - 1)) : (P >> C);
       const uint32_t r_lo = r & ((1 << f) - 1);
       uint64_t T3 = ntt::pow_table(a.wtab, (uint64_t)r_lo << (a.log_n - f - 4));
       round16<INV, 4, false>(x, T3);
-#pragma unroll
-      for (int m = 0; m < 16; m++) tile[pad(P + (m << F))] = x[m];
     }
+    Plast = P;
+    Fprev = F;
   }
   // ---- epilogue: inter-pass twiddle, scaling, store -----------------------------------------
   // the thread holds r = r_base + m (m = 0..15) for one (cc): k_loc(m) = rev_L(r_base) + rev4(m) << (L-4)
@@ -197,20 +221,33 @@ __global__ __launch_bounds__(THREADS) void k_dif_pass16(ntt::PassArgs a) {
       for (int m = 0; m < 16; m++) x[m] = gl::mul(x[m], a.scale);
     }
     if (ROWS && a.natural_out) {
-      // single-pass transform: position r holds X[rev_L(r)]; un-permute through LDS, store coalesced
+      // single-pass transform: position r holds X[rev_L(r)]; un-permute through LDS (low words, then high words), store coalesced
+      uint32_t lo[16];
       __syncthreads();
 #pragma unroll
-      for (int m = 0; m < 16; m++) tile[pad((int)ntt::bitrev((uint32_t)(P + m), L))] = x[m];
+      for (int m = 0; m < 16; m++) tile[pad((int)ntt::bitrev((uint32_t)(P + m), L))] = gl::lo32(x[m]);
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 16; m++) lo[m] = tile[pad(t + (m << (LOG_TILE - 4)))];
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 16; m++) tile[pad((int)ntt::bitrev((uint32_t)(P + m), L))] = gl::hi32(x[m]);
       __syncthreads();
 #pragma unroll
       for (int m = 0; m < 16; m++) {
         int pos = t + (m << (LOG_TILE - 4));
-        poly[((size_t)blockIdx.x << LOG_TILE) + pos] = tile[pad(pos)];
+        poly[((size_t)blockIdx.x << LOG_TILE) + pos] = gl::pack(lo[m], tile[pad(pos)]);
       }
       return;
     }
+    if (ROWS) {
+      uint64_t *out_t = poly + ((size_t)blockIdx.x << LOG_TILE) + P;
 #pragma unroll
-    for (int m = 0; m < 16; m++) poly[gidx<L, C, ROWS>(P + (m << Flast), blockIdx.x, q)] = x[m];
+      for (int m = 0; m < 16; m++) out_t[m << Flast] = x[m];
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; m++) poly[gidx<L, C, ROWS>(P + (m << Flast), blockIdx.x, q)] = x[m];
+    }
   }
 }
 
