@@ -132,7 +132,8 @@ __device__ __forceinline__ size_t gidx(int pos, uint32_t tile_id, int q) {
 #define NTT16_MIN_WAVES 5
 #endif
 template <int L, int C, bool ROWS, bool INV>
-__global__ __launch_bounds__(THREADS, NTT16_MIN_WAVES) void k_dif_pass16(ntt::PassArgs a) {
+__global__ __launch_bounds__(THREADS, (L == 4 && !ROWS) ? 4 : NTT16_MIN_WAVES) void k_dif_pass16(ntt::PassArgs a) {  // the one-round column
+  // pass (no exchange; 16 + 15 epilogue twiddles live at once) would spill a dozen registers at five waves
   static_assert(L + C == LOG_TILE && L >= 4, "tile shape");
   __shared__ uint32_t tile[(1 << LOG_TILE) + (1 << (LOG_TILE - 4))];  // one 32-bit half of the tile at a time (exchange)
   constexpr int B0 = ((L - 1) % 4) + 1;       // stages of the first round; the rest are full rounds
