@@ -179,22 +179,32 @@ int run_dif(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stride,
     const bool need16 = ex.src || ex.ptab || ex.n_blocks > 1 || ex.natural_out;
     if (L >= 4 && L + c == ntt16::LOG_TILE && (need16 || !getenv("CITYPROVER_NTT_V1"))) {
       // register radix-16 pass (ntt16.h)
-#define PASS16(LL)                                                                                   \
-  case LL:                                                                                           \
-    if (q_after == 0) {                                                                              \
-      if (inverse) LAUNCH(ctx, "ntt16_rows", (ntt16::k_dif_pass16<LL, 12 - LL, true, true>), grid, dim3(ntt16::THREADS), a);  \
-      else LAUNCH(ctx, "ntt16_rows", (ntt16::k_dif_pass16<LL, 12 - LL, true, false>), grid, dim3(ntt16::THREADS), a);        \
-    } else {                                                                                         \
-      if (inverse) LAUNCH(ctx, "ntt16_cols", (ntt16::k_dif_pass16<LL, 12 - LL, false, true>), grid, dim3(ntt16::THREADS), a); \
-      else LAUNCH(ctx, "ntt16_cols", (ntt16::k_dif_pass16<LL, 12 - LL, false, false>), grid, dim3(ntt16::THREADS), a);       \
-    }                                                                                                \
-    done = true;                                                                                     \
+      // a pass of a big transform has the GPU to itself and is occupancy-bound: half-tile exchange, five waves per SIMD; the
+      // 2^12-2^15 transforms of a proof run beside other contexts' kernels: whole-tile exchange, fewer barriers (ntt16.h)
+      const bool half = log_n >= 16;
+#define PASS16_(LL, ROWS_, NAME)                                                                                              \
+  if (inverse) {                                                                                                              \
+    if (half) LAUNCH(ctx, NAME, (ntt16::k_dif_pass16<LL, 12 - LL, ROWS_, true, true>), grid, dim3(ntt16::THREADS), a);        \
+    else LAUNCH(ctx, NAME, (ntt16::k_dif_pass16<LL, 12 - LL, ROWS_, true, false>), grid, dim3(ntt16::THREADS), a);            \
+  } else {                                                                                                                    \
+    if (half) LAUNCH(ctx, NAME, (ntt16::k_dif_pass16<LL, 12 - LL, ROWS_, false, true>), grid, dim3(ntt16::THREADS), a);       \
+    else LAUNCH(ctx, NAME, (ntt16::k_dif_pass16<LL, 12 - LL, ROWS_, false, false>), grid, dim3(ntt16::THREADS), a);           \
+  }
+#define PASS16(LL)                                 \
+  case LL:                                         \
+    if (q_after == 0) {                            \
+      PASS16_(LL, true, "ntt16_rows")              \
+    } else {                                       \
+      PASS16_(LL, false, "ntt16_cols")             \
+    }                                              \
+    done = true;                                   \
     break;
       switch (L) {
         PASS16(4) PASS16(5) PASS16(6) PASS16(7) PASS16(8) PASS16(9) PASS16(10) PASS16(11) PASS16(12)
         default: break;
       }
 #undef PASS16
+#undef PASS16_
     }
     if (!done && need16) return set_error(ctx, CP_ERR_INTERNAL, "radix-16 pass required but unavailable (L=%d c=%d)", L, c);
     if (!done) {

@@ -11,6 +11,8 @@
 // thread-uniform factor per stage, omega_{2^(f+b+1)}^(r_lo): one table lookup and three squarings
 // per round. The last round of a pass (f = 0) needs no multiplications at all.
 #pragma once
+#include <type_traits>
+
 #include "gl.h"
 #include "ntt.h"
 
@@ -92,28 +94,40 @@ constexpr int THREADS = 1 << (LOG_TILE - 4);  // 256
 
 __device__ __forceinline__ int pad(int p) { return p + (p >> 4); }
 
-// The tile crosses LDS one 32-bit HALF at a time: a thread's 16 elements are 128 bytes, and with the whole tile resident
-// (34 KB per workgroup) a CU holds four workgroups — four waves per SIMD, which is what bounded both passes (the passes
-// spend 56-66 % of every wave's cycles waiting on memory; with the LDS of a workgroup grown so that only three fit they run
-// 20-22 % slower). Half the bytes, twice the workgroups (now bounded by registers: eight waves per SIMD); the price is two
-// more barriers and 32-bit LDS accesses. x[m] sits at tile position Pw + (m << Fw) and is needed at Pr + (m << Fr).
-__device__ __forceinline__ void exchange(uint32_t *tile, uint64_t (&x)[16], int Pw, int Fw, int Pr, int Fr) {
-  // P has zeros in bits [F, F + 4) (that is where m goes), so pad(P + (m << F)) = pad(P) + pad(m << F): one address register
-  // per side and sixteen compile-time offsets instead of sixteen computed addresses
-  uint32_t *w = tile + pad(Pw), *r = tile + pad(Pr);
-  uint32_t lo[16];
+// Two ways for the tile to cross LDS between rounds.
+// HALF = false: all 4096 elements at once (34 KB per workgroup: four workgroups per CU, four waves per SIMD) and one barrier.
+// HALF = true: one 32-bit half at a time (17 KB; low words, barrier, high words) — with 85-89 VGPRs that is five waves per
+// SIMD, at the price of two more barriers and 32-bit LDS accesses. A pass that has the GPU to itself is bound by that
+// occupancy (56-66 % of every wave's cycles are memory waits; with the LDS of a workgroup grown so that only three fit, the
+// passes run 20-22 % slower; with HALF the 135 x 2^20 passes go 0.85 -> 0.74 ms and 1.05 -> 0.89 ms). The 2^12-2^15 transforms of
+// a proof run beside the kernels of the other contexts, which hide the waits anyway; there the extra barriers only cost
+// (three contexts x batch 32: 1 963 -> 1 918 proofs/s with HALF everywhere), so cityprover.hip picks HALF by transform size.
+// x[m] sits at tile position Pw + (m << Fw) and is needed at Pr + (m << Fr). P has zeros in bits [F, F + 4) (that is where m
+// goes), so pad(P + (m << F)) = pad(P) + pad(m << F): one address register per side and sixteen compile-time offsets.
+template <bool HALF, typename T>
+__device__ __forceinline__ void exchange(T *tile, uint64_t (&x)[16], int Pw, int Fw, int Pr, int Fr) {
+  T *w = tile + pad(Pw), *r = tile + pad(Pr);
+  if constexpr (HALF) {
+    uint32_t lo[16];
 #pragma unroll
-  for (int m = 0; m < 16; m++) w[pad(m << Fw)] = gl::lo32(x[m]);
-  __syncthreads();
+    for (int m = 0; m < 16; m++) w[pad(m << Fw)] = gl::lo32(x[m]);
+    __syncthreads();
 #pragma unroll
-  for (int m = 0; m < 16; m++) lo[m] = r[pad(m << Fr)];
-  __syncthreads();  // every low word has been read before a high word takes its place
+    for (int m = 0; m < 16; m++) lo[m] = r[pad(m << Fr)];
+    __syncthreads();  // every low word has been read before a high word takes its place
 #pragma unroll
-  for (int m = 0; m < 16; m++) w[pad(m << Fw)] = gl::hi32(x[m]);
-  __syncthreads();
+    for (int m = 0; m < 16; m++) w[pad(m << Fw)] = gl::hi32(x[m]);
+    __syncthreads();
 #pragma unroll
-  for (int m = 0; m < 16; m++) x[m] = gl::pack(lo[m], r[pad(m << Fr)]);
-  // no barrier here: the next writes of a thread go to the positions it has just read (its own set)
+    for (int m = 0; m < 16; m++) x[m] = gl::pack(lo[m], r[pad(m << Fr)]);
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; m++) w[pad(m << Fw)] = x[m];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = r[pad(m << Fr)];
+  }
+  // no barrier at the end: the next writes of a thread go to the positions it has just read (its own set)
 }
 
 // global element index of tile position `pos`
@@ -125,17 +139,18 @@ __device__ __forceinline__ size_t gidx(int pos, uint32_t tile_id, int q) {
 }
 
 // One pass, L stages, tile = 2^L rows x 2^C outer indices (L + C == 12).
-// Five waves per SIMD: 96 VGPRs, which both passes fit without spilling (85 / 89) once the LDS and row addresses are a base
-// plus compile-time offsets; at six (80 VGPRs) 10-20 registers spill and the passes are slower again (measured: 0.74 / 0.89 ms
-// per 135-column step at five, 0.79 / 1.02 at six, 0.85 / 1.05 with the whole tile in LDS at four).
+// HALF passes ask for five waves per SIMD: 96 VGPRs, which they fit without spilling (85 / 89) now that the LDS and row
+// addresses are a base plus compile-time offsets; at six (80 VGPRs) 10-20 registers spill and the passes are slower again
+// (0.79 / 1.02 ms per 135-column step against 0.74 / 0.89). The one-round column pass (L = 4: no exchange, 16 + 15 epilogue
+// twiddles live at once) would spill a dozen registers at five and keeps the default.
 #ifndef NTT16_MIN_WAVES
 #define NTT16_MIN_WAVES 5
 #endif
-template <int L, int C, bool ROWS, bool INV>
-__global__ __launch_bounds__(THREADS, (L == 4 && !ROWS) ? 4 : NTT16_MIN_WAVES) void k_dif_pass16(ntt::PassArgs a) {  // the one-round column
-  // pass (no exchange; 16 + 15 epilogue twiddles live at once) would spill a dozen registers at five waves
+template <int L, int C, bool ROWS, bool INV, bool HALF>
+__global__ __launch_bounds__(THREADS, (HALF && !(L == 4 && !ROWS)) ? NTT16_MIN_WAVES : 1) void k_dif_pass16(ntt::PassArgs a) {
   static_assert(L + C == LOG_TILE && L >= 4, "tile shape");
-  __shared__ uint32_t tile[(1 << LOG_TILE) + (1 << (LOG_TILE - 4))];  // one 32-bit half of the tile at a time (exchange)
+  using tile_t = typename std::conditional<HALF, uint32_t, uint64_t>::type;
+  __shared__ tile_t tile[(1 << LOG_TILE) + (1 << (LOG_TILE - 4))];
   constexpr int B0 = ((L - 1) % 4) + 1;       // stages of the first round; the rest are full rounds
   constexpr int NROUNDS = 1 + (L - B0) / 4;
   const int t = threadIdx.x;
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(THREADS, (L == 4 && !ROWS) ? 4 : NTT16_MIN_WAVES) v
     const int f = L - B0 - 4 * k;             // compile-time after unrolling
     const int F = ROWS ? f : C + f;
     const int P = ((t >> F) << (F + 4)) | (t & ((1 << F) - 1));
-    exchange(tile, x, Plast, Fprev, P, F);
+    exchange<HALF>(tile, x, Plast, Fprev, P, F);
     if (f == 0) {
       round16<INV, 4, true>(x, 1);
     } else {
@@ -222,22 +237,33 @@ __global__ __launch_bounds__(THREADS, (L == 4 && !ROWS) ? 4 : NTT16_MIN_WAVES) v
       for (int m = 0; m < 16; m++) x[m] = gl::mul(x[m], a.scale);
     }
     if (ROWS && a.natural_out) {
-      // single-pass transform: position r holds X[rev_L(r)]; un-permute through LDS (low words, then high words), store coalesced
-      uint32_t lo[16];
+      // single-pass transform: position r holds X[rev_L(r)]; un-permute through LDS (HALF: low words, then high words), store coalesced
       __syncthreads();
+      if constexpr (HALF) {
+        uint32_t lo[16];
 #pragma unroll
-      for (int m = 0; m < 16; m++) tile[pad((int)ntt::bitrev((uint32_t)(P + m), L))] = gl::lo32(x[m]);
-      __syncthreads();
+        for (int m = 0; m < 16; m++) tile[pad((int)ntt::bitrev((uint32_t)(P + m), L))] = gl::lo32(x[m]);
+        __syncthreads();
 #pragma unroll
-      for (int m = 0; m < 16; m++) lo[m] = tile[pad(t + (m << (LOG_TILE - 4)))];
-      __syncthreads();
+        for (int m = 0; m < 16; m++) lo[m] = tile[pad(t + (m << (LOG_TILE - 4)))];
+        __syncthreads();
 #pragma unroll
-      for (int m = 0; m < 16; m++) tile[pad((int)ntt::bitrev((uint32_t)(P + m), L))] = gl::hi32(x[m]);
-      __syncthreads();
+        for (int m = 0; m < 16; m++) tile[pad((int)ntt::bitrev((uint32_t)(P + m), L))] = gl::hi32(x[m]);
+        __syncthreads();
 #pragma unroll
-      for (int m = 0; m < 16; m++) {
-        int pos = t + (m << (LOG_TILE - 4));
-        poly[((size_t)blockIdx.x << LOG_TILE) + pos] = gl::pack(lo[m], tile[pad(pos)]);
+        for (int m = 0; m < 16; m++) {
+          int pos = t + (m << (LOG_TILE - 4));
+          poly[((size_t)blockIdx.x << LOG_TILE) + pos] = gl::pack(lo[m], tile[pad(pos)]);
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 16; m++) tile[pad((int)ntt::bitrev((uint32_t)(P + m), L))] = x[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+          int pos = t + (m << (LOG_TILE - 4));
+          poly[((size_t)blockIdx.x << LOG_TILE) + pos] = tile[pad(pos)];
+        }
       }
       return;
     }
