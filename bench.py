@@ -178,18 +178,20 @@ def native_qbench(device, rank, pack):
         serial = run(["-i", dump, "--contexts", "1", "--batch", "1"])
         thr = run(["--mode", "throughput", "--contexts", "3", "--batch", "32", "--iters", "8"])
         # the reference's loops unchanged (one job per pop, one proof per call) as 128 threads sharing one context through cp_batcher
+        # (rank 0 only: a side measurement, and 128 threads per rank would be a thousand on an 8-GPU node)
         callers = run(["-i", dump, "-n", "64", "--blocks-in-flight", "32", "--contexts", "1", "--lanes", "4", "--callers", "128",
-                       "--batch", "32", "--linger-us", "300"])
+                       "--batch", "32", "--linger-us", "300"]) if rank == 0 else None
     return {"blocks_per_s": many["blocks_per_s"], "proofs_per_s": many["proofs_per_s"], "blocks_in_flight": many["blocks_in_flight"],
             "jobs_per_block": many["jobs_per_block"], "proofs_per_block": many["proofs_per_block"],
             "proofs_byte_checked": many["proofs_byte_checked"], "job_records_written": len(per_job),
             "one_block_latency_ms": one["mean_block_latency_ms"],
             "reference_loop_block_ms": serial["mean_block_latency_ms"],
             "throughput_mode_proofs_per_s": thr["proofs_per_s"], "contexts_per_gpu": 3, "max_batch": 32,
-            "one_job_per_call_threads": {"blocks_per_s": callers["blocks_per_s"], "proofs_per_s": callers["proofs_per_s"],
-                                         "threads": 128, "lanes": 4, "linger_us": 300, "proofs_byte_checked": callers["proofs_byte_checked"],
-                                         "note": "--callers 128 --lanes 4: the DAG drained by one-job-per-call threads merged by "
-                                                 "cp_batcher (include/cityprover.h) instead of a batching worker"},
+            "one_job_per_call_threads": None if callers is None else {
+                "blocks_per_s": callers["blocks_per_s"], "proofs_per_s": callers["proofs_per_s"], "threads": 128, "lanes": 4,
+                "linger_us": 300, "proofs_byte_checked": callers["proofs_byte_checked"],
+                "note": "rank 0's GPU only; --callers 128 --lanes 4: the DAG drained by one-job-per-call threads merged by "
+                        "cp_batcher (include/cityprover.h) instead of a batching worker"},
             "harness": "tools/cityprover_qbench -i tests/golden/qbench_example.bin (the reference's own q-bench dump) -n 128 "
                        "--blocks-in-flight 32 --contexts 3 --batch 32; one_block = the same dump alone; reference_loop = one "
                        "context, one job at a time (the reference's single-threaded loop)",
