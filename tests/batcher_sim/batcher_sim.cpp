@@ -46,6 +46,7 @@ int set_error(cp_ctx *ctx, int code, const char *fmt, ...) noexcept {
   return code;
 }
 int exception_status(cp_ctx *ctx) noexcept { return set_error(ctx, CP_ERR_INTERNAL, "internal error"); }
+#define CP_CATCH(ctxexpr) catch (...) { return exception_status(ctxexpr); }
 bool same_shape(const cp_shape &a, const cp_shape &b) { return memcmp(&a, &b, sizeof(cp_shape)) == 0; }
 std::atomic<int> g_violations{0};
 std::atomic<long> g_batches{0};

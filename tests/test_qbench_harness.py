@@ -193,7 +193,11 @@ def test_scheduler_under_thread_sanitizer(golden_dir, tmp_path):
                         "-I" + os.path.join(ROOT, "tools"), EXE + ".cpp", "-L" + os.path.join(ROOT, "city-rollup_amd"), "-lcityprover_hip",
                         "-Wl,-rpath," + os.path.join(ROOT, "city-rollup_amd"), "-lpthread", "-o", exe], capture_output=True, text=True)
     if r.returncode != 0:
-        pytest.skip("no ThreadSanitizer build: " + r.stderr[-300:])
+        probe = subprocess.run([clang, "-x", "c++", "-fsanitize=thread", "-o", exe, "-"], input="int main() { return 0; }",
+                               capture_output=True, text=True)
+        if probe.returncode != 0:
+            pytest.skip("no ThreadSanitizer toolchain: " + probe.stderr[-300:])
+        raise AssertionError(r.stderr[-3000:])
     dump = os.path.join(golden_dir, "qbench_example.bin")
     for args in (["--contexts", "32", "--batch", "1", "-n", "16", "--blocks-in-flight", "4"],
                  ["--contexts", "16", "--batch", "4", "-n", "8", "--blocks-in-flight", "8"]):
