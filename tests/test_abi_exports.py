@@ -49,6 +49,23 @@ def test_batcher_entry_points_reject_null_without_a_gpu():
     lib.cp_batcher_destroy(None)
 
 
+def test_every_entry_point_is_a_function_try_block():
+    """Nothing may unwind through the C ABI into the host (Rust) process: every exported function that does more than read a
+    field is a function-try-block (`int cp_x(...) try { ... } CP_CATCH(ctx)`). The exceptions are listed and trivial."""
+    import glob
+    src = "\n".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "city-rollup_amd", "csrc", "*.hip")) +
+                                                    glob.glob(os.path.join(ROOT, "city-rollup_amd", "csrc", "*.inc"))))
+    trivial = {"cp_abi_version", "cp_device_count", "cp_last_error", "cp_free", "cp_fault_inject", "cp_circuit_shape",
+               "cp_ctx_destroy", "cp_circuit_destroy", "cp_batcher_destroy"}   # getters, free(), destructors (void, try inside)
+    without = set()
+    for sym in header_symbols():
+        m = re.search(r"^(?:extern \"C\" )?[A-Za-z_][\w \*]*\b" + sym + r"\s*\(([^;{]*?)\)\s*(try\s*)?\{", src, flags=re.M | re.S)
+        assert m, f"{sym}: definition not found in csrc"
+        if not m.group(2):
+            without.add(sym)
+    assert without == trivial, sorted(without ^ trivial)
+
+
 def test_product_does_not_reference_oracle():
     # the product path must never import / link / call the oracle
     pkg = os.path.join(ROOT, "city-rollup_amd")
