@@ -362,7 +362,9 @@ int cp_prove_batch_zk_host(cp_ctx *ctx, size_t n_proofs, cp_circuit *const *circ
  * calling thread) does not fail the requests it was batched with: they are proved again singly.
  * linger_us > 0 lets a leader that found fewer than max_batch requests wait that long for more (0: never wait).
  * With cp_ctx_set_lanes(ctx, L > 1) BEFORE cp_batcher_create, up to L batches run at once, one per lane, so that the host
- * phases of one overlap the kernels of another. While a batcher exists, nothing else may prove on its context.
+ * phases of one overlap the kernels of another (the HIP runtime maps the streams of one process onto GPU_MAX_HW_QUEUES = 4
+ * hardware queues by default: with more than three lanes export GPU_MAX_HW_QUEUES=8 before the first cp_* call). While a
+ * batcher exists, nothing else may prove on its context.
  * cp_batcher_destroy waits for running batches; calling it with callers still inside cp_batcher_prove is an error. */
 typedef struct cp_batcher cp_batcher;
 typedef struct cp_batcher_stats {
