@@ -155,7 +155,7 @@ def test_reference_proof_merkle_paths_on_gpu(prover, golden_dir):
 
 
 # ---- NTT -----------------------------------------------------------------------------------
-@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8, 10, 11, 12, 13, 14, 15, 16, 18, 20])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])
 def test_ntt_forward_inverse_match_oracle(prover, log_n):
     import cityprover as cp
     n = 1 << log_n
@@ -195,6 +195,20 @@ def test_coset_ntt_and_lde(prover):
     got = prover.lde(cs, 2, shift=3)
     for b in range(4):
         assert (got[b] == O.coset_lde(cs[b], 2, 3)).all()
+
+
+def test_coset_ntt_above_the_exchange_switch(prover):
+    """2^17 = a 5-stage column pass + a 12-stage row pass, both with the half-tile exchange (transforms of 2^16 and up,
+    ntt16.h): coset forward against the oracle, inverse coset back, and the rate-2 LDE (pre-scale table path)."""
+    import cityprover as cp
+    c = felts(2 << 17, 91).reshape(2, -1)
+    got = prover.ntt(c, flags=cp.NTT_COSET, shift=7)
+    for b in range(2):
+        assert (got[b] == O.coset_lde(c[b], 0, 7)).all()
+    assert (prover.ntt(got, flags=cp.NTT_COSET | cp.NTT_INVERSE, shift=7) == c).all()
+    lde = prover.lde(c, 1, bitrev=True)
+    for b in range(2):
+        assert (lde[b] == O.bit_reverse(O.coset_lde(c[b], 1, 7))).all()
 
 
 def test_ntt_strided_batch(prover):
