@@ -2,6 +2,7 @@
 // ThreadSanitizer, without a GPU: the proving call it merges requests into is replaced by a stand-in that sleeps, checks
 // what a real batch would check (one shape per batch, one batch per slot at a time) and returns bytes derived from the
 // request, so that every caller can verify it received ITS result. Test scaffolding only (tests/test_batcher_sim.py).
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -48,6 +49,7 @@ int set_error(cp_ctx *ctx, int code, const char *fmt, ...) noexcept {
 int exception_status(cp_ctx *ctx) noexcept { return set_error(ctx, CP_ERR_INTERNAL, "internal error"); }
 #define CP_CATCH(ctxexpr) catch (...) { return exception_status(ctxexpr); }
 bool same_shape(const cp_shape &a, const cp_shape &b) { return memcmp(&a, &b, sizeof(cp_shape)) == 0; }
+size_t max_batch(const cp_shape &sh) { return sh.degree_bits == 13 ? 3 : 4096; }  // the second shape fits three proofs per launch
 std::atomic<int> g_violations{0};
 std::atomic<long> g_batches{0};
 }  // namespace
@@ -63,6 +65,7 @@ extern "C" int cp_prove_batch_host(cp_ctx *ctx, size_t n, cp_circuit *const *cir
   int rc = CP_OK;
   for (size_t i = 0; i < n; i++) {
     if (!same_shape(circuits[i]->sh, circuits[0]->sh)) { g_violations++; rc = set_error(ctx, CP_ERR_INVALID_ARG, "mixed shapes"); }
+    if (n > max_batch(circuits[0]->sh)) { g_violations++; rc = set_error(ctx, CP_ERR_INVALID_ARG, "batch too large for this shape"); }
     if (wires[i][0] == 0xBAD) rc = set_error(ctx, CP_ERR_INVALID_ARG, "request with wire 0xBAD is not canonical");
     (void)pis; (void)npi;
   }
