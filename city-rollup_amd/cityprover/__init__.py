@@ -972,3 +972,183 @@ def fri_fold(prover, coeffs_re_im, arity_bits, beta):
     finally:
         din.free()
         dout.free()
+
+
+# ---- the two plonky2-level seams: PolynomialBatch handles and prove_openings / verify_fri_proof -------------------
+class ChallengerState(ctypes.Structure):
+    """cp_challenger_state: plonky2 `Challenger` by value (sponge state, pending inputs, unread outputs)."""
+    _fields_ = [("sponge_state", ctypes.c_uint64 * 12), ("input_buffer", ctypes.c_uint64 * 8),
+                ("output_buffer", ctypes.c_uint64 * 8), ("n_input", ctypes.c_uint32), ("n_output", ctypes.c_uint32)]
+
+    def observe(self, elements):
+        e = _as_u64(elements).ravel()
+        lib = load_library()
+        rc = lib.cp_challenger_observe(ctypes.byref(self), _ptr(e) if e.size else None, e.size)
+        if rc != 0:
+            raise CityProverError(f"[{rc}] " + lib.cp_last_error(None).decode())
+        return self
+
+    def challenges(self, count):
+        out = np.zeros(count, np.uint64)
+        lib = load_library()
+        rc = lib.cp_challenger_challenges(ctypes.byref(self), _ptr(out), count)
+        if rc != 0:
+            raise CityProverError(f"[{rc}] " + lib.cp_last_error(None).decode())
+        return out
+
+    def ext_challenge(self):
+        return self.challenges(2)
+
+    def copy(self):
+        c = ChallengerState()
+        ctypes.memmove(ctypes.byref(c), ctypes.byref(self), ctypes.sizeof(ChallengerState))
+        return c
+
+    def as_tuple(self):
+        return (tuple(self.sponge_state), tuple(self.input_buffer[:self.n_input]), tuple(self.output_buffer[:self.n_output]))
+
+
+class FriParams(ctypes.Structure):
+    """cp_fri_params (plonky2 FriParams)."""
+    _fields_ = [(n, ctypes.c_int) for n in ("degree_bits", "rate_bits", "cap_height", "pow_bits", "num_query_rounds", "n_arity")] + [
+        ("arity_bits", ctypes.c_int * 8)]
+
+
+def fri_params(degree_bits, rate_bits, cap_height, pow_bits, num_query_rounds, arity_bits):
+    p = FriParams(degree_bits, rate_bits, cap_height, pow_bits, num_query_rounds, len(arity_bits))
+    for i, a in enumerate(arity_bits):
+        p.arity_bits[i] = a
+    return p
+
+
+class FriPolyRange(ctypes.Structure):
+    _fields_ = [("oracle", ctypes.c_uint32), ("first", ctypes.c_uint32), ("count", ctypes.c_uint32)]
+
+
+class FriBatch(ctypes.Structure):
+    """cp_fri_batch (plonky2 FriBatchInfo with the polynomial list as runs)."""
+    _fields_ = [("point", ctypes.c_uint64 * 2), ("ranges", ctypes.POINTER(FriPolyRange)), ("n_ranges", ctypes.c_size_t)]
+
+
+class FriOracleInfo(ctypes.Structure):
+    _fields_ = [("num_polys", ctypes.c_uint32), ("blinding", ctypes.c_uint32)]
+
+
+def _fri_batches(batches):
+    """[(point (2,), [(oracle, first, count), ...]), ...] -> (ctypes array of FriBatch, keep-alive list)"""
+    arr = (FriBatch * len(batches))()
+    keep = []
+    for i, (pt, ranges) in enumerate(batches):
+        rr = (FriPolyRange * max(1, len(ranges)))()
+        for j, (o, f, c) in enumerate(ranges):
+            rr[j] = FriPolyRange(o, f, c)
+        keep.append(rr)
+        arr[i].point[0], arr[i].point[1] = int(pt[0]), int(pt[1])
+        arr[i].ranges = ctypes.cast(rr, ctypes.POINTER(FriPolyRange))
+        arr[i].n_ranges = len(ranges)
+    return arr, keep
+
+
+BATCH_FROM_COEFFS = 1
+_u8pp = ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8))
+ABI.update({
+    "cp_batch_commit": (ctypes.c_int, [_vp, _u64p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, _u64p,
+                                       ctypes.POINTER(_vp)]),
+    "cp_batch_commit_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, _vp,
+                                           ctypes.POINTER(_vp)]),
+    "cp_batch_destroy": (None, [_vp]),
+    "cp_batch_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_size_t)] + [ctypes.POINTER(ctypes.c_int)] * 4),
+    "cp_batch_cap": (ctypes.c_int, [_vp, _u64p]),
+    "cp_batch_eval_ext": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, _u64p, _u64p]),
+    "cp_batch_lde_rows": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, _u64p]),
+    "cp_batch_device_ptrs": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "cp_fri_prove": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_size_t, ctypes.POINTER(FriBatch), ctypes.c_size_t,
+                                    ctypes.POINTER(FriParams), ctypes.POINTER(ChallengerState), ctypes.c_int, ctypes.c_uint64,
+                                    _u8pp, ctypes.POINTER(ctypes.c_size_t)]),
+    "cp_fri_verify": (ctypes.c_int, [ctypes.POINTER(FriParams), ctypes.POINTER(FriOracleInfo), ctypes.c_size_t,
+                                     ctypes.POINTER(_u64p), ctypes.POINTER(FriBatch), ctypes.c_size_t, ctypes.POINTER(_u64p),
+                                     ctypes.POINTER(ChallengerState), ctypes.c_char_p, ctypes.c_size_t]),
+    "cp_challenger_observe": (ctypes.c_int, [ctypes.POINTER(ChallengerState), _u64p, ctypes.c_size_t]),
+    "cp_challenger_challenges": (ctypes.c_int, [ctypes.POINTER(ChallengerState), _u64p, ctypes.c_size_t]),
+})
+
+
+class PolyBatch:
+    """cp_poly_batch: plonky2 `PolynomialBatch` resident on the device (coefficients, bit-reversed LDE, Merkle tree)."""
+
+    def __init__(self, prover, polys, rate_bits, cap_height, from_coeffs=False, salts=None, device_ptr=None, shape=None):
+        self.prover = prover
+        h = _vp()
+        flags = BATCH_FROM_COEFFS if from_coeffs else 0
+        if device_ptr is not None:
+            k, n = shape
+            sp = None if salts is None else salts
+            prover._check(prover.lib.cp_batch_commit_dev(prover.ctx, device_ptr, k, int(n).bit_length() - 1, rate_bits, cap_height,
+                                                         flags, sp, ctypes.byref(h)))
+        else:
+            v = _as_u64(polys)
+            k, n = v.shape
+            s = None if salts is None else _as_u64(salts)
+            prover._check(prover.lib.cp_batch_commit(prover.ctx, _ptr(v), k, int(n).bit_length() - 1, rate_bits, cap_height, flags,
+                                                     None if s is None else _ptr(s), ctypes.byref(h)))
+        self.handle = h.value
+        self.k, self.degree_bits, self.rate_bits, self.cap_height = k, int(n).bit_length() - 1, rate_bits, cap_height
+        self.blinding = salts is not None
+
+    def cap(self):
+        cap = np.zeros((1 << self.cap_height, 4), np.uint64)
+        self.prover._check(self.prover.lib.cp_batch_cap(self.handle, _ptr(cap)))
+        return cap
+
+    def eval_ext(self, point, first=0, count=None):
+        count = self.k - first if count is None else count
+        out = np.zeros((count, 2), np.uint64)
+        pt = _as_u64(point)
+        self.prover._check(self.prover.lib.cp_batch_eval_ext(self.handle, first, count, _ptr(pt), _ptr(out)))
+        return out
+
+    def lde_rows(self, first_index, count, step=1):
+        out = np.zeros((count, self.k), np.uint64)
+        self.prover._check(self.prover.lib.cp_batch_lde_rows(self.handle, first_index, count, step, _ptr(out)))
+        return out
+
+    def device_ptrs(self):
+        c, l = _vp(), _vp()
+        self.prover._check(self.prover.lib.cp_batch_device_ptrs(self.handle, ctypes.byref(c), ctypes.byref(l)))
+        return c.value, l.value
+
+    def close(self):
+        if self.handle:
+            self.prover.lib.cp_batch_destroy(self.handle)
+            self.handle = None
+
+
+def fri_prove(prover, oracles, batches, params, challenger, pow_override=None):
+    """cp_fri_prove: `PolynomialBatch::prove_openings`. oracles: [PolyBatch]; batches: [(point, [(oracle, first, count)])];
+    challenger: ChallengerState (advanced in place). Returns bincode FriProof bytes."""
+    hs = (_vp * len(oracles))(*[o.handle for o in oracles])
+    arr, keep = _fri_batches(batches)
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    ln = ctypes.c_size_t()
+    prover._check(prover.lib.cp_fri_prove(prover.ctx, hs, len(oracles), arr, len(batches), ctypes.byref(params), ctypes.byref(challenger),
+                                          0 if pow_override is None else 1, pow_override or 0, ctypes.byref(out), ctypes.byref(ln)))
+    try:
+        return ctypes.string_at(out, ln.value)
+    finally:
+        prover.lib.cp_free(out)
+
+
+def fri_verify(params, oracle_infos, caps, batches, opened_values, challenger, proof_bytes):
+    """cp_fri_verify: `fri_challenges` + `verify_fri_proof`. oracle_infos: [(num_polys, blinding)]; caps: [array (2^cap_height, 4)];
+    opened_values: per batch an (n_polys, 2) array. Raises CityProverError on rejection; advances `challenger` on success."""
+    lib = load_library()
+    infos = (FriOracleInfo * len(oracle_infos))(*[FriOracleInfo(int(k), int(bool(b))) for k, b in oracle_infos])
+    cap_arrs = [_as_u64(c) for c in caps]
+    capp = (_u64p * len(cap_arrs))(*[_ptr(c) for c in cap_arrs])
+    arr, keep = _fri_batches(batches)
+    ov = [_as_u64(o) for o in opened_values]
+    ovp = (_u64p * len(ov))(*[_ptr(o) if o.size else None for o in ov])
+    rc = lib.cp_fri_verify(ctypes.byref(params), infos, len(oracle_infos), capp, arr, len(batches), ovp, ctypes.byref(challenger),
+                           proof_bytes, len(proof_bytes))
+    if rc != 0:
+        raise CityProverError(f"[{rc}] " + lib.cp_last_error(None).decode())

@@ -800,5 +800,6 @@ int cp_commit_dev(cp_ctx *ctx, const uint64_t *values, size_t k, int log_n, int 
 #include "prover_tail.inc"
 #include "batcher.inc"
 #include "verify.inc"
+#include "fri_prove.inc"
 #include "circuit_file.inc"
 // (the BLS12-381 / Groth16 side is its own translation unit: bls.hip)

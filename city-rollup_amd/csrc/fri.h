@@ -67,27 +67,36 @@ __global__ __launch_bounds__(256) void k_eval_at_point(const uint64_t *__restric
   if (threadIdx.x == 0) out[proof * out_stride + out_off + blockIdx.x] = r;
 }
 
+// Oracles of a FRI instance as the kernels see them: oracle o of proof p is at base[o] + p*stride[o], or, when
+// table[o] is set, at table[o][p] (the constants/sigmas oracle of a plonky2 proof belongs to the circuit, so proofs of
+// different circuits reach it through a per-proof pointer table).
+constexpr int MAX_ORACLES = 8;   // plonky2: 4 (constants+sigmas, wires, Z/partial products, quotient); a STARK: trace rounds + quotient
+constexpr int MAX_RANGES = 16;   // polynomial ranges of one opening batch per k_combine launch (longer lists: several launches)
+
 struct BatchRefs {
-  const uint64_t *const *table0;  // per-proof pointer to oracle 0 (constants+sigmas) coefficients
-  const uint64_t *base[4];        // oracles 1..3: base[b] + proof*proof_stride[b]
-  size_t proof_stride[4];
-  int k[4];                       // polynomials taken from each oracle, in order
+  const uint64_t *base[MAX_ORACLES];           // coefficient arrays, polynomial j of oracle o at + j*n
+  size_t proof_stride[MAX_ORACLES];
+  const uint64_t *const *table[MAX_ORACLES];   // per-proof pointer table (device) or null
+  int n_ranges;
+  int r_oracle[MAX_RANGES], r_first[MAX_RANGES], r_count[MAX_RANGES];  // FriBatchInfo::polynomials as (oracle, first, count) runs
   size_t n;
 };
 
-// comp[proof][c] = sum_{listed polynomials p, in order} apow[proof][idx(p)] * f_p[c].   grid = (n/256, B)
-__global__ __launch_bounds__(256) void k_combine(BatchRefs refs, const Ext *__restrict__ apow, size_t apow_stride,
-                                                 Ext *__restrict__ comp) {
+// comp[proof][c] (+)= sum_{listed polynomials p, in order} apow[proof][apow_off + idx(p)] * f_p[c].   grid = (n/256, B)
+// (plonky2 `ReducingFactor::reduce_polys_base` over one FriBatchInfo)
+__global__ __launch_bounds__(256) void k_combine(BatchRefs refs, const Ext *__restrict__ apow, size_t apow_stride, size_t apow_off,
+                                                 int accumulate, Ext *__restrict__ comp) {
   size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= refs.n) return;
   const size_t proof = blockIdx.y;
-  const Ext *ap = apow + proof * apow_stride;
+  const Ext *ap = apow + proof * apow_stride + apow_off;
   Ext acc{0, 0};
+  if (accumulate) acc = comp[proof * refs.n + c];
   int idx = 0;
-  for (int b = 0; b < 4; b++) {
-    if (!refs.k[b]) continue;
-    const uint64_t *f = (b == 0 ? refs.table0[proof] : refs.base[b] + proof * refs.proof_stride[b]) + c;
-    for (int p = 0; p < refs.k[b]; p++, idx++) {
+  for (int r = 0; r < refs.n_ranges; r++) {
+    const int o = refs.r_oracle[r];
+    const uint64_t *f = (refs.table[o] ? refs.table[o][proof] : refs.base[o] + proof * refs.proof_stride[o]) + (size_t)refs.r_first[r] * refs.n + c;
+    for (int p = 0; p < refs.r_count[r]; p++, idx++) {
       uint64_t v = f[(size_t)p * refs.n];
       Ext a = ap[idx];
       acc.a = gl::add(acc.a, gl::mul(v, a.a));
@@ -251,15 +260,16 @@ __global__ __launch_bounds__(256) void k_pow_grind(const PowState *__restrict__ 
 
 // Query gathering: one workgroup per (query round, proof); writes the bincode words of a FriQueryRound.
 struct QueryRefs {
-  const uint64_t *const *lde0;      // oracle 0 per-proof pointer tables
-  const uint64_t *const *digests0;
-  const uint64_t *lde[4];           // oracles 1..3: + proof*lde_stride[b]
-  const uint64_t *digests[4];       //               + proof*dig_stride[b]
-  size_t lde_stride[4], dig_stride[4];
-  int k[4];
-  const uint64_t *salt[4];          // zero-knowledge: n_salt[b] extra leaf elements per oracle ([proof][n_salt][N]), else null
-  size_t salt_stride[4];
-  int n_salt[4];
+  int n_oracles;
+  const uint64_t *lde[MAX_ORACLES];           // oracle o of proof p: lde[o] + p*lde_stride[o], or lde_table[o][p]
+  const uint64_t *digests[MAX_ORACLES];       //                      digests[o] + p*dig_stride[o], or dig_table[o][p]
+  const uint64_t *const *lde_table[MAX_ORACLES];
+  const uint64_t *const *dig_table[MAX_ORACLES];
+  size_t lde_stride[MAX_ORACLES], dig_stride[MAX_ORACLES];
+  int k[MAX_ORACLES];
+  const uint64_t *salt[MAX_ORACLES];          // blinded oracle: n_salt[o] extra leaf elements ([proof][n_salt][N]), else null
+  size_t salt_stride[MAX_ORACLES];
+  int n_salt[MAX_ORACLES];
   size_t N;
   int depth0;                       // log2(N) - cap_height
   int n_layers;
@@ -290,11 +300,11 @@ __global__ __launch_bounds__(256) void k_gather_queries(QueryRefs r, const uint6
   uint64_t *o = out + (proof * r.n_queries + blockIdx.x) * r.words_per_query;
   const size_t x = (size_t)indices[proof * r.n_queries + blockIdx.x];
   size_t w = 0;
-  if (threadIdx.x == 0) o[w] = 4;
+  if (threadIdx.x == 0) o[w] = (uint64_t)r.n_oracles;
   w += 1;
-  for (int b = 0; b < 4; b++) {
-    const uint64_t *lde = b == 0 ? r.lde0[proof] : r.lde[b] + proof * r.lde_stride[b];
-    const uint64_t *dig = b == 0 ? r.digests0[proof] : r.digests[b] + proof * r.dig_stride[b];
+  for (int b = 0; b < r.n_oracles; b++) {
+    const uint64_t *lde = r.lde_table[b] ? r.lde_table[b][proof] : r.lde[b] + proof * r.lde_stride[b];
+    const uint64_t *dig = r.dig_table[b] ? r.dig_table[b][proof] : r.digests[b] + proof * r.dig_stride[b];
     const int ns = r.salt[b] ? r.n_salt[b] : 0;
     if (threadIdx.x == 0) o[w] = (uint64_t)(r.k[b] + ns);   // the whole leaf: values, then the salt
     w += 1;

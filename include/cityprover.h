@@ -13,7 +13,8 @@
  * commitments); circuits (cp_circuit_load, cp_circuit_set_gates); proving (cp_prove, cp_prove_batch{,_host},
  * cp_prove_batch_zk_host, cp_prove_tail*, cp_zs_partial_products_dev) and cp_verify; and, for the Groth16 wrap
  * (SURVEY.md §8(a) A12), the BLS12-381 G1 / G2 multi-scalar multiplications (cp_msm_bls12381_*) and the scalar-field NTT
- * (cp_ntt_bls12381_fr*).
+ * (cp_ntt_bls12381_fr*); and the generic polynomial-commitment seams under all of it — cp_batch_* (`PolynomialBatch`) and
+ * cp_fri_prove / cp_fri_verify (`prove_openings` / `verify_fri_proof` over arbitrary oracles and opening batches).
  *
  * Conventions
  *  - every plonky2 field element is a canonical Goldilocks u64 (little-endian on the wire), p = 2^64-2^32+1;
@@ -41,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CP_ABI_VERSION 2
+#define CP_ABI_VERSION 3
 
 typedef enum cp_status {
   CP_OK = 0,
@@ -407,6 +408,96 @@ int cp_fri_combine_dev(cp_ctx *ctx, const uint64_t *polys_dev, size_t k, size_t 
                        uint64_t *comp_dev);
 int cp_fri_fold_dev(cp_ctx *ctx, const uint64_t *coeffs_dev, size_t n_in, int arity_bits, const uint64_t beta[2],
                     uint64_t *out_dev);
+
+/* ---- the two plonky2-level seams every FRI-based prover goes through -----------
+ * `CircuitData::prove` is one client of plonky2's polynomial commitment; the SHA-256 STARK the sighash circuit proves
+ * three times per block is another: starkyx `ByteStark::prove` (city_common_circuit/src/hash/accelerator/sha256/
+ * smartgadget.rs:518-524, called from city_rollup_circuit/src/sighash_circuits/sighash.rs:132-146) is built on plonky2's
+ * own config and FRI (`plonky2::{stark::config::GenericCombinedConfig, Plonky2Air}`, smartgadget.rs:48-49): it commits
+ * its 418 + 912 trace columns (smartgadget.rs:55-79) with `PolynomialBatch::from_values` and opens them with
+ * `PolynomialBatch::prove_openings`. These entry points are those two functions with the data resident on the device;
+ * cp_prove itself runs on the same code (csrc/fri_engine.inc). The AIR (constraint evaluation) stays with the caller.
+ *
+ * cp_poly_batch = plonky2 `PolynomialBatch`: k polynomials of degree < n = 2^degree_bits in coefficient form, their
+ * rate-2^rate_bits LDE on the coset 7<omega_N> in bit-reversed order, and the Merkle tree over the LDE rows (leaf i =
+ * the k values at bit-reversed position i, followed by the salt when blinding) with its 2^cap_height-entry cap.
+ * Owned by the caller (cp_batch_destroy); bound to the context that made it. */
+typedef struct cp_poly_batch cp_poly_batch;
+#define CP_BATCH_FROM_COEFFS 1u /* polys are coefficients (PolynomialBatch::from_coeffs), not values over <omega_n> */
+/* polys_host: k x n, polynomial-major. salts_host: NULL = blinding off; else CP_SALT_SIZE x N uniformly random canonical
+ * elements indexed by leaf (plonky2 draws them inside from_values(.., blinding = true, ..); here the caller's RNG does). */
+int cp_batch_commit(cp_ctx *ctx, const uint64_t *polys_host, size_t k, int degree_bits, int rate_bits, int cap_height,
+                    unsigned flags, const uint64_t *salts_host, cp_poly_batch **batch_out);
+/* the same from device memory (polys_dev: k x n; salts_dev: CP_SALT_SIZE x N or NULL); the inputs are not retained */
+int cp_batch_commit_dev(cp_ctx *ctx, const uint64_t *polys_dev, size_t k, int degree_bits, int rate_bits, int cap_height,
+                        unsigned flags, const uint64_t *salts_dev, cp_poly_batch **batch_out);
+void cp_batch_destroy(cp_poly_batch *batch);
+/* any out pointer may be NULL; n_salt_out: CP_SALT_SIZE for a blinded batch, else 0 */
+int cp_batch_info(const cp_poly_batch *batch, size_t *k_out, int *degree_bits_out, int *rate_bits_out, int *cap_height_out,
+                  int *n_salt_out);
+/* `merkle_tree.cap`: 2^cap_height x 4 */
+int cp_batch_cap(cp_poly_batch *batch, uint64_t *cap_out_host);
+/* out[j] = polynomials[first + j].to_extension().eval(point), j < count (what `OpeningSet::new` / starky's
+ * `StarkOpeningSet::new` compute from a commitment); point, out: F_p^2 elements as 2 u64 */
+int cp_batch_eval_ext(cp_poly_batch *batch, size_t first, size_t count, const uint64_t point[2], uint64_t *out_host);
+/* `PolynomialBatch::get_lde_values(index * step, ..)` for `count` consecutive indices: row r of out_host
+ * (count x k, row-major) = the k LDE values at NATURAL position (first_index + r) * step of the coset (salt excluded) —
+ * what a CPU constraint evaluator reads while it builds the quotient. */
+int cp_batch_lde_rows(cp_poly_batch *batch, size_t first_index, size_t count, size_t step, uint64_t *out_host);
+/* device views for callers that evaluate their constraints on the device: coefficient array (k x n) and bit-reversed
+ * LDE (k x N), polynomial-major, valid until cp_batch_destroy */
+int cp_batch_device_ptrs(cp_poly_batch *batch, const uint64_t **coeffs_dev_out, const uint64_t **lde_dev_out);
+
+/* plonky2 `Challenger<F, PoseidonHash>` by value: the duplex sponge state, the elements observed since the last
+ * permutation (input_buffer, n_input <= 8) and the squeezed elements not yet handed out (output_buffer; challenges are
+ * popped from its END, n_output <= 8). Crosses the ABI in both directions so that the caller's transcript continues
+ * exactly where plonky2's would. */
+typedef struct cp_challenger_state {
+  uint64_t sponge_state[12];
+  uint64_t input_buffer[8];
+  uint64_t output_buffer[8];
+  uint32_t n_input, n_output;
+} cp_challenger_state;
+/* plonky2 `FriParams` (config.rate_bits, config.cap_height, config.proof_of_work_bits, config.num_query_rounds,
+ * degree_bits, reduction_arity_bits; `hiding` is carried by the batches / cp_fri_oracle_info::blinding) */
+typedef struct cp_fri_params {
+  int degree_bits, rate_bits, cap_height, pow_bits, num_query_rounds;
+  int n_arity;
+  int arity_bits[8];
+} cp_fri_params;
+/* `FriBatchInfo { point, polynomials }` with the polynomial list as runs: polynomials first .. first+count-1 of oracle
+ * `oracle`, in list order (a FriPolynomialInfo list is the concatenation of its runs) */
+typedef struct cp_fri_poly_range { uint32_t oracle, first, count; } cp_fri_poly_range;
+typedef struct cp_fri_batch {
+  uint64_t point[2];
+  const cp_fri_poly_range *ranges;
+  size_t n_ranges;
+} cp_fri_batch;
+/* `PolynomialBatch::prove_openings(instance, oracles, challenger, fri_params, timing) -> FriProof`.
+ * oracles: n_oracles (<= 8) batches of one degree, rate and cap height — `FriInstanceInfo::oracles`; batches:
+ * `FriInstanceInfo::batches`. The caller has observed the opened values already (plonky2 `observe_openings`); this
+ * draws alpha, commits the folded layers (observing each cap, drawing each beta), observes the final polynomial, grinds
+ * the proof of work (the SMALLEST witness whose response has pow_bits leading zeros, unless use_pow_override) and
+ * draws the query indices — `challenger` comes back in the state plonky2's would be in. fri_proof_out: bincode
+ * `FriProof { commit_phase_merkle_caps, query_round_proofs, final_poly, pow_witness }` (malloc'd; cp_free). */
+int cp_fri_prove(cp_ctx *ctx, cp_poly_batch *const *oracles, size_t n_oracles, const cp_fri_batch *batches, size_t n_batches,
+                 const cp_fri_params *params, cp_challenger_state *challenger, int use_pow_override, uint64_t pow_override,
+                 uint8_t **fri_proof_out, size_t *fri_proof_len);
+/* The verifier side (plonky2 `Challenger::fri_challenges` + `verify_fri_proof`; starkyx verifies the proof it has just
+ * made natively, smartgadget.rs:524): from the oracle caps, the opened values of every batch (opened_values[b]: n_polys
+ * of batch b x 2 u64, in list order — `FriOpenings`), the challenger state after `observe_openings` and the FriProof
+ * bytes. Checks the proof shape, the proof of work, and for every query round the Merkle paths of the initial oracles,
+ * fri_combine_initial, the fold chain with its layer paths and the final polynomial. Host arithmetic only: needs no
+ * context and no GPU. 0 = accepted; CP_ERR_VERIFY with cp_last_error(NULL) naming the first failing check. */
+typedef struct cp_fri_oracle_info { uint32_t num_polys, blinding; } cp_fri_oracle_info;
+int cp_fri_verify(const cp_fri_params *params, const cp_fri_oracle_info *oracles, size_t n_oracles,
+                  const uint64_t *const *oracle_caps, const cp_fri_batch *batches, size_t n_batches,
+                  const uint64_t *const *opened_values, cp_challenger_state *challenger, const uint8_t *fri_proof,
+                  size_t fri_proof_len);
+/* Transcript helpers with plonky2's semantics (observe_elements / get_n_challenges), for hosts that keep the challenger
+ * in this form between calls (tests, the C++ harness); a Rust caller converts its own `Challenger` instead. */
+int cp_challenger_observe(cp_challenger_state *challenger, const uint64_t *elements, size_t count);
+int cp_challenger_challenges(cp_challenger_state *challenger, uint64_t *out, size_t count);
 
 /* ---- BLS12-381 G1 multi-scalar multiplication ---------------------------------
  * The G1 MSMs of the Groth16 wrap proof: replaces the CPU MSM inside `gnark_plonky2_wrapper::wrap_plonky2_proof`

@@ -137,6 +137,30 @@ void or_fri_compute_evaluation(uint64_t x, size_t x_index_within_coset, int arit
 uint64_t or_fri_query_point(size_t x_index, int log_n);
 void or_free(void *p);
 
+/* ---- the generic seams under the whole-proof functions (plonky2_tail.c): plonky2 `PolynomialBatch` (from_values /
+ * from_coeffs, optional salt = OR_SALT_SIZE x N leaf-ordered elements), `PolynomialBatch::prove_openings` over any
+ * oracles and opening batches, `verify_fri_proof`. Checker of cp_batch_* / cp_fri_prove / cp_fri_verify. ---- */
+typedef struct or_batch or_batch;
+or_batch *or_batch_commit(const uint64_t *polys, size_t k, int log_n, int rate_bits, int cap_height, int from_coeffs,
+                          const uint64_t *salt);
+void or_batch_free(or_batch *b);
+const uint64_t *or_batch_cap(const or_batch *b);
+const uint64_t *or_batch_coeffs(const or_batch *b);
+const uint64_t *or_batch_lde(const or_batch *b);
+void or_batch_eval_ext(const or_batch *b, size_t first, size_t count, const uint64_t point[2], uint64_t *out);
+void or_batch_lde_rows(const or_batch *b, size_t first_index, size_t count, size_t step, uint64_t *out);
+typedef struct { int degree_bits, rate_bits, cap_height, pow_bits, num_query_rounds, n_arity; int arity_bits[8]; } or_fri_params;
+typedef struct { uint32_t oracle, first, count; } or_fri_range;
+typedef struct { uint64_t point[2]; const or_fri_range *ranges; size_t n_ranges; } or_fri_batch;
+/* c: the transcript after the openings were observed; advanced as plonky2's would be. out: bincode FriProof (or_free). */
+int or_fri_prove(const or_batch *const *oracles, size_t n_oracles, const or_fri_batch *batches, size_t n_batches,
+                 const or_fri_params *params, or_challenger *c, int use_pow_override, uint64_t pow_override,
+                 uint8_t **out, size_t *len, or_tail_debug *dbg);
+/* opened[b]: the claimed values of batch b (n_polys x 2 u64, list order). 0 = accepted (c advanced), else the failing check. */
+int or_fri_verify(const or_fri_params *params, const uint32_t *num_polys, const uint32_t *blinding, size_t n_oracles,
+                  const uint64_t *const *caps, const or_fri_batch *batches, size_t n_batches, const uint64_t *const *opened,
+                  or_challenger *c, const uint8_t *proof, size_t len, or_tail_debug *dbg);
+
 /* ---- gates / quotient (plonky2_quotient.c) ---- */
 enum { OR_GATE_NOOP = 0, OR_GATE_CONSTANT = 1, OR_GATE_PUBLIC_INPUT = 2, OR_GATE_ARITHMETIC = 3, OR_GATE_POSEIDON = 4,
        OR_GATE_COMPARISON = 5, OR_GATE_U32_ARITHMETIC = 6, OR_GATE_U32_RANGE_CHECK = 7,

@@ -7,10 +7,18 @@
  * bincode serialisation of ProofWithPublicInputs, and the matching verifier side for the FRI part.
  * plonky2 is an un-vendored dependency (QEDProtocol/plonky2-hwa @ 6a8ca008, Cargo.lock:4174-4223):
  * the algorithm is restated from its published definition (SURVEY.md §3.3 steps 3-4, 6, 8-11,
- * Appendix B). What the reference tree pins: the proof shape and byte layout, Merkle paths, the FRI
- * leaf layout and the FRI fold / final-polynomial relation of the 3 reference proofs in
- * tests/golden (tests/test_oracle_fri_reference.py). Transcript order and the batching order of the
- * opened polynomials are NOT pinned by reference data ("parity unpinned" for those two facts).
+ * Appendix B). What the reference tree pins, on ALL TEN reference proofs of qbench_data/example.bin
+ * (tests/golden/qbench_example.bin): the proof shape and byte layout, every Merkle path, the FRI leaf
+ * layout, the FRI fold / final-polynomial relation (tests/test_oracle_fri_reference.py) and
+ * fri_combine_initial — i.e. the order of the opened polynomials inside each batch, the alpha-power /
+ * shift convention of ReducingFactor and the g*zeta point (tests/test_oracle_fri_combine_reference.py,
+ * challenges recovered from the proof bytes by algebra). NOT pinned by reference data: the transcript
+ * order (which values are observed when; no circuit digest comes with the fixture proofs) — "parity
+ * unpinned" for that fact.
+ *
+ * The FRI part is generic (or_fri_prove / or_fri_verify over any oracles and opening batches, plonky2
+ * `PolynomialBatch::prove_openings` / `verify_fri_proof`): the whole-proof functions below are one
+ * client, the STARK-shaped tests (tests/test_gpu_fri_generic.py) another.
  */
 #define _POSIX_C_SOURCE 200809L
 #include "cityoracle.h"
@@ -55,9 +63,20 @@ static gl2_t ch_ext(or_challenger *c) {
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* byte buffer (bincode 1.3 default: LE, u64 length prefixes) */
+
+typedef struct { uint8_t *p; size_t len, cap; } buf_t;
+static void buf_put(buf_t *b, const void *src, size_t n) {
+  if (b->len + n > b->cap) { b->cap = (b->len + n) * 2 + 1024; b->p = (uint8_t *)realloc(b->p, b->cap); }
+  memcpy(b->p + b->len, src, n); b->len += n;
+}
+static void buf_u64(buf_t *b, uint64_t v) { buf_put(b, &v, 8); }
+static void buf_felts(buf_t *b, const uint64_t *v, size_t n) { buf_put(b, v, 8 * n); }
+
+/* ------------------------------------------------------------------------------------------ */
 /* polynomial batches */
 
-typedef struct {
+typedef struct or_batch {
   size_t k;      /* polynomials */
   size_t n_salt; /* extra leaf elements after the k polynomial values (zero-knowledge: OR_SALT_SIZE, else 0) */
   int log_n, rate_bits, cap_height;
@@ -66,6 +85,11 @@ typedef struct {
   uint64_t *digests; /* levels below the cap */
   uint64_t *cap;     /* 2^cap_height x 4 */
 } batch_t;
+
+/* FriParams without the circuit around it */
+typedef struct { int db, rb, ch, pow_bits, nq, n_arity; int arity_bits[8]; } fri_cfg_t;
+static int fri_prove_core(const batch_t *const *B, size_t n_oracles, const or_fri_batch *batches, size_t n_batches, const fri_cfg_t *cfg,
+                          or_challenger *c, int use_pow_override, uint64_t pow_override, buf_t *out, or_tail_debug *dbg);
 
 static size_t digest_nodes(size_t n_leaves, int cap_height) {
   size_t cap_n = (size_t)1 << cap_height;
@@ -114,17 +138,6 @@ static void merkle_path(const uint64_t *digests, size_t n_leaves, int cap_height
   }
 }
 static int log2z(size_t x) { int l = 0; while (((size_t)1 << l) < x) l++; return l; }
-
-/* ------------------------------------------------------------------------------------------ */
-/* byte buffer (bincode 1.3 default: LE, u64 length prefixes) */
-
-typedef struct { uint8_t *p; size_t len, cap; } buf_t;
-static void buf_put(buf_t *b, const void *src, size_t n) {
-  if (b->len + n > b->cap) { b->cap = (b->len + n) * 2 + 1024; b->p = (uint8_t *)realloc(b->p, b->cap); }
-  memcpy(b->p + b->len, src, n); b->len += n;
-}
-static void buf_u64(buf_t *b, uint64_t v) { buf_put(b, &v, 8); }
-static void buf_felts(buf_t *b, const uint64_t *v, size_t n) { buf_put(b, v, 8 * n); }
 
 /* ------------------------------------------------------------------------------------------ */
 /* polynomial helpers */
@@ -273,30 +286,77 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
   for (size_t i = 0; i < k_all; i++) or_ch_observe(&c, open[i].c, 2);
   for (int i = 0; i < sh->num_challenges; i++) or_ch_observe(&c, open_next[i].c, 2);
 
-  PHASE("fri batch poly");
-  /* ---- FRI batch polynomial: final = alpha^(#batch1) * Q0 + Q1 ---- */
+  PHASE("fri");
+  /* ---- the FRI opening proof: plonky2 `fri_instance` = everything at zeta, the Z polynomials at g*zeta ---- */
+  buf_t fri = {0};
+  {
+    const batch_t *oracles[4] = {&B[0], &B[1], &B[2], &B[3]};
+    or_fri_range r0[4] = {{0, 0, (uint32_t)k_cs}, {1, 0, (uint32_t)k_w}, {2, 0, (uint32_t)k_z}, {3, 0, (uint32_t)k_q}};
+    or_fri_range r1[1] = {{2, 0, (uint32_t)sh->num_challenges}};
+    or_fri_batch fb[2] = {{{zeta.c[0], zeta.c[1]}, r0, 4}, {{zeta_next.c[0], zeta_next.c[1]}, r1, 1}};
+    fri_cfg_t cfg = {db, rb, ch, sh->pow_bits, sh->num_query_rounds, sh->n_arity, {0}};
+    for (int l = 0; l < 8; l++) cfg.arity_bits[l] = sh->arity_bits[l];
+    int frc = fri_prove_core(oracles, 4, fb, 2, &cfg, &c, use_pow_override, pow_override, &fri, dbg);
+    if (frc) return frc;
+  }
+
+  PHASE("serialise");
+  /* ---- serialise ---- */
+  buf_t out = {0};
+  for (int b = 1; b <= 3; b++) { buf_u64(&out, cap_n); buf_felts(&out, B[b].cap, cap_n * 4); }
+  {
+    size_t o = 0;
+    /* constants, plonk_sigmas */
+    buf_u64(&out, sh->num_constants); buf_put(&out, open + o, (size_t)sh->num_constants * 16); o += sh->num_constants;
+    buf_u64(&out, sh->num_routed_wires); buf_put(&out, open + o, (size_t)sh->num_routed_wires * 16); o += sh->num_routed_wires;
+    buf_u64(&out, k_w); buf_put(&out, open + o, k_w * 16); o += k_w;
+    buf_u64(&out, sh->num_challenges); buf_put(&out, open + o, (size_t)sh->num_challenges * 16);
+    buf_u64(&out, sh->num_challenges); buf_put(&out, open_next, (size_t)sh->num_challenges * 16);
+    size_t npp = k_z - sh->num_challenges;
+    buf_u64(&out, npp); buf_put(&out, open + o + sh->num_challenges, npp * 16); o += k_z;
+    buf_u64(&out, k_q); buf_put(&out, open + o, k_q * 16);
+    buf_u64(&out, 0); buf_u64(&out, 0); /* lookup_zs, lookup_zs_next */
+  }
+  buf_put(&out, fri.p, fri.len); /* FriProof */
+  free(fri.p);
+  buf_u64(&out, n_pi); buf_felts(&out, public_inputs, n_pi);
+
+  *proof_out = out.p; *proof_len = out.len;
+  free(open); free(open_next);
+  for (int b = 0; b < 4; b++) batch_free(&B[b]);
+  return 0;
+}
+
+/* plonky2 `PolynomialBatch::prove_openings` + `fri_proof`: draws alpha, builds the batch polynomial
+ *   final = sum_b alpha^(counts of the later batches) * (F_b - F_b(z_b)) / (X - z_b),  F_b = sum_j alpha^j f_bj
+ * commits the folded layers, observes the final polynomial, grinds the proof of work (smallest witness), draws the query
+ * indices and writes bincode FriProof { commit_phase_merkle_caps, query_round_proofs, final_poly, pow_witness }. */
+static int fri_prove_core(const batch_t *const *B, size_t n_oracles, const or_fri_batch *batches, size_t n_batches, const fri_cfg_t *cfg,
+                          or_challenger *cp, int use_pow_override, uint64_t pow_override, buf_t *outp, or_tail_debug *dbg) {
+  const int db = cfg->db, rb = cfg->rb, ch = cfg->ch;
+  const size_t n = (size_t)1 << db, N = n << rb, cap_n = (size_t)1 << ch;
+  or_challenger c = *cp;
   gl2_t fri_alpha = ch_ext(&c);
   gl2_t *fin = (gl2_t *)calloc(N, sizeof(gl2_t)); /* LDE-padded coefficient vector */
-  for (int batch = 0; batch < 2; batch++) {
+  for (size_t batch = 0; batch < n_batches; batch++) {
     gl2_t *comp = (gl2_t *)calloc(n, sizeof(gl2_t));
     gl2_t ap = gl2_from_base(1);
     size_t cnt = 0;
-    for (int b = 0; b < 4; b++) {
-      size_t lo = 0, hi = B[b].k;
-      if (batch == 1) { if (b != 2) continue; hi = sh->num_challenges; }
-      for (size_t p = lo; p < hi; p++) {
-        const uint64_t *f = B[b].coeffs + p * n;
+    for (size_t r = 0; r < batches[batch].n_ranges; r++) {
+      const or_fri_range *R = &batches[batch].ranges[r];
+      for (size_t p = R->first; p < (size_t)R->first + R->count; p++) {
+        const uint64_t *f = B[R->oracle]->coeffs + p * n;
         for (size_t i = 0; i < n; i++) comp[i] = gl2_add(comp[i], gl2_scale(ap, f[i]));
         ap = gl2_mul(ap, fri_alpha);
         cnt++;
       }
     }
     /* divide_by_linear(point): q[i-1] = comp[i] + z*q[i] */
-    gl2_t z = batch == 0 ? zeta : zeta_next;
+    gl2_t z = gl2_make(batches[batch].point[0], batches[batch].point[1]);
     gl2_t *q = (gl2_t *)calloc(n, sizeof(gl2_t));
     gl2_t acc = gl2_from_base(0);
     for (size_t i = n; i-- > 1;) { acc = gl2_add(gl2_mul(acc, z), comp[i]); q[i - 1] = acc; }
-    /* final = final * alpha^cnt + q */
+    /* final = final * alpha^cnt + q   (ReducingFactor::shift_poly with the count of THIS batch) */
     gl2_t sh_f = gl2_pow(fri_alpha, cnt);
     for (size_t i = 0; i < n; i++) fin[i] = gl2_add(gl2_mul(fin[i], sh_f), q[i]);
     free(comp); free(q);
@@ -305,14 +365,13 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
   gl2_t *vals = (gl2_t *)malloc(N * sizeof(gl2_t));
   ext_coset_ntt(fin, db + rb, GL_GENERATOR, vals);
 
-  PHASE("fri commit");
   /* ---- commit phase ---- */
   fri_trees_t T; memset(&T, 0, sizeof T);
-  T.n_layers = sh->n_arity;
+  T.n_layers = cfg->n_arity;
   gl2_t *coeffs = fin; size_t clen = N; int clog = db + rb;
   uint64_t shift = GL_GENERATOR;
-  for (int l = 0; l < sh->n_arity; l++) {
-    int ab = sh->arity_bits[l]; size_t arity = (size_t)1 << ab;
+  for (int l = 0; l < cfg->n_arity; l++) {
+    int ab = cfg->arity_bits[l]; size_t arity = (size_t)1 << ab;
     size_t nl = clen >> ab;
     uint64_t *leaves = (uint64_t *)malloc(clen * 16);
     for (size_t i = 0; i < clen; i++) { /* position i of the bit-reversed value vector */
@@ -338,7 +397,6 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
   size_t final_len = clen >> rb;
   for (size_t i = 0; i < final_len; i++) or_ch_observe(&c, coeffs[i].c, 2);
 
-  PHASE("pow");
   /* ---- proof of work: smallest witness whose response has >= pow_bits leading zeros ---- */
   uint64_t pow_witness = 0;
   {
@@ -353,52 +411,37 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
         uint64_t t[12]; memcpy(t, st, sizeof t);
         t[pos] = base + (uint64_t)k;
         or_poseidon_permute(t);
-        if (pow_ok(t[7], sh->pow_bits) && base + (uint64_t)k < found) found = base + (uint64_t)k;
+        if (pow_ok(t[7], cfg->pow_bits) && base + (uint64_t)k < found) found = base + (uint64_t)k;
       }
       if (found != UINT64_MAX) { pow_witness = found; break; }
     }
     or_ch_observe(&c, &pow_witness, 1);
     uint64_t resp = or_ch_challenge(&c);
     if (dbg) dbg->pow_response = resp;
-    if (!use_pow_override && !pow_ok(resp, sh->pow_bits)) return -1;
+    if (!use_pow_override && !pow_ok(resp, cfg->pow_bits)) return -1;
   }
 
-  PHASE("queries+serialise");
-  /* ---- serialise ---- */
-  buf_t out = {0};
-  for (int b = 1; b <= 3; b++) { buf_u64(&out, cap_n); buf_felts(&out, B[b].cap, cap_n * 4); }
-  {
-    size_t o = 0;
-    /* constants, plonk_sigmas */
-    buf_u64(&out, sh->num_constants); buf_put(&out, open + o, (size_t)sh->num_constants * 16); o += sh->num_constants;
-    buf_u64(&out, sh->num_routed_wires); buf_put(&out, open + o, (size_t)sh->num_routed_wires * 16); o += sh->num_routed_wires;
-    buf_u64(&out, k_w); buf_put(&out, open + o, k_w * 16); o += k_w;
-    buf_u64(&out, sh->num_challenges); buf_put(&out, open + o, (size_t)sh->num_challenges * 16);
-    buf_u64(&out, sh->num_challenges); buf_put(&out, open_next, (size_t)sh->num_challenges * 16);
-    size_t npp = k_z - sh->num_challenges;
-    buf_u64(&out, npp); buf_put(&out, open + o + sh->num_challenges, npp * 16); o += k_z;
-    buf_u64(&out, k_q); buf_put(&out, open + o, k_q * 16);
-    buf_u64(&out, 0); buf_u64(&out, 0); /* lookup_zs, lookup_zs_next */
-  }
-  buf_u64(&out, sh->n_arity);
-  for (int l = 0; l < sh->n_arity; l++) { buf_u64(&out, cap_n); buf_felts(&out, T.cap[l], cap_n * 4); }
-  buf_u64(&out, sh->num_query_rounds);
+  /* ---- FriProof ---- */
+  buf_t out = *outp;
+  buf_u64(&out, cfg->n_arity);
+  for (int l = 0; l < cfg->n_arity; l++) { buf_u64(&out, cap_n); buf_felts(&out, T.cap[l], cap_n * 4); }
+  buf_u64(&out, cfg->nq);
   int depth0 = db + rb - ch;
   uint64_t sib[64 * 4];
-  for (int qi = 0; qi < sh->num_query_rounds; qi++) {
+  for (int qi = 0; qi < cfg->nq; qi++) {
     size_t x = (size_t)(or_ch_challenge(&c) % N);
     if (dbg && qi < 64) dbg->query_indices[qi] = x;
-    buf_u64(&out, 4);
-    for (int b = 0; b < 4; b++) {
-      buf_u64(&out, B[b].k + B[b].n_salt); /* the whole leaf, salt included */
-      for (size_t p = 0; p < B[b].k + B[b].n_salt; p++) buf_u64(&out, B[b].lde[p * N + x]);
-      merkle_path(B[b].digests, N, ch, x, sib);
+    buf_u64(&out, n_oracles);
+    for (size_t b = 0; b < n_oracles; b++) {
+      buf_u64(&out, B[b]->k + B[b]->n_salt); /* the whole leaf, salt included */
+      for (size_t p = 0; p < B[b]->k + B[b]->n_salt; p++) buf_u64(&out, B[b]->lde[p * N + x]);
+      merkle_path(B[b]->digests, N, ch, x, sib);
       buf_u64(&out, depth0); buf_felts(&out, sib, (size_t)depth0 * 4);
     }
-    buf_u64(&out, sh->n_arity);
+    buf_u64(&out, cfg->n_arity);
     size_t xi = x;
-    for (int l = 0; l < sh->n_arity; l++) {
-      int ab = sh->arity_bits[l]; size_t arity = (size_t)1 << ab;
+    for (int l = 0; l < cfg->n_arity; l++) {
+      int ab = cfg->arity_bits[l]; size_t arity = (size_t)1 << ab;
       xi >>= ab;
       buf_u64(&out, arity); buf_felts(&out, T.leaves[l] + xi * 2 * arity, 2 * arity);
       int depth = log2z(T.n_leaves[l]) - ch; if (depth < 0) depth = 0;
@@ -408,13 +451,53 @@ static int prove_impl(const or_shape *sh, const or_gates *G, const uint64_t circ
   }
   buf_u64(&out, final_len); buf_put(&out, coeffs, final_len * 16);
   buf_u64(&out, pow_witness);
-  buf_u64(&out, n_pi); buf_felts(&out, public_inputs, n_pi);
-
-  *proof_out = out.p; *proof_len = out.len;
-  for (int l = 0; l < sh->n_arity; l++) { free(T.leaves[l]); free(T.digests[l]); free(T.cap[l]); }
+  *outp = out;
+  *cp = c;
+  for (int l = 0; l < cfg->n_arity; l++) { free(T.leaves[l]); free(T.digests[l]); free(T.cap[l]); }
   if (coeffs != fin) free(coeffs);
-  free(fin); free(vals); free(open); free(open_next);
-  for (int b = 0; b < 4; b++) batch_free(&B[b]);
+  free(fin); free(vals);
+  return 0;
+}
+
+/* ---- the generic seams as entry points (plonky2 PolynomialBatch / prove_openings) ---- */
+or_batch *or_batch_commit(const uint64_t *polys, size_t k, int log_n, int rate_bits, int cap_height, int from_coeffs, const uint64_t *salt) {
+  batch_t *b = (batch_t *)calloc(1, sizeof(batch_t));
+  if (from_coeffs) batch_from_coeffs(b, polys, k, log_n, rate_bits, cap_height, salt);
+  else batch_from_values(b, polys, k, log_n, rate_bits, cap_height, salt);
+  return b;
+}
+void or_batch_free(or_batch *b) { if (b) { batch_free(b); free(b); } }
+const uint64_t *or_batch_cap(const or_batch *b) { return b->cap; }
+const uint64_t *or_batch_coeffs(const or_batch *b) { return b->coeffs; }
+const uint64_t *or_batch_lde(const or_batch *b) { return b->lde; }
+void or_batch_eval_ext(const or_batch *b, size_t first, size_t count, const uint64_t point[2], uint64_t *out) {
+  size_t n = (size_t)1 << b->log_n;
+  gl2_t z = gl2_make(point[0], point[1]);
+  for (size_t j = 0; j < count; j++) {
+    gl2_t v = eval_base_poly_ext(b->coeffs + (first + j) * n, n, z);
+    out[2 * j] = v.c[0]; out[2 * j + 1] = v.c[1];
+  }
+}
+/* PolynomialBatch::get_lde_values(index * step): the leaf at bit-reversed position = the values at NATURAL position */
+void or_batch_lde_rows(const or_batch *b, size_t first_index, size_t count, size_t step, uint64_t *out) {
+  int lb = b->log_n + b->rate_bits;
+  size_t N = (size_t)1 << lb;
+  for (size_t r = 0; r < count; r++) {
+    size_t pos = bitrev_sz(((first_index + r) * step) & (N - 1), lb);
+    for (size_t j = 0; j < b->k; j++) out[r * b->k + j] = b->lde[j * N + pos];
+  }
+}
+int or_fri_prove(const or_batch *const *oracles, size_t n_oracles, const or_fri_batch *batches, size_t n_batches,
+                 const or_fri_params *params, or_challenger *c, int use_pow_override, uint64_t pow_override,
+                 uint8_t **out, size_t *len, or_tail_debug *dbg) {
+  fri_cfg_t cfg = {params->degree_bits, params->rate_bits, params->cap_height, params->pow_bits, params->num_query_rounds, params->n_arity, {0}};
+  for (int l = 0; l < 8; l++) cfg.arity_bits[l] = params->arity_bits[l];
+  for (size_t o = 0; o < n_oracles; o++)
+    if (oracles[o]->log_n != cfg.db || oracles[o]->rate_bits != cfg.rb || oracles[o]->cap_height != cfg.ch) return -2;
+  buf_t b = {0};
+  int rc = fri_prove_core(oracles, n_oracles, batches, n_batches, &cfg, c, use_pow_override, pow_override, &b, dbg);
+  if (rc) { free(b.p); return rc; }
+  *out = b.p; *len = b.len;
   return 0;
 }
 
@@ -459,13 +542,138 @@ typedef struct { const uint8_t *p; size_t len, o; int bad; } rd_t;
 static uint64_t rd_u64(rd_t *r) { if (r->o + 8 > r->len) { r->bad = 1; return 0; } uint64_t v; memcpy(&v, r->p + r->o, 8); r->o += 8; return v; }
 static const uint64_t *rd_felts(rd_t *r, size_t n) { if (r->o + 8 * n > r->len) { r->bad = 1; return NULL; } const uint64_t *v = (const uint64_t *)(r->p + r->o); r->o += 8 * n; return v; }
 
+/* ---- generic FRI verifier: plonky2 `Challenger::fri_challenges` + `verify_fri_proof` ----
+ * kk[o] / leaf_len[o]: polynomials of oracle o / its leaf length (+ OR_SALT_SIZE when blinded); caps[o]: its cap;
+ * batches: the opening batches; opened[b]: the claimed values of batch b in list order (2 u64 each).
+ * Reads FriProof from r (leaves r->o behind the pow witness). 0 = accepted. */
+static int fri_verify_core(const fri_cfg_t *cfg, size_t n_oracles, const size_t *kk, const size_t *leaf_len, const uint64_t *const *caps,
+                           const or_fri_batch *batches, size_t n_batches, const uint64_t *const *opened, or_challenger *cp, rd_t *r,
+                           or_tail_debug *dbg) {
+  const int db = cfg->db, rb = cfg->rb, ch = cfg->ch;
+  const size_t n = (size_t)1 << db, N = n << rb, cap_n = (size_t)1 << ch;
+  (void)kk;
+  if (rd_u64(r) != (uint64_t)cfg->n_arity) return -4;
+  const uint64_t *fcap[8];
+  for (int l = 0; l < cfg->n_arity; l++) { if (rd_u64(r) != cap_n) return -4; fcap[l] = rd_felts(r, cap_n * 4); }
+  if (rd_u64(r) != (uint64_t)cfg->nq) return -5;
+  size_t q_off = r->o;
+  /* skip the queries to reach final poly / pow */
+  int depth0 = db + rb - ch;
+  for (int qi = 0; qi < cfg->nq; qi++) {
+    if (rd_u64(r) != n_oracles) return -6;
+    for (size_t b = 0; b < n_oracles; b++) { if (rd_u64(r) != leaf_len[b]) return -6; rd_felts(r, leaf_len[b]); if (rd_u64(r) != (uint64_t)depth0) return -6; rd_felts(r, (size_t)depth0 * 4); }
+    if (rd_u64(r) != (uint64_t)cfg->n_arity) return -6;
+    size_t nl = N;
+    for (int l = 0; l < cfg->n_arity; l++) {
+      size_t arity = (size_t)1 << cfg->arity_bits[l]; nl >>= cfg->arity_bits[l];
+      if (rd_u64(r) != arity) return -6;
+      rd_felts(r, 2 * arity);
+      int depth = log2z(nl) - ch; if (depth < 0) depth = 0;
+      if (rd_u64(r) != (uint64_t)depth) return -6;
+      rd_felts(r, (size_t)depth * 4);
+    }
+    if (r->bad) return -7;
+  }
+  size_t final_len = rd_u64(r);
+  int total_arity = 0;
+  for (int l = 0; l < cfg->n_arity; l++) total_arity += cfg->arity_bits[l];
+  if (final_len != n >> total_arity) return -7;
+  const uint64_t *final_poly = rd_felts(r, final_len * 2);
+  uint64_t pow_witness = rd_u64(r);
+  if (r->bad) return -7;
+
+  or_challenger c = *cp;
+  gl2_t alpha = ch_ext(&c);
+  gl2_t betas[8];
+  for (int l = 0; l < cfg->n_arity; l++) { or_ch_observe(&c, fcap[l], cap_n * 4); betas[l] = ch_ext(&c); }
+  or_ch_observe(&c, final_poly, final_len * 2);
+  or_ch_observe(&c, &pow_witness, 1);
+  uint64_t resp = or_ch_challenge(&c);
+  if (dbg) { dbg->pow_response = resp;
+             for (int l = 0; l < cfg->n_arity; l++) { dbg->fri_betas[l][0] = betas[l].c[0]; dbg->fri_betas[l][1] = betas[l].c[1]; } }
+  if (!pow_ok(resp, cfg->pow_bits)) return -8;
+
+  /* reduced openings: sum alpha^j opening_j per batch; shift = alpha^(count of the batch) */
+  gl2_t *red = (gl2_t *)malloc(n_batches * sizeof(gl2_t)), *shf = (gl2_t *)malloc(n_batches * sizeof(gl2_t));
+  for (size_t b = 0; b < n_batches; b++) {
+    size_t cnt = 0;
+    for (size_t i = 0; i < batches[b].n_ranges; i++) cnt += batches[b].ranges[i].count;
+    red[b] = gl2_from_base(0);
+    for (size_t j = cnt; j-- > 0;) red[b] = gl2_add(gl2_mul(red[b], alpha), gl2_make(opened[b][2 * j], opened[b][2 * j + 1]));
+    shf[b] = gl2_pow(alpha, cnt);
+  }
+  int rc = 0;
+  rd_t q = {r->p, r->len, q_off, 0};
+  for (int qi = 0; qi < cfg->nq && !rc; qi++) {
+    size_t x_index = (size_t)(or_ch_challenge(&c) % N);
+    if (dbg && qi < 64) dbg->query_indices[qi] = x_index;
+    rd_u64(&q);
+    const uint64_t *ev[16];
+    for (size_t b = 0; b < n_oracles; b++) {
+      rd_u64(&q); ev[b] = rd_felts(&q, leaf_len[b]); rd_u64(&q);
+      const uint64_t *sibs = rd_felts(&q, (size_t)depth0 * 4);
+      if (!or_merkle_verify(ev[b], leaf_len[b], x_index, sibs, depth0, caps[b], ch)) { rc = -10 - (int)b; break; }
+    }
+    if (rc) break;
+    uint64_t x = or_fri_query_point(x_index, db + rb);
+    /* fri_combine_initial */
+    gl2_t sum = gl2_from_base(0);
+    for (size_t b = 0; b < n_batches; b++) {
+      gl2_t re = gl2_from_base(0);
+      for (size_t i = batches[b].n_ranges; i-- > 0;) {
+        const or_fri_range *R = &batches[b].ranges[i];
+        for (size_t j = R->count; j-- > 0;) re = gl2_add(gl2_mul(re, alpha), gl2_from_base(ev[R->oracle][R->first + j]));
+      }
+      gl2_t num = gl2_sub(re, red[b]), den = gl2_sub(gl2_from_base(x), gl2_make(batches[b].point[0], batches[b].point[1]));
+      sum = gl2_add(gl2_mul(sum, shf[b]), gl2_mul(num, gl2_inv(den))); /* alpha.shift(sum) uses the count of THIS batch */
+    }
+    rd_u64(&q);
+    gl2_t old = sum; size_t xi = x_index; size_t nl = N;
+    for (int l = 0; l < cfg->n_arity; l++) {
+      int ab = cfg->arity_bits[l]; size_t arity = (size_t)1 << ab; nl >>= ab;
+      rd_u64(&q); const uint64_t *fe = rd_felts(&q, 2 * arity);
+      int depth = log2z(nl) - ch; if (depth < 0) depth = 0;
+      rd_u64(&q); const uint64_t *sibs = rd_felts(&q, (size_t)depth * 4);
+      size_t within = xi & (arity - 1), coset = xi >> ab;
+      if (fe[2 * within] != old.c[0] || fe[2 * within + 1] != old.c[1]) { rc = -20 - l; break; }
+      uint64_t o2[2];
+      or_fri_compute_evaluation(x, within, ab, fe, betas[l].c, o2);
+      old = gl2_make(o2[0], o2[1]);
+      if (!or_merkle_verify(fe, 2 * arity, coset, sibs, depth, fcap[l], ch)) { rc = -30 - l; break; }
+      for (int s2 = 0; s2 < ab; s2++) x = gl_mul(x, x);
+      xi = coset;
+    }
+    if (rc) break;
+    gl2_t fp = eval_ext_poly((const gl2_t *)final_poly, final_len, gl2_from_base(x));
+    if (!gl2_eq(fp, old)) rc = -40;
+  }
+  free(red); free(shf);
+  if (!rc) *cp = c;
+  return rc;
+}
+
+int or_fri_verify(const or_fri_params *params, const uint32_t *num_polys, const uint32_t *blinding, size_t n_oracles,
+                  const uint64_t *const *caps, const or_fri_batch *batches, size_t n_batches, const uint64_t *const *opened,
+                  or_challenger *c, const uint8_t *proof, size_t len, or_tail_debug *dbg) {
+  if (n_oracles > 16) return -2;
+  fri_cfg_t cfg = {params->degree_bits, params->rate_bits, params->cap_height, params->pow_bits, params->num_query_rounds, params->n_arity, {0}};
+  for (int l = 0; l < 8; l++) cfg.arity_bits[l] = params->arity_bits[l];
+  size_t kk[16], leaf_len[16];
+  for (size_t o = 0; o < n_oracles; o++) { kk[o] = num_polys[o]; leaf_len[o] = kk[o] + (blinding[o] ? OR_SALT_SIZE : 0); }
+  rd_t r = {proof, len, 0, 0};
+  int rc = fri_verify_core(&cfg, n_oracles, kk, leaf_len, caps, batches, n_batches, opened, c, &r, dbg);
+  if (rc) return rc;
+  if (r.bad || r.o != len) return -7;
+  return 0;
+}
+
 /* Verify everything of a proof that does not need the gate constraints: transcript, proof of work,
  * Merkle paths of all queries, fri_combine_initial against the openings, fold consistency, final poly.
  * Returns 0 if ok, otherwise a negative code naming the first failing check. */
 int or_verify_tail(const or_shape *sh, const uint64_t circuit_digest[4], const uint64_t *cs_cap,
                    const uint8_t *proof, size_t len, or_tail_debug *dbg) {
   const int db = sh->degree_bits, rb = sh->rate_bits, ch = sh->cap_height;
-  const size_t n = (size_t)1 << db, N = n << rb, cap_n = (size_t)1 << ch;
+  const size_t cap_n = (size_t)1 << ch;
   const size_t k_cs = sh->num_constants + sh->num_routed_wires, k_w = sh->num_wires;
   const size_t k_z = (size_t)sh->num_challenges * (1 + sh->num_partial_products);
   const size_t k_q = (size_t)sh->num_challenges * sh->quotient_degree_factor;
@@ -476,36 +684,37 @@ int or_verify_tail(const or_shape *sh, const uint64_t circuit_digest[4], const u
                    k_z - sh->num_challenges, k_q, 0, 0};
   const uint64_t *op[9];
   for (int i = 0; i < 9; i++) { if (rd_u64(&r) != cnt[i]) return -3; op[i] = rd_felts(&r, cnt[i] * 2); }
-  if (rd_u64(&r) != (uint64_t)sh->n_arity) return -4;
-  const uint64_t *fcap[8];
-  for (int l = 0; l < sh->n_arity; l++) { if (rd_u64(&r) != cap_n) return -4; fcap[l] = rd_felts(&r, cap_n * 4); }
-  if (rd_u64(&r) != (uint64_t)sh->num_query_rounds) return -5;
-  size_t q_off = r.o;
-  /* skip the queries to reach final poly / pow / public inputs */
-  int depth0 = db + rb - ch;
+  if (r.bad) return -7;
+  size_t fri_off = r.o;
+  /* the public inputs sit behind the FriProof: parse it once to find them */
   size_t kk[4] = {k_cs, k_w, k_z, k_q};
   /* FriParams::hiding: the blinded oracles' leaves carry OR_SALT_SIZE salt elements after the polynomial values; the
    * Merkle check covers the whole leaf, fri_combine_initial only the unsalted part (FriInitialTreeProof::unsalted_eval) */
   size_t leaf_len[4];
   for (int b = 0; b < 4; b++) leaf_len[b] = kk[b] + ((sh->zero_knowledge && b >= 1) ? OR_SALT_SIZE : 0);
-  for (int qi = 0; qi < sh->num_query_rounds; qi++) {
-    if (rd_u64(&r) != 4) return -6;
-    for (int b = 0; b < 4; b++) { if (rd_u64(&r) != leaf_len[b]) return -6; rd_felts(&r, leaf_len[b]); if (rd_u64(&r) != (uint64_t)depth0) return -6; rd_felts(&r, (size_t)depth0 * 4); }
-    if (rd_u64(&r) != (uint64_t)sh->n_arity) return -6;
-    size_t nl = N;
+  fri_cfg_t cfg = {db, rb, ch, sh->pow_bits, sh->num_query_rounds, sh->n_arity, {0}};
+  for (int l = 0; l < 8; l++) cfg.arity_bits[l] = sh->arity_bits[l];
+  size_t pi_off;
+  {
+    /* length of the FriProof from the shape alone */
+    int depth0 = db + rb - ch;
+    size_t words = 1 + (size_t)sh->n_arity * (1 + cap_n * 4) + 1, per_q = 1;
+    for (int b = 0; b < 4; b++) per_q += 1 + leaf_len[b] + 1 + (size_t)depth0 * 4;
+    per_q += 1;
+    size_t nl = (size_t)1 << (db + rb); int total = 0;
     for (int l = 0; l < sh->n_arity; l++) {
-      size_t arity = (size_t)1 << sh->arity_bits[l]; nl >>= sh->arity_bits[l];
-      if (rd_u64(&r) != arity) return -6; rd_felts(&r, 2 * arity);
+      nl >>= sh->arity_bits[l]; total += sh->arity_bits[l];
       int depth = log2z(nl) - ch; if (depth < 0) depth = 0;
-      if (rd_u64(&r) != (uint64_t)depth) return -6; rd_felts(&r, (size_t)depth * 4);
+      per_q += 1 + ((size_t)2 << sh->arity_bits[l]) + 1 + (size_t)depth * 4;
     }
+    words += per_q * (size_t)sh->num_query_rounds + 1 + 2 * (((size_t)1 << db) >> total) + 1;
+    pi_off = fri_off + 8 * words;
   }
-  size_t final_len = rd_u64(&r);
-  const uint64_t *final_poly = rd_felts(&r, final_len * 2);
-  uint64_t pow_witness = rd_u64(&r);
-  size_t n_pi = rd_u64(&r);
-  const uint64_t *pi = rd_felts(&r, n_pi);
-  if (r.bad || r.o != len) return -7;
+  if (pi_off + 8 > len) return -7;
+  rd_t rp = {proof, len, pi_off, 0};
+  size_t n_pi = rd_u64(&rp);
+  const uint64_t *pi = rd_felts(&rp, n_pi);
+  if (rp.bad || rp.o != len) return -7;
 
   /* transcript */
   uint64_t pi_hash[4]; or_hash_no_pad(pi, n_pi, pi_hash);
@@ -520,69 +729,26 @@ int or_verify_tail(const or_shape *sh, const uint64_t circuit_digest[4], const u
   or_ch_observe(&c, caps[3], cap_n * 4);
   gl2_t zeta = ch_ext(&c);
   gl2_t zeta_next = gl2_scale(zeta, gl_root_of_unity(db));
+  if (dbg) { dbg->zeta[0] = zeta.c[0]; dbg->zeta[1] = zeta.c[1]; }
   /* zeta batch order: constants, sigmas, wires, zs, partial products, quotient ; next batch: zs_next */
   int zorder[6] = {0, 1, 2, 3, 5, 6};
-  for (int i = 0; i < 6; i++) or_ch_observe(&c, op[zorder[i]], cnt[zorder[i]] * 2);
-  or_ch_observe(&c, op[4], cnt[4] * 2);
-  gl2_t alpha = ch_ext(&c);
-  gl2_t betas[8];
-  for (int l = 0; l < sh->n_arity; l++) { or_ch_observe(&c, fcap[l], cap_n * 4); betas[l] = ch_ext(&c); }
-  or_ch_observe(&c, final_poly, final_len * 2);
-  or_ch_observe(&c, &pow_witness, 1);
-  uint64_t resp = or_ch_challenge(&c);
-  if (dbg) { dbg->zeta[0] = zeta.c[0]; dbg->zeta[1] = zeta.c[1]; dbg->pow_response = resp;
-             for (int l = 0; l < sh->n_arity; l++) { dbg->fri_betas[l][0] = betas[l].c[0]; dbg->fri_betas[l][1] = betas[l].c[1]; } }
-  if (!pow_ok(resp, sh->pow_bits)) return -8;
-
-  /* reduced openings: sum alpha^j opening_j per batch */
-  gl2_t red0 = gl2_from_base(0), red1 = gl2_from_base(0);
-  for (int i = 5; i >= 0; i--) for (size_t j = cnt[zorder[i]]; j-- > 0;)
-    red0 = gl2_add(gl2_mul(red0, alpha), gl2_make(op[zorder[i]][2 * j], op[zorder[i]][2 * j + 1]));
-  for (size_t j = cnt[4]; j-- > 0;) red1 = gl2_add(gl2_mul(red1, alpha), gl2_make(op[4][2 * j], op[4][2 * j + 1]));
-
-  rd_t q = {proof, len, q_off, 0};
-  for (int qi = 0; qi < sh->num_query_rounds; qi++) {
-    size_t x_index = (size_t)(or_ch_challenge(&c) % N);
-    if (dbg && qi < 64) dbg->query_indices[qi] = x_index;
-    rd_u64(&q);
-    const uint64_t *ev[4];
-    for (int b = 0; b < 4; b++) {
-      rd_u64(&q); ev[b] = rd_felts(&q, leaf_len[b]); rd_u64(&q);
-      const uint64_t *sibs = rd_felts(&q, (size_t)depth0 * 4);
-      if (!or_merkle_verify(ev[b], leaf_len[b], x_index, sibs, depth0, caps[b], ch)) return -10 - b;
-    }
-    uint64_t x = or_fri_query_point(x_index, db + rb);
-    /* fri_combine_initial */
-    gl2_t sum = gl2_from_base(0);
-    {
-      gl2_t re = gl2_from_base(0);
-      for (int b = 3; b >= 0; b--) for (size_t j = kk[b]; j-- > 0;) re = gl2_add(gl2_mul(re, alpha), gl2_from_base(ev[b][j]));
-      gl2_t num = gl2_sub(re, red0), den = gl2_sub(gl2_from_base(x), zeta);
-      sum = gl2_mul(num, gl2_inv(den)); /* alpha.shift(0) = 0 */
-      gl2_t re1 = gl2_from_base(0);
-      for (size_t j = sh->num_challenges; j-- > 0;) re1 = gl2_add(gl2_mul(re1, alpha), gl2_from_base(ev[2][j]));
-      gl2_t num1 = gl2_sub(re1, red1), den1 = gl2_sub(gl2_from_base(x), zeta_next);
-      sum = gl2_add(gl2_mul(sum, gl2_pow(alpha, sh->num_challenges)), gl2_mul(num1, gl2_inv(den1)));
-    }
-    rd_u64(&q);
-    gl2_t old = sum; size_t xi = x_index; size_t nl = N;
-    for (int l = 0; l < sh->n_arity; l++) {
-      int ab = sh->arity_bits[l]; size_t arity = (size_t)1 << ab; nl >>= ab;
-      rd_u64(&q); const uint64_t *fe = rd_felts(&q, 2 * arity);
-      int depth = log2z(nl) - ch; if (depth < 0) depth = 0;
-      rd_u64(&q); const uint64_t *sibs = rd_felts(&q, (size_t)depth * 4);
-      size_t within = xi & (arity - 1), coset = xi >> ab;
-      if (fe[2 * within] != old.c[0] || fe[2 * within + 1] != old.c[1]) return -20 - l;
-      uint64_t o2[2];
-      or_fri_compute_evaluation(x, within, ab, fe, betas[l].c, o2);
-      old = gl2_make(o2[0], o2[1]);
-      if (!or_merkle_verify(fe, 2 * arity, coset, sibs, depth, fcap[l], ch)) return -30 - l;
-      for (int s = 0; s < ab; s++) x = gl_mul(x, x);
-      xi = coset;
-    }
-    gl2_t fp = eval_ext_poly((const gl2_t *)final_poly, final_len, gl2_from_base(x));
-    if (!gl2_eq(fp, old)) return -40;
+  size_t k_all = k_cs + k_w + k_z + k_q;
+  uint64_t *open0 = (uint64_t *)malloc(k_all * 16);
+  {
+    size_t o = 0;
+    for (int i = 0; i < 6; i++) { or_ch_observe(&c, op[zorder[i]], cnt[zorder[i]] * 2); memcpy(open0 + o, op[zorder[i]], cnt[zorder[i]] * 16); o += cnt[zorder[i]] * 2; }
   }
+  or_ch_observe(&c, op[4], cnt[4] * 2);
+
+  or_fri_range r0[4] = {{0, 0, (uint32_t)k_cs}, {1, 0, (uint32_t)k_w}, {2, 0, (uint32_t)k_z}, {3, 0, (uint32_t)k_q}};
+  or_fri_range r1[1] = {{2, 0, (uint32_t)sh->num_challenges}};
+  or_fri_batch fb[2] = {{{zeta.c[0], zeta.c[1]}, r0, 4}, {{zeta_next.c[0], zeta_next.c[1]}, r1, 1}};
+  const uint64_t *opened[2] = {open0, op[4]};
+  rd_t rf = {proof, len, fri_off, 0};
+  int rc = fri_verify_core(&cfg, 4, kk, leaf_len, caps, fb, 2, opened, &c, &rf, dbg);
+  free(open0);
+  if (rc) return rc;
+  if (rf.o != pi_off) return -7;
   return 0;
 }
 

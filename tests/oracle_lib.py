@@ -495,3 +495,151 @@ def fr_root_of_unity(log_n):
     out = np.zeros(4, np.uint64)
     lib().or_fr_root_of_unity(ctypes.c_int(log_n), ptr(out))
     return _int(out)
+
+
+# ---- the generic seams: PolynomialBatch handles, prove_openings / verify_fri_proof over any instance -------------------
+class FriParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("degree_bits", "rate_bits", "cap_height", "pow_bits", "num_query_rounds", "n_arity")] + [
+        ("arity_bits", ctypes.c_int * 8)]
+
+
+class FriRange(ctypes.Structure):
+    _fields_ = [("oracle", ctypes.c_uint32), ("first", ctypes.c_uint32), ("count", ctypes.c_uint32)]
+
+
+class FriBatch(ctypes.Structure):
+    _fields_ = [("point", ctypes.c_uint64 * 2), ("ranges", ctypes.POINTER(FriRange)), ("n_ranges", ctypes.c_size_t)]
+
+
+def fri_params(degree_bits, rate_bits, cap_height, pow_bits, num_query_rounds, arity_bits):
+    p = FriParams(degree_bits, rate_bits, cap_height, pow_bits, num_query_rounds, len(arity_bits))
+    for i, a in enumerate(arity_bits):
+        p.arity_bits[i] = a
+    return p
+
+
+def _fri_batches(batches):
+    a = (FriBatch * len(batches))()
+    keep = []
+    for i, (pt, ranges) in enumerate(batches):
+        rr = (FriRange * max(1, len(ranges)))()
+        for j, (o, f, c) in enumerate(ranges):
+            rr[j] = FriRange(o, f, c)
+        keep.append(rr)
+        a[i].point[0], a[i].point[1] = int(pt[0]), int(pt[1])
+        a[i].ranges = ctypes.cast(rr, ctypes.POINTER(FriRange))
+        a[i].n_ranges = len(ranges)
+    return a, keep
+
+
+class Batch:
+    """or_batch: PolynomialBatch on the CPU (coefficients, bit-reversed LDE, Merkle tree)."""
+
+    def __init__(self, polys, rate_bits, cap_height, from_coeffs=False, salts=None):
+        L = lib()
+        L.or_batch_commit.restype = ctypes.c_void_p
+        v = arr(polys)
+        self.k, n = v.shape
+        self.log_n, self.rate_bits, self.cap_height = int(n).bit_length() - 1, rate_bits, cap_height
+        s = None if salts is None else arr(salts)
+        self.blinding = salts is not None
+        self.h = ctypes.c_void_p(L.or_batch_commit(ptr(v), ctypes.c_size_t(self.k), self.log_n, rate_bits, cap_height,
+                                                   1 if from_coeffs else 0, ptr(s)))
+
+    def _view(self, fn, count):
+        L = lib()
+        f = getattr(L, fn)
+        f.restype = _u64p
+        f.argtypes = [ctypes.c_void_p]
+        return np.ctypeslib.as_array(f(self.h), shape=(count,)).copy()
+
+    def cap(self):
+        return self._view("or_batch_cap", 4 << self.cap_height).reshape(-1, 4)
+
+    def coeffs(self):
+        return self._view("or_batch_coeffs", self.k << self.log_n).reshape(self.k, -1)
+
+    def lde(self):
+        return self._view("or_batch_lde", (self.k + (4 if self.blinding else 0)) << (self.log_n + self.rate_bits)).reshape(-1, 1 << (self.log_n + self.rate_bits))
+
+    def eval_ext(self, point, first=0, count=None):
+        count = self.k - first if count is None else count
+        out = np.zeros((count, 2), np.uint64)
+        pt = arr(point)
+        L = lib()
+        L.or_batch_eval_ext.restype = None
+        L.or_batch_eval_ext(self.h, ctypes.c_size_t(first), ctypes.c_size_t(count), ptr(pt), ptr(out))
+        return out
+
+    def lde_rows(self, first_index, count, step=1):
+        out = np.zeros((count, self.k), np.uint64)
+        L = lib()
+        L.or_batch_lde_rows.restype = None
+        L.or_batch_lde_rows(self.h, ctypes.c_size_t(first_index), ctypes.c_size_t(count), ctypes.c_size_t(step), ptr(out))
+        return out
+
+    def close(self):
+        if self.h:
+            L = lib()
+            L.or_batch_free.restype = None
+            L.or_batch_free(self.h)
+            self.h = None
+
+
+def challenger_new():
+    c = Challenger()
+    lib().or_ch_init(ctypes.byref(c))
+    return c
+
+
+def challenger_observe(c, elems):
+    e = arr(elems).ravel()
+    L = lib()
+    L.or_ch_observe.restype = None
+    L.or_ch_observe(ctypes.byref(c), ptr(e), ctypes.c_size_t(e.size))
+
+
+def challenger_challenges(c, count):
+    L = lib()
+    L.or_ch_challenge.restype = ctypes.c_uint64
+    return np.array([L.or_ch_challenge(ctypes.byref(c)) for _ in range(count)], dtype=np.uint64)
+
+
+def challenger_tuple(c):
+    return (tuple(c.state), tuple(c.inb[:c.n_in]), tuple(c.out[:c.n_out]))
+
+
+def fri_prove(oracles, batches, params, challenger, pow_override=None):
+    """or_fri_prove; advances `challenger` (oracle_lib.Challenger). Returns (FriProof bytes, TailDebug)."""
+    L = lib()
+    L.or_fri_prove.restype = ctypes.c_int
+    hs = (ctypes.c_void_p * len(oracles))(*[o.h for o in oracles])
+    a, keep = _fri_batches(batches)
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    ln = ctypes.c_size_t()
+    dbg = TailDebug()
+    rc = L.or_fri_prove(hs, ctypes.c_size_t(len(oracles)), a, ctypes.c_size_t(len(batches)), ctypes.byref(params),
+                        ctypes.byref(challenger), ctypes.c_int(0 if pow_override is None else 1),
+                        ctypes.c_uint64(pow_override or 0), ctypes.byref(out), ctypes.byref(ln), ctypes.byref(dbg))
+    assert rc == 0, rc
+    data = ctypes.string_at(out, ln.value)
+    L.or_free(out)
+    return data, dbg
+
+
+def fri_verify(params, oracle_infos, caps, batches, opened_values, challenger, proof_bytes):
+    """or_fri_verify -> (rc, TailDebug); rc == 0: accepted and `challenger` advanced."""
+    L = lib()
+    L.or_fri_verify.restype = ctypes.c_int
+    nps = (ctypes.c_uint32 * len(oracle_infos))(*[int(k) for k, _ in oracle_infos])
+    bl = (ctypes.c_uint32 * len(oracle_infos))(*[int(bool(b)) for _, b in oracle_infos])
+    cap_arrs = [arr(c) for c in caps]
+    capp = (_u64p * len(cap_arrs))(*[ptr(c) for c in cap_arrs])
+    a, keep = _fri_batches(batches)
+    ov = [arr(o) for o in opened_values]
+    ovp = (_u64p * len(ov))(*[ptr(o) for o in ov])
+    buf = (ctypes.c_uint8 * len(proof_bytes)).from_buffer_copy(proof_bytes)
+    dbg = TailDebug()
+    rc = L.or_fri_verify(ctypes.byref(params), nps, bl, ctypes.c_size_t(len(oracle_infos)), capp, a, ctypes.c_size_t(len(batches)), ovp,
+                         ctypes.byref(challenger), buf, ctypes.c_size_t(len(proof_bytes)), ctypes.byref(dbg))
+    return rc, dbg

@@ -1,0 +1,145 @@
+"""GPU parity of the two plonky2-level seams (include/cityprover.h cp_batch_* / cp_fri_prove): `PolynomialBatch` handles and
+`PolynomialBatch::prove_openings` over ARBITRARY oracles and opening batches, against the CPU oracle (or_batch_* / or_fri_prove):
+  * commitments (values / coefficients, with and without blinding): cap, openings, `get_lde_values` rows;
+  * seeded random FRI instances (1-5 oracles, 1-4 batches given as up to 39 polynomial runs, 0-4 reduction layers): FriProof
+    bytes and the challenger state handed back, both verifiers accept;
+  * the SHA-256 STARK's shapes (city_common_circuit/src/hash/accelerator/sha256/smartgadget.rs:55-79,310-312: 418 free + 912
+    extended columns, 2^k rows; starky's fast config: rate_bits 1, cap height 4, 16-bit PoW, 84 queries) with three opening batches,
+    bytes == oracle at 2^14 and 2^16 rows;
+  * a toy AIR (cubic-extension-free) proved end to end through the C ABI and verified.
+Parity for A13 itself stays UNPINNED: the reference asserts SHA digests only (smartgadget.rs:505-513), no STARK proof bytes exist."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import fri_instances as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def prover():
+    import cityprover
+    p = cityprover.Prover(0)
+    O.lib().or_set_threads(min(16, os.cpu_count() or 1))
+    yield p
+    O.lib().or_set_threads(1)
+    p.close()
+
+
+@pytest.mark.parametrize("k,db,rb,ch,coeffs,salt", [(5, 6, 1, 2, False, False), (135, 12, 3, 4, False, False), (7, 5, 2, 0, True, False),
+                                                    (20, 8, 3, 4, False, True), (3, 3, 1, 4, True, True), (1, 0, 1, 0, False, False),
+                                                    (33, 13, 1, 4, False, False)])
+def test_batch_commit_matches_oracle(prover, k, db, rb, ch, coeffs, salt):
+    import cityprover
+    n, N = 1 << db, 1 << (db + rb)
+    polys = O.splitmix64_felts(k * 31 + db, k * n).reshape(k, n)
+    salts = O.splitmix64_felts(77 + k, 4 * N).reshape(4, N) if salt else None
+    g = cityprover.PolyBatch(prover, polys, rb, ch, coeffs, salts)
+    o = O.Batch(polys, rb, ch, coeffs, salts)
+    try:
+        assert (g.cap() == o.cap()).all()
+        pt = np.array([0x1234567890ABCDEF % O.P, 0x0FEDCBA987654321], dtype=np.uint64)
+        assert (g.eval_ext(pt) == o.eval_ext(pt)).all()
+        if k > 2:
+            assert (g.eval_ext(pt, 1, k - 2) == o.eval_ext(pt, 1, k - 2)).all()
+        cnt = min(N, 37)
+        for first, step in ((0, 1), (N - cnt, 1), (3 % N, 1 << rb), (1, 3)):
+            if first + cnt > N and step == 1:
+                continue
+            assert (g.lde_rows(first, cnt, step) == o.lde_rows(first, cnt, step)).all()
+        # device views: the coefficient array and the bit-reversed LDE the handle keeps
+        cptr, lptr = g.device_ptrs()
+        co = np.empty(k * n, np.uint64)
+        prover._check(prover.lib.cp_d2h(prover.ctx, co.ctypes.data, cptr, co.size * 8))
+        assert (co.reshape(k, n) == o.coeffs()).all()
+        ld = np.empty(k * N, np.uint64)
+        prover._check(prover.lib.cp_d2h(prover.ctx, ld.ctypes.data, lptr, ld.size * 8))
+        assert (ld.reshape(k, N) == o.lde()[:k]).all()
+    finally:
+        g.close()
+        o.close()
+
+
+def test_batch_commit_refuses_bad_arguments(prover):
+    import cityprover
+    ok = O.splitmix64_felts(1, 4 * 16).reshape(4, 16)
+    bad = ok.copy()
+    bad[2, 3] = O.P
+    with pytest.raises(cityprover.CityProverError, match="canonical"):
+        cityprover.PolyBatch(prover, bad, 1, 2)
+    with pytest.raises(cityprover.CityProverError, match="cap_height"):
+        cityprover.PolyBatch(prover, ok, 1, 9)
+    b = cityprover.PolyBatch(prover, ok, 1, 2)
+    with pytest.raises(cityprover.CityProverError, match="out of range"):
+        b.eval_ext(np.array([3, 0], dtype=np.uint64), 2, 3)
+    with pytest.raises(cityprover.CityProverError, match="canonical"):
+        b.eval_ext(np.array([O.P, 0], dtype=np.uint64))
+    # FriParams that do not match the batch, a batch list pointing outside an oracle, a point on the LDE coset
+    st = cityprover.ChallengerState()
+    with pytest.raises(cityprover.CityProverError, match="differ"):
+        cityprover.fri_prove(prover, [b], [((3, 0), [(0, 0, 4)])], cityprover.fri_params(4, 2, 2, 0, 2, ()), st)
+    with pytest.raises(cityprover.CityProverError, match="out of range"):
+        cityprover.fri_prove(prover, [b], [((3, 0), [(0, 2, 3)])], cityprover.fri_params(4, 1, 2, 0, 2, ()), st)
+    with pytest.raises(cityprover.CityProverError, match="LDE coset"):
+        cityprover.fri_prove(prover, [b], [((7, 0), [(0, 0, 4)])], cityprover.fri_params(4, 1, 2, 0, 2, ()), st)
+    assert st.as_tuple() == cityprover.ChallengerState().as_tuple()   # a refused call leaves the transcript alone
+    b.close()
+
+
+N_RANDOM = int(os.environ.get("CITY_RANDOM_FRI", "40"))
+
+
+@pytest.mark.parametrize("seed", range(N_RANDOM))
+def test_fri_prove_matches_oracle_on_random_instances(prover, seed):
+    spec = F.random_instance(seed)
+    want = F.run_instance(F.OracleBackend(), spec)
+    got = F.run_instance(F.GpuBackend(prover), spec)
+    assert got["state_before"] == want["state_before"]
+    assert got["proof"] == want["proof"], spec
+    assert got["state_after"] == want["state_after"]
+    F.verify_both(spec, got)
+
+
+def test_fri_prove_with_injected_pow_witness(prover):
+    spec = F.random_instance(3)
+    spec["pow_bits"] = 5
+    want = F.run_instance(F.OracleBackend(), spec, pow_override=12345)
+    got = F.run_instance(F.GpuBackend(prover), spec, pow_override=12345)
+    assert got["proof"] == want["proof"] and got["state_after"] == want["state_after"]
+
+
+def stark_spec(log_rows, seed):
+    # trace rounds of the SHA-256 STARK (418 free + 912 extended columns) + a quotient oracle; everything opened at zeta, the
+    # trace also at g*zeta (next row), and a third batch at g^2*zeta over a sub-range (what a multi-row window would open)
+    arity = []
+    bits, cap = log_rows + 1, 4
+    while bits - 4 >= max(cap, 1) and log_rows - 4 * (len(arity) + 1) >= 0 and (log_rows - 4 * len(arity)) > 5:
+        arity.append(4)   # ConstantArityBits(4, 5): reduce by 16 while the degree is above 2^5 and the layer still has a cap
+        bits -= 4
+    return dict(seed=seed, degree_bits=log_rows, rate_bits=1, cap_height=cap, arity_bits=tuple(arity), pow_bits=16, num_query_rounds=84,
+                ks=[418, 912, 8], blinding=[False, False, False],
+                batches=[[(0, 0, 418), (1, 0, 912), (2, 0, 8)], [(0, 0, 418), (1, 0, 912)], [(1, 100, 300), (0, 17, 5)]])
+
+
+@pytest.mark.parametrize("log_rows", [14, 16])
+def test_fri_prove_at_the_sha256_stark_shapes(prover, log_rows):
+    spec = stark_spec(log_rows, 4242 + log_rows)
+    polys, salts = F.instance_inputs(spec)
+    want = F.run_instance(F.OracleBackend(), spec, polys, salts)
+    got = F.run_instance(F.GpuBackend(prover), spec, polys, salts)
+    assert [c.tolist() for c in got["caps"]] == [c.tolist() for c in want["caps"]]
+    assert all((a == b).all() for a, b in zip(got["opened"], want["opened"]))
+    assert got["proof"] == want["proof"]
+    assert got["state_after"] == want["state_after"]
+    F.verify_both(spec, got)
+
+
+def test_toy_air_end_to_end_through_the_c_abi(prover):
+    want = F.toy_stark_prove(F.OracleBackend(), degree_bits=8, rate_bits=1, cap_height=3, pow_bits=8, num_query_rounds=20, arity_bits=(3, 2))
+    got = F.toy_stark_prove(F.GpuBackend(prover), degree_bits=8, rate_bits=1, cap_height=3, pow_bits=8, num_query_rounds=20, arity_bits=(3, 2))
+    assert got["proof"] == want["proof"] and got["state_after"] == want["state_after"]
+    assert F.toy_stark_verify(got, use_product=True) is None
+    assert F.toy_stark_verify(got, use_product=False) is None
