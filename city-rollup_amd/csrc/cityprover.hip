@@ -174,6 +174,8 @@ int run_dif(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stride,
     a.block_stride = ex.block_stride;
     a.block_bits = ex.block_bits;
     a.natural_out = ex.natural_out ? 1 : 0;
+    static const int staged = getenv("CITYPROVER_NTT_STAGED_STORE") ? atoi(getenv("CITYPROVER_NTT_STAGED_STORE")) : 1;
+    a.staged_store = (staged && q_after == 0 && log_n >= 16) ? 1 : 0;
     dim3 grid((unsigned)(((size_t)1 << outer_bits) >> c), (unsigned)batch, (unsigned)ex.n_blocks);
     bool done = false;
     const bool need16 = ex.src || ex.ptab || ex.n_blocks > 1 || ex.natural_out;

@@ -18,7 +18,8 @@ namespace gl {
 constexpr uint64_t P = 0xFFFFFFFF00000001ULL;
 constexpr uint64_t EPS = 0xFFFFFFFFULL;  // 2^64 mod p
 
-GL_HD uint64_t canon(uint64_t x) { return x >= P ? x - P : x; }
+// x - p == x + EPS (mod 2^64): one 64-bit compare, one select, one 64-bit add (v_lshl_add_u64) on gfx950
+GL_HD uint64_t canon(uint64_t x) { return x + (x >= P ? EPS : 0); }
 
 GL_HD uint32_t lo32(uint64_t x) { return (uint32_t)x; }
 GL_HD uint32_t hi32(uint64_t x) { return (uint32_t)(x >> 32); }
@@ -36,8 +37,14 @@ GL_HD uint64_t sub(uint64_t a, uint64_t b) {
   return (uint64_t)d - (borrowed & EPS);
 }
 GL_HD uint64_t neg(uint64_t a) { return a ? P - a : 0; }
-// a, b canonical -> canonical.  a + b == a - (p - b)
-GL_HD uint64_t add(uint64_t a, uint64_t b) { return sub(a, P - b); }
+// a, b canonical -> canonical, five instructions on gfx950 (one v_lshl_add_u64, two 64-bit compares, a select, one more add; as
+// a - (p - b) through carry chains it was seven). s = a + b mod 2^64. If it wrapped, the true sum is s + 2^64 == s + EPS, which
+// cannot wrap again (s <= 2p - 2 - 2^64) and is below p; if it did not wrap but s >= p, then s - p == s + EPS (mod 2^64): both
+// repairs add EPS.
+GL_HD uint64_t add(uint64_t a, uint64_t b) {
+  const uint64_t s = a + b;
+  return s + (((s < a) | (s >= P)) ? EPS : 0);
+}
 
 // lazy add: a any u64, b any u64 -> u64 congruent to a+b (not canonical)
 GL_HD uint64_t add_lazy(uint64_t a, uint64_t b) {

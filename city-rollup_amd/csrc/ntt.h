@@ -52,6 +52,8 @@ struct PassArgs {
   size_t block_stride;     // blockIdx.z selects an output block: data + b*stride + z*block_stride
   int block_bits;          // ptab row = bitrev(z, block_bits)  (output block z holds coset rev(z))
   int natural_out;         // ROWS single-pass transforms only: store in natural order
+  int staged_store;        // ROWS passes: stage the last round's 16 consecutive elements per thread through LDS so that a wave
+                           // stores 512 contiguous bytes per instruction (ntt16.h)
 };
 
 // position of (r, cc) inside the LDS tile == order of the tile's elements in memory

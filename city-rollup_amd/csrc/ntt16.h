@@ -267,7 +267,41 @@ __global__ __launch_bounds__(THREADS, (HALF && !(L == 4 && !ROWS)) ? NTT16_MIN_W
       }
       return;
     }
-    if (ROWS) {
+    if (ROWS && a.staged_store) {
+      // The last round leaves every thread 16 CONSECUTIVE elements: stored directly, one instruction of a wave writes 8 bytes
+      // into each of 64 different 128-byte lines. Through LDS (same positions, read back lane-contiguous) a wave writes 512
+      // contiguous bytes per instruction.
+      uint64_t *out_t = poly + ((size_t)blockIdx.x << LOG_TILE);
+      __syncthreads();
+      if constexpr (HALF) {
+        uint32_t lo[16];
+        tile_t *w = tile + pad(P);
+#pragma unroll
+        for (int m = 0; m < 16; m++) w[pad(m)] = gl::lo32(x[m]);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 16; m++) lo[m] = tile[pad(t + (m << (LOG_TILE - 4)))];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 16; m++) w[pad(m)] = gl::hi32(x[m]);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+          const int pos = t + (m << (LOG_TILE - 4));
+          out_t[pos] = gl::pack(lo[m], tile[pad(pos)]);
+        }
+      } else {
+        tile_t *w = tile + pad(P);
+#pragma unroll
+        for (int m = 0; m < 16; m++) w[pad(m)] = x[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+          const int pos = t + (m << (LOG_TILE - 4));
+          out_t[pos] = tile[pad(pos)];
+        }
+      }
+    } else if (ROWS) {
       uint64_t *out_t = poly + ((size_t)blockIdx.x << LOG_TILE) + P;
 #pragma unroll
       for (int m = 0; m < 16; m++) out_t[m << Flast] = x[m];

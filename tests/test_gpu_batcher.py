@@ -81,16 +81,17 @@ def test_concurrent_callers_get_cp_prove_bytes(lanes, linger_us):
     prover.close()
 
 
-def test_a_failing_request_fails_alone():
-    """One caller hands in a non-canonical public input (cp_prove: CP_ERR_INVALID_ARG). Whatever it was batched with is
-    proved all the same, and the failing caller gets the status and the message in its own thread."""
+def test_a_bad_request_is_refused_before_it_is_queued():
+    """One caller hands in a non-canonical public input (cp_prove: CP_ERR_INVALID_ARG). It is refused before it reaches the queue
+    (inside a merged batch it would fail the batch and have every neighbour proved again singly); the failing caller
+    gets the status and the message in its own thread, the others their proofs in ONE pass."""
     import cityprover as cp
     prover = cp.Prover(0)
     (c, circ), = _circuits(cp, prover, [(6, 16, 20, (2, 2), 21)])
     want = cp.prove(circ, c["wires"], c["public_inputs"])
     bad = np.array(c["public_inputs"], dtype=np.uint64).copy()
     bad[0] = np.uint64(P)
-    batcher = cp.Batcher(prover, max_batch=16, linger_us=20000)   # linger: the eight calls below share one batch
+    batcher = cp.Batcher(prover, max_batch=16, linger_us=20000)   # linger: the calls below share one batch
     jobs = [(circ, c["wires"], bad if j == 3 else c["public_inputs"]) for j in range(8)]
     got = _run_callers(batcher, jobs, 8)
     for j, g in enumerate(got):
@@ -99,7 +100,30 @@ def test_a_failing_request_fails_alone():
         else:
             assert g == want, f"job {j}: {g!r:.80}"
     st = batcher.stats()
-    assert st["calls"] == 8 and st["retried_singly"] >= 1
+    assert st["calls"] == 7 and st["proofs"] == 7 and st["retried_singly"] == 0
+    batcher.close()
+    circ.close()
+    prover.close()
+
+
+def test_a_failing_batch_is_retried_request_by_request():
+    """A failure that only shows inside the batch (here: an injected allocation failure in one of its phases, as an
+    out-of-memory would) fails the merged call as a whole; every request of it is then proved singly and gets its bytes."""
+    import cityprover as cp
+    prover = cp.Prover(0)
+    (c, circ), = _circuits(cp, prover, [(6, 16, 20, (2, 2), 22)])
+    want = cp.prove(circ, c["wires"], c["public_inputs"])
+    batcher = cp.Batcher(prover, max_batch=16, linger_us=20000)
+    jobs = [(circ, c["wires"], c["public_inputs"]) for _ in range(6)]
+    assert prover.lib.cp_fault_inject(1, 2) == 0        # CP_FAULT_ALLOC: the third checkpoint from now fails, once
+    try:
+        got = _run_callers(batcher, jobs, 6)
+    finally:
+        prover.lib.cp_fault_inject(1, -1)
+    for j, g in enumerate(got):
+        assert g == want, f"job {j}: {g!r:.80}"
+    st = batcher.stats()
+    assert st["calls"] == 6 and st["retried_singly"] >= 1
     batcher.close()
     circ.close()
     prover.close()
