@@ -364,6 +364,13 @@ def main():
                "fr_ntt_2^20_inverse_ms": f20["inverse_ms"], "groth16_quotient_2^20_ms": f20["groth16_quotient_ms"],
                "groth16_prove_2^20_ms": pr20["prove_ms"]}
 
+    # A13's polynomial-commitment half through the generic seams (cp_batch_commit_dev / cp_fri_prove) at the SHA-256 STARK's
+    # shapes, side measurement on rank 0 with cp_fri_verify as its check — tools/bench_stark_fri.py
+    stark = None
+    if rank == 0 and not args.no_qbench:
+        import bench_stark_fri
+        stark = {"2^14": bench_stark_fri.run(prover, 14, reps=3), "2^16": bench_stark_fri.run(prover, 16, reps=2)}
+
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
         ntts = k * world
@@ -446,6 +453,7 @@ def main():
             "cpu_baseline": base,
             "qbench": qb,
             "groth16_kernels": g16,
+            "stark_commit_fri": stark,
         }
         print(json.dumps(out))
     cap.free()

@@ -1061,6 +1061,7 @@ ABI.update({
     "cp_batch_cap": (ctypes.c_int, [_vp, _u64p]),
     "cp_batch_eval_ext": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, _u64p, _u64p]),
     "cp_batch_lde_rows": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, _u64p]),
+    "cp_batch_leaves": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, _u64p]),
     "cp_batch_device_ptrs": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "cp_fri_prove": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_size_t, ctypes.POINTER(FriBatch), ctypes.c_size_t,
                                     ctypes.POINTER(FriParams), ctypes.POINTER(ChallengerState), ctypes.c_int, ctypes.c_uint64,
@@ -1110,6 +1111,11 @@ class PolyBatch:
     def lde_rows(self, first_index, count, step=1):
         out = np.zeros((count, self.k), np.uint64)
         self.prover._check(self.prover.lib.cp_batch_lde_rows(self.handle, first_index, count, step, _ptr(out)))
+        return out
+
+    def leaves(self, first_leaf, count):
+        out = np.zeros((count, self.k + (SALT_SIZE if self.blinding else 0)), np.uint64)
+        self.prover._check(self.prover.lib.cp_batch_leaves(self.handle, first_leaf, count, _ptr(out)))
         return out
 
     def device_ptrs(self):

@@ -444,6 +444,10 @@ int cp_batch_eval_ext(cp_poly_batch *batch, size_t first, size_t count, const ui
  * (count x k, row-major) = the k LDE values at NATURAL position (first_index + r) * step of the coset (salt excluded) —
  * what a CPU constraint evaluator reads while it builds the quotient. */
 int cp_batch_lde_rows(cp_poly_batch *batch, size_t first_index, size_t count, size_t step, uint64_t *out_host);
+/* `merkle_tree.leaves[first_leaf .. first_leaf + count)`: the Merkle leaves themselves, in LEAF order (leaf i = the LDE row at
+ * natural position bit_reverse(i)), salt included — count x (k + n_salt) row-major. What a host-side `PolynomialBatch` keeps
+ * so that plonky2's own `get_lde_values` / `get_lde_values_packed` keep working on a batch committed on the device. */
+int cp_batch_leaves(cp_poly_batch *batch, size_t first_leaf, size_t count, uint64_t *out_host);
 /* device views for callers that evaluate their constraints on the device: coefficient array (k x n) and bit-reversed
  * LDE (k x N), polynomial-major, valid until cp_batch_destroy */
 int cp_batch_device_ptrs(cp_poly_batch *batch, const uint64_t **coeffs_dev_out, const uint64_t **lde_dev_out);

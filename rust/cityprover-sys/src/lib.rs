@@ -130,6 +130,10 @@ pub struct Circuit {
     pub digest: [u64; 4],
 }
 unsafe impl Send for Circuit {}
+// The device data of a circuit is read-only after `load` and the C side documents sharing between lanes / batcher callers
+// (include/cityprover.h, cp_batcher): `&Circuit` may be used from several threads. Without this, a `CircuitData` holding a
+// GPU twin would stop being `Sync`, which plonky2's rayon users rely on.
+unsafe impl Sync for Circuit {}
 
 impl Circuit {
     /// From flat data (see `plonky2-hwa-patch`: `flatten_circuit`). `cs_values`: the constants (selectors first)
@@ -200,6 +204,120 @@ impl Drop for Circuit {
     fn drop(&mut self) {
         unsafe { ffi::cp_circuit_destroy(self.raw) }
     }
+}
+
+/// Error classes the caller may want to tell apart: a request the GPU backend REFUSES (unsupported gate, zero-knowledge
+/// circuit on a plain entry point, malformed argument) is not a failed proof — the caller falls back to the CPU prover.
+pub fn is_refusal(err: &anyhow::Error) -> bool {
+    let s = err.to_string();
+    s.starts_with(&format!("cityprover[{}]", ffi::CP_ERR_INVALID_ARG)) || s.starts_with(&format!("cityprover[{}]", ffi::CP_ERR_UNSUPPORTED))
+}
+
+/// plonky2 `PolynomialBatch` resident on the GPU (`cp_poly_batch`): coefficients, bit-reversed LDE and Merkle tree of k
+/// polynomials. The generic seam every FRI-based prover goes through — `CircuitData::prove` and starkyx's `ByteStark::prove`
+/// (city_common_circuit/src/hash/accelerator/sha256/smartgadget.rs:518-524) alike.
+pub struct PolyBatch {
+    raw: *mut ffi::CpPolyBatch,
+    pub k: usize,
+    pub degree_bits: usize,
+    pub rate_bits: usize,
+    pub cap_height: usize,
+    pub blinding: bool,
+}
+unsafe impl Send for PolyBatch {}
+unsafe impl Sync for PolyBatch {}
+
+impl PolyBatch {
+    /// `PolynomialBatch::from_values` (`from_coeffs` with `coeffs = true`). `polys`: k x n, polynomial-major canonical u64.
+    /// `salts`: `Some(CP_SALT_SIZE x N)` = blinding with the caller's randomness.
+    pub fn commit(ctx: &Context, polys: &[u64], k: usize, degree_bits: usize, rate_bits: usize, cap_height: usize, coeffs: bool, salts: Option<&[u64]>) -> Result<Self> {
+        if polys.len() != k << degree_bits {
+            bail!("PolyBatch::commit: {} elements for {k} polynomials of 2^{degree_bits}", polys.len());
+        }
+        if let Some(s) = salts {
+            if s.len() != ffi::CP_SALT_SIZE << (degree_bits + rate_bits) {
+                bail!("PolyBatch::commit: salts have the wrong length");
+            }
+        }
+        let mut raw = ptr::null_mut();
+        check(ctx.raw, unsafe {
+            ffi::cp_batch_commit(
+                ctx.raw, polys.as_ptr(), k, degree_bits as c_int, rate_bits as c_int, cap_height as c_int,
+                if coeffs { ffi::CP_BATCH_FROM_COEFFS } else { 0 }, salts.map_or(ptr::null(), |s| s.as_ptr()), &mut raw,
+            )
+        })?;
+        Ok(Self { raw, k, degree_bits, rate_bits, cap_height, blinding: salts.is_some() })
+    }
+
+    fn ok(&self, rc: c_int) -> Result<()> {
+        if rc == ffi::CP_OK {
+            return Ok(());
+        }
+        bail!("cityprover[{rc}]: {}", last_error(ptr::null_mut()))
+    }
+
+    /// `merkle_tree.cap`
+    pub fn cap(&self) -> Result<Vec<[u64; 4]>> {
+        let mut flat = vec![0u64; 4 << self.cap_height];
+        self.ok(unsafe { ffi::cp_batch_cap(self.raw, flat.as_mut_ptr()) })?;
+        Ok(flat.chunks_exact(4).map(|c| [c[0], c[1], c[2], c[3]]).collect())
+    }
+
+    /// `polynomials[first..first+count].map(|p| p.to_extension().eval(point))`
+    pub fn eval_ext(&self, first: usize, count: usize, point: [u64; 2]) -> Result<Vec<[u64; 2]>> {
+        let mut flat = vec![0u64; 2 * count];
+        self.ok(unsafe { ffi::cp_batch_eval_ext(self.raw, first, count, point.as_ptr(), flat.as_mut_ptr()) })?;
+        Ok(flat.chunks_exact(2).map(|c| [c[0], c[1]]).collect())
+    }
+
+    /// `merkle_tree.leaves[first..first+count]`, row-major, salt included
+    pub fn leaves(&self, first: usize, count: usize) -> Result<Vec<u64>> {
+        let w = self.k + if self.blinding { ffi::CP_SALT_SIZE } else { 0 };
+        let mut out = vec![0u64; count * w];
+        self.ok(unsafe { ffi::cp_batch_leaves(self.raw, first, count, out.as_mut_ptr()) })?;
+        Ok(out)
+    }
+
+    pub fn raw(&self) -> *mut ffi::CpPolyBatch {
+        self.raw
+    }
+}
+
+impl Drop for PolyBatch {
+    fn drop(&mut self) {
+        unsafe { ffi::cp_batch_destroy(self.raw) }
+    }
+}
+
+/// One opening batch (`FriBatchInfo`): the point and the polynomial list as (oracle, first, count) runs.
+pub struct FriBatch {
+    pub point: [u64; 2],
+    pub ranges: Vec<ffi::CpFriPolyRange>,
+}
+
+/// `PolynomialBatch::prove_openings`: bincode `FriProof` bytes; `challenger` is advanced as plonky2's would be.
+pub fn fri_prove(ctx: &Context, oracles: &[&PolyBatch], batches: &[FriBatch], params: &ffi::CpFriParams, challenger: &mut ffi::CpChallengerState, pow_witness: Option<u64>) -> Result<Vec<u8>> {
+    let os: Vec<*mut ffi::CpPolyBatch> = oracles.iter().map(|o| o.raw).collect();
+    let bs: Vec<ffi::CpFriBatch> = batches.iter().map(|b| ffi::CpFriBatch { point: b.point, ranges: b.ranges.as_ptr(), n_ranges: b.ranges.len() }).collect();
+    let (mut out, mut len) = (ptr::null_mut::<u8>(), 0usize);
+    check(ctx.raw, unsafe {
+        ffi::cp_fri_prove(ctx.raw, os.as_ptr(), os.len(), bs.as_ptr(), bs.len(), params, challenger, pow_witness.is_some() as c_int, pow_witness.unwrap_or(0), &mut out, &mut len)
+    })?;
+    let v = unsafe { std::slice::from_raw_parts(out, len) }.to_vec();
+    unsafe { ffi::cp_free(out.cast()) };
+    Ok(v)
+}
+
+/// `verify_fri_proof` (+ `fri_challenges`): host arithmetic, no GPU.
+pub fn fri_verify(params: &ffi::CpFriParams, oracles: &[ffi::CpFriOracleInfo], caps: &[&[u64]], batches: &[FriBatch], opened: &[&[u64]], challenger: &mut ffi::CpChallengerState, proof: &[u8]) -> Result<()> {
+    let cs: Vec<*const u64> = caps.iter().map(|c| c.as_ptr()).collect();
+    let ov: Vec<*const u64> = opened.iter().map(|o| o.as_ptr()).collect();
+    let bs: Vec<ffi::CpFriBatch> = batches.iter().map(|b| ffi::CpFriBatch { point: b.point, ranges: b.ranges.as_ptr(), n_ranges: b.ranges.len() }).collect();
+    let rc = unsafe { ffi::cp_fri_verify(params, oracles.as_ptr(), oracles.len(), cs.as_ptr(), bs.as_ptr(), bs.len(), ov.as_ptr(), challenger, proof.as_ptr(), proof.len()) };
+    if rc == ffi::CP_OK {
+        return Ok(());
+    }
+    Err(anyhow!("cityprover[{rc}]: {}", last_error(ptr::null_mut())))
 }
 
 /// Group commit for worker loops that prove one job per call (`SimpleActorWorker::process_next_job`,

@@ -299,6 +299,9 @@ pub fn load_gpu_circuit(
     verifier_only: &VerifierOnlyCircuitData<C, D>,
 ) -> Result<GpuHandle> {
     let flat = flatten_circuit(common, prover_only)?;
+    // zero-knowledge circuits (standard_recursion_zk_config: the user-side signature circuits) need leaf salts from plonky2's RNG;
+    // `prove_gpu` below calls the plain entry points, which refuse them — such a circuit stays on the CPU prover
+    ensure!(flat.shape.zero_knowledge == 0, "zero-knowledge circuit: salts are drawn by the CPU prover");
     if let Ok(dir) = std::env::var("CITYPROVER_DUMP_DIR") {
         // one file per circuit, named by its digest: the input of the native q-bench harness
         let name = format!("{:016x}{:016x}.cpcirc", flat.digest[0], flat.digest[1]);
@@ -324,6 +327,19 @@ pub fn load_gpu_circuit(
 }
 
 /// `prove_with_partition_witness` after witness generation: the wire matrix goes to the GPU, the bincode bytes come back.
+/// `Ok(None)`: the backend REFUSED the request (CP_ERR_INVALID_ARG / CP_ERR_UNSUPPORTED) — the caller proves on the CPU; any
+/// other failure (device error, out of memory) is an `Err`, as it is for the CPU prover.
+pub fn prove_gpu_or_refuse(handle: &GpuHandle, witness: &MatrixWitness<F>, public_inputs: &[F], pow_witness: Option<u64>) -> Result<Option<ProofWithPublicInputs<F, C, D>>> {
+    match prove_gpu(handle, witness, public_inputs, pow_witness) {
+        Ok(p) => Ok(Some(p)),
+        Err(e) if cityprover_sys::is_refusal(&e) => {
+            log::warn!("cityprover: request refused, proving on the CPU: {e}");
+            Ok(None)
+        }
+        Err(e) => Err(e),
+    }
+}
+
 pub fn prove_gpu(handle: &GpuHandle, witness: &MatrixWitness<F>, public_inputs: &[F], pow_witness: Option<u64>) -> Result<ProofWithPublicInputs<F, C, D>> {
     let wires: Vec<u64> = witness.wire_values.iter().flat_map(|col| col.iter().map(|v| v.to_canonical_u64())).collect();
     let pis: Vec<u64> = public_inputs.iter().map(|v| v.to_canonical_u64()).collect();
@@ -337,4 +353,171 @@ pub fn prove_gpu(handle: &GpuHandle, witness: &MatrixWitness<F>, public_inputs: 
     };
     // the bytes ARE the bincode the worker stores (city_redis_store/src/lib.rs:71-83)
     Ok(bincode::deserialize(&bytes)?)
+}
+
+
+// ---- the two generic seams: PolynomialBatch::from_values and PolynomialBatch::prove_openings ---------------------------------
+// Every FRI-based prover in the process goes through these two functions of plonky2 — `CircuitData::prove` (which the hook
+// above replaces wholesale) and starkyx's `ByteStark::prove` (the SHA-256 STARK of the sighash circuit:
+// city_common_circuit/src/hash/accelerator/sha256/smartgadget.rs:518-524, 418 + 912 columns, three proofs per block). With the
+// hooks of hooks.patch, a `PolynomialBatch` built by `from_values` carries a GPU twin, and `prove_openings` runs on the device
+// when every oracle has one. UNCOMPILED, from memory of plonky2 0.2.2: names to re-check — `PolynomialBatch::{polynomials,
+// merkle_tree, degree_log, rate_bits, blinding}`, `MerkleTree::{leaves, digests, cap}`, `FriInstanceInfo::{oracles, batches}`,
+// `FriBatchInfo::{point, polynomials}`, `FriPolynomialInfo::{oracle_index, polynomial_index}`, `Challenger::{sponge_state,
+// input_buffer, output_buffer}` (private fields: this module lives inside the crate), `FriParams::{config, degree_bits,
+// reduction_arity_bits, hiding}`, `SALT_SIZE`.
+use cityprover_sys::ffi::{CpChallengerState, CpFriParams, CpFriPolyRange};
+use cityprover_sys::{FriBatch, PolyBatch};
+
+use crate::field::extension::quadratic::QuadraticExtension;
+use crate::field::polynomial::{PolynomialCoeffs, PolynomialValues};
+use crate::fri::oracle::PolynomialBatch;
+use crate::fri::proof::FriProof;
+use crate::fri::structure::FriInstanceInfo;
+use crate::fri::FriParams;
+use crate::hash::hash_types::HashOut;
+use crate::hash::merkle_tree::{MerkleCap, MerkleTree};
+use crate::hash::poseidon::PoseidonHash;
+use crate::iop::challenger::Challenger;
+
+/// Smallest commitment worth a round trip: below this the CPU is faster than the copies (override: CITYPROVER_MIN_COMMIT).
+fn min_commit_elements() -> usize {
+    std::env::var("CITYPROVER_MIN_COMMIT").ok().and_then(|s| s.parse().ok()).unwrap_or(1 << 18)
+}
+
+/// `PolynomialBatch::from_values` on the GPU: iNTT, coset LDE, Merkle tree. Returns the host-side `PolynomialBatch` plonky2
+/// expects — `polynomials` (coefficients) and `merkle_tree.{leaves, cap}` fetched from the device, so that `get_lde_values`,
+/// `get_lde_values_packed` and `eval` of CPU callers (a STARK's constraint evaluation) keep working — with the device twin
+/// attached. `merkle_tree.digests` stays EMPTY: the only consumer of the inner nodes is `prove_openings`, which runs on the
+/// device when the twin is there (`MerkleTree::prove` on such a tree is a bug; the CPU fallback of `prove_openings` below
+/// rebuilds the tree first). `None`: not worth it / not possible (blinding needs plonky2's RNG: the salts are drawn HERE, on
+/// the Rust side, and handed over).
+pub fn batch_from_values_gpu(values: &[PolynomialValues<F>], rate_bits: usize, blinding: bool, cap_height: usize) -> Result<Option<PolynomialBatch<F, C, D>>> {
+    let k = values.len();
+    if k == 0 {
+        return Ok(None);
+    }
+    let n = values[0].len();
+    if k * n < min_commit_elements() || !n.is_power_of_two() {
+        return Ok(None);
+    }
+    let degree_bits = n.trailing_zeros() as usize;
+    let flat: Vec<u64> = values.iter().flat_map(|p| p.values.iter().map(|v| v.to_canonical_u64())).collect();
+    let big_n = n << rate_bits;
+    let salts: Option<Vec<u64>> = blinding.then(|| (0..crate::plonk::plonk_common::SALT_SIZE * big_n).map(|_| F::rand().to_canonical_u64()).collect());
+    let ctx = context()?.lock().unwrap();
+    let twin = match PolyBatch::commit(&ctx, &flat, k, degree_bits, rate_bits, cap_height, false, salts.as_deref()) {
+        Ok(t) => t,
+        Err(e) if cityprover_sys::is_refusal(&e) => return Ok(None),
+        Err(e) => return Err(e),
+    };
+    // host mirror
+    let cap = MerkleCap(twin.cap()?.into_iter().map(|h| HashOut { elements: h.map(F::from_canonical_u64) }).collect());
+    let width = k + if blinding { crate::plonk::plonk_common::SALT_SIZE } else { 0 };
+    let mut leaves = Vec::with_capacity(big_n);
+    const SLICE: usize = 1 << 14; // leaves per copy
+    for first in (0..big_n).step_by(SLICE) {
+        let cnt = SLICE.min(big_n - first);
+        let rows = twin.leaves(first, cnt)?;
+        leaves.extend(rows.chunks_exact(width).map(|r| r.iter().map(|v| F::from_canonical_u64(*v)).collect::<Vec<_>>()));
+    }
+    // coefficients: one more device -> host copy through the evaluation entry point would be k Horner sums; the plain copy is
+    // cp_batch_device_ptrs + cp_d2h (k x n u64)
+    let polynomials = fetch_coeffs(&ctx, &twin, k, n)?;
+    Ok(Some(PolynomialBatch {
+        polynomials,
+        merkle_tree: MerkleTree { leaves, digests: Vec::new(), cap },
+        degree_log: degree_bits,
+        rate_bits,
+        blinding,
+        gpu: Some(std::sync::Arc::new(twin)),
+    }))
+}
+
+fn fetch_coeffs(ctx: &cityprover_sys::Context, twin: &PolyBatch, k: usize, n: usize) -> Result<Vec<PolynomialCoeffs<F>>> {
+    use cityprover_sys::ffi;
+    let (mut c, mut l) = (std::ptr::null(), std::ptr::null());
+    let rc = unsafe { ffi::cp_batch_device_ptrs(twin.raw(), &mut c, &mut l) };
+    ensure!(rc == ffi::CP_OK, "cp_batch_device_ptrs failed");
+    let mut flat = vec![0u64; k * n];
+    let rc = unsafe { ffi::cp_d2h(ctx.raw(), flat.as_mut_ptr().cast(), c.cast(), k * n * 8) };
+    ensure!(rc == ffi::CP_OK, "cp_d2h failed");
+    Ok(flat.chunks_exact(n).map(|p| PolynomialCoeffs::new(p.iter().map(|v| F::from_canonical_u64(*v)).collect())).collect())
+}
+
+fn challenger_to_c(ch: &Challenger<F, PoseidonHash>) -> CpChallengerState {
+    let mut s: CpChallengerState = unsafe { std::mem::zeroed() };
+    for (d, v) in s.sponge_state.iter_mut().zip(ch.sponge_state.as_ref()) {
+        *d = v.to_canonical_u64();
+    }
+    for (d, v) in s.input_buffer.iter_mut().zip(&ch.input_buffer) {
+        *d = v.to_canonical_u64();
+    }
+    for (d, v) in s.output_buffer.iter_mut().zip(&ch.output_buffer) {
+        *d = v.to_canonical_u64();
+    }
+    s.n_input = ch.input_buffer.len() as u32;
+    s.n_output = ch.output_buffer.len() as u32;
+    s
+}
+
+fn challenger_from_c(s: &CpChallengerState, ch: &mut Challenger<F, PoseidonHash>) {
+    for (d, v) in ch.sponge_state.as_mut().iter_mut().zip(s.sponge_state) {
+        *d = F::from_canonical_u64(v);
+    }
+    ch.input_buffer = s.input_buffer[..s.n_input as usize].iter().map(|v| F::from_canonical_u64(*v)).collect();
+    ch.output_buffer = s.output_buffer[..s.n_output as usize].iter().map(|v| F::from_canonical_u64(*v)).collect();
+}
+
+/// `PolynomialBatch::prove_openings` on the GPU when every oracle carries a device twin; `None` otherwise (the caller runs
+/// plonky2's own code). The polynomial lists of the instance are compressed into runs; the bytes that come back are the
+/// bincode of `FriProof<F, PoseidonHash, D>`.
+pub fn prove_openings_gpu(
+    instance: &FriInstanceInfo<F, D>,
+    oracles: &[&PolynomialBatch<F, C, D>],
+    challenger: &mut Challenger<F, PoseidonHash>,
+    fri_params: &FriParams,
+) -> Result<Option<FriProof<F, PoseidonHash, D>>> {
+    let twins: Option<Vec<&PolyBatch>> = oracles.iter().map(|o| o.gpu.as_deref()).collect();
+    let Some(twins) = twins else { return Ok(None) };
+    if twins.len() > 8 || fri_params.reduction_arity_bits.len() > 8 {
+        return Ok(None);
+    }
+    let batches: Vec<FriBatch> = instance
+        .batches
+        .iter()
+        .map(|b| {
+            let mut ranges: Vec<CpFriPolyRange> = Vec::new();
+            for p in &b.polynomials {
+                match ranges.last_mut() {
+                    Some(r) if r.oracle as usize == p.oracle_index && (r.first + r.count) as usize == p.polynomial_index => r.count += 1,
+                    _ => ranges.push(CpFriPolyRange { oracle: p.oracle_index as u32, first: p.polynomial_index as u32, count: 1 }),
+                }
+            }
+            let pt: QuadraticExtension<F> = b.point;
+            FriBatch { point: [pt.0[0].to_canonical_u64(), pt.0[1].to_canonical_u64()], ranges }
+        })
+        .collect();
+    let mut arity_bits = [0i32; 8];
+    for (d, a) in arity_bits.iter_mut().zip(&fri_params.reduction_arity_bits) {
+        *d = *a as i32;
+    }
+    let params = CpFriParams {
+        degree_bits: fri_params.degree_bits as i32,
+        rate_bits: fri_params.config.rate_bits as i32,
+        cap_height: fri_params.config.cap_height as i32,
+        pow_bits: fri_params.config.proof_of_work_bits as i32,
+        num_query_rounds: fri_params.config.num_query_rounds as i32,
+        n_arity: fri_params.reduction_arity_bits.len() as i32,
+        arity_bits,
+    };
+    let mut state = challenger_to_c(challenger);
+    let ctx = context()?.lock().unwrap();
+    let bytes = match cityprover_sys::fri_prove(&ctx, &twins, &batches, &params, &mut state, None) {
+        Ok(b) => b,
+        Err(e) if cityprover_sys::is_refusal(&e) => return Ok(None),
+        Err(e) => return Err(e),
+    };
+    challenger_from_c(&state, challenger);
+    Ok(Some(bincode::deserialize(&bytes)?))
 }

@@ -50,6 +50,10 @@ def test_batch_commit_matches_oracle(prover, k, db, rb, ch, coeffs, salt):
             if (first + cnt > N and step == 1) or step > N:
                 continue
             assert (g.lde_rows(first, cnt, step) == o.lde_rows(first, cnt, step)).all()
+        # merkle_tree.leaves: leaf order, salt included
+        lv = o.lde()
+        assert (g.leaves(0, min(N, 50)) == lv[:, :min(N, 50)].T).all()
+        assert (g.leaves(N - 1, 1) == lv[:, N - 1:].T).all()
         # device views: the coefficient array and the bit-reversed LDE the handle keeps
         cptr, lptr = g.device_ptrs()
         co = np.empty(k * n, np.uint64)

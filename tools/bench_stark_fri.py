@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""The polynomial-commitment half of a SHA-256 STARK proof through the two generic seams (include/cityprover.h cp_batch_* /
+cp_fri_prove), at the shapes of city-rollup's `ByteStark` (city_common_circuit/src/hash/accelerator/sha256/smartgadget.rs:55-79,
+310-312, 518-524): commit a 418-column and a 912-column trace and an 8-column quotient (`PolynomialBatch::from_values`,
+values resident in HBM), open everything at zeta and the traces at g*zeta, then `prove_openings` (rate_bits 1, cap height 4,
+16-bit PoW, 84 queries — starky's fast config). The proof is checked by cp_fri_verify (the host verifier cp_verify runs);
+tests/test_gpu_fri_generic.py holds the same shapes against the CPU oracle's bytes. The AIR (trace generation, constraint
+evaluation) is the caller's and is NOT in these numbers. One JSON line, or run(prover, log_rows) from bench.py."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "city-rollup_amd"))
+import numpy as np  # noqa: E402
+import cityprover as cp  # noqa: E402
+
+KS = (418, 912, 8)
+
+
+def arity_for(log_rows, rate_bits=1, cap_height=4):
+    """plonky2 FriReductionStrategy::ConstantArityBits(4, 5)"""
+    out, db = [], log_rows
+    while db > 5 and db + rate_bits - 4 >= cap_height:
+        out.append(4)
+        db -= 4
+    return tuple(out)
+
+
+def run(prover, log_rows, reps=3, seed=1):
+    rb, ch, pow_bits, nq = 1, 4, 16, 84
+    n = 1 << log_rows
+    rng = np.random.default_rng(seed)
+    dev = []
+    for k in KS:
+        dev.append(prover.to_device(rng.integers(0, cp.P, size=(k, n), dtype=np.uint64)))
+    params = cp.fri_params(log_rows, rb, ch, pow_bits, nq, arity_for(log_rows, rb, ch))
+    g = pow(7, (cp.P - 1) >> log_rows, cp.P)
+    t_commit, t_open, t_fri, proof_len = [], [], [], 0
+    ok = False
+    for it in range(reps + 1):
+        prover.sync()
+        t0 = time.perf_counter()
+        B = [cp.PolyBatch(prover, None, rb, ch, device_ptr=d.ptr, shape=(k, n)) for d, k in zip(dev, KS)]
+        t1 = time.perf_counter()
+        st = cp.ChallengerState()
+        caps = [b.cap() for b in B]
+        for c in caps:
+            st.observe(c)
+        zeta = [int(v) for v in st.challenges(2)]
+        zn = [zeta[0] * g % cp.P, zeta[1] * g % cp.P]
+        batches = [(zeta, [(0, 0, KS[0]), (1, 0, KS[1]), (2, 0, KS[2])]), (zn, [(0, 0, KS[0]), (1, 0, KS[1])])]
+        opened = [np.concatenate([B[o].eval_ext(np.array(pt, dtype=np.uint64), f, c) for o, f, c in rr]) for pt, rr in batches]
+        for o in opened:
+            st.observe(o)
+        t2 = time.perf_counter()
+        before = st.copy()
+        proof = cp.fri_prove(prover, B, batches, params, st)
+        t3 = time.perf_counter()
+        if it == 0:   # warm-up iteration: also the correctness gate
+            cp.fri_verify(params, [(k, 0) for k in KS], caps, batches, opened, before, proof)
+            assert before.as_tuple() == st.as_tuple(), "verifier and prover transcripts differ"
+            ok = True
+            proof_len = len(proof)
+        else:
+            t_commit.append(t1 - t0)
+            t_open.append(t2 - t1)
+            t_fri.append(t3 - t2)
+        for b in B:
+            b.close()
+    for d in dev:
+        d.free()
+    med = lambda v: sorted(v)[len(v) // 2] * 1e3
+    N = n << rb
+    return {"log_rows": log_rows, "columns": list(KS), "rate_bits": rb, "cap_height": ch, "pow_bits": pow_bits, "num_query_rounds": nq,
+            "arity_bits": list(arity_for(log_rows, rb, ch)), "commit_ms": med(t_commit), "openings_ms": med(t_open), "fri_prove_ms": med(t_fri),
+            "total_ms": med(t_commit) + med(t_open) + med(t_fri), "fri_proof_bytes": proof_len, "checked": ok,
+            "leaf_permutations": N * sum((k + 7) // 8 for k in KS),
+            "note": "commit = 3 x PolynomialBatch::from_values from HBM-resident values (handle allocation included); openings = "
+                    "2 668 evaluations in F_p^2 + transcript; fri_prove = prove_openings; checked = cp_fri_verify accepts and leaves "
+                    "the transcript where the prover left it"}
+
+
+if __name__ == "__main__":
+    p = cp.Prover(0)
+    print(json.dumps({"what": "SHA-256 STARK commitment + FRI through cp_batch_commit_dev / cp_fri_prove", "cases": [run(p, k) for k in (12, 14, 16)]}))
+    p.close()
