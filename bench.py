@@ -184,6 +184,10 @@ def native_qbench(device, rank, pack):
     return {"blocks_per_s": many["blocks_per_s"], "proofs_per_s": many["proofs_per_s"], "blocks_in_flight": many["blocks_in_flight"],
             "jobs_per_block": many["jobs_per_block"], "proofs_per_block": many["proofs_per_block"],
             "proofs_byte_checked": many["proofs_byte_checked"], "job_records_written": len(per_job),
+            "distinct_proofs_per_block": many["distinct_proofs"], "distinct_circuits": many["circuits"],
+            "distinct_proofs_equal_to_oracle_bytes": many["distinct_proofs_equal_to_recorded_bytes"],
+            "distinct_proofs_cp_verified": many["distinct_proofs_cp_verified"], "mean_batch": many["mean_batch"],
+            "launches": many["launches"], "one_block_mean_batch": one["mean_batch"],
             "one_block_latency_ms": one["mean_block_latency_ms"],
             "reference_loop_block_ms": serial["mean_block_latency_ms"],
             "throughput_mode_proofs_per_s": thr["proofs_per_s"], "contexts_per_gpu": 3, "max_batch": 32,
@@ -195,8 +199,11 @@ def native_qbench(device, rank, pack):
             "harness": "tools/cityprover_qbench -i tests/golden/qbench_example.bin (the reference's own q-bench dump) -n 128 "
                        "--blocks-in-flight 32 --contexts 3 --batch 32; one_block = the same dump alone; reference_loop = one "
                        "context, one job at a time (the reference's single-threaded loop)",
-            "workload": "the example block's 46 jobs = 64 plonky2 proofs per block on synthetic shape-equivalent circuits (n = 2^12, 135 "
-                        "wires / 80 routed, 28 queries, 16-bit PoW, the 14-gate city-common set, rows ~60 % Poseidon); wires in "
+            "workload": "SURVEY.md section 8(d) M1: the example block's 46 jobs = 64 DISTINCT plonky2 proofs per block — one synthetic "
+                        "shape-equivalent circuit per (job type, stage) (26 circuits), one witness per job (seed = job index); n = 2^12, 135 "
+                        "wires / 80 routed, 28 queries, 16-bit PoW, the 14-gate city-common set, rows ~60 % Poseidon. Before the clock starts "
+                        "8 of the 64 must equal the CPU oracle's bytes and the other 56 pass cp_verify; every proof of the timed run is "
+                        "compared with the bytes that passed. Ready jobs of any type share launches (one shape, one gate set); wires in "
                         "page-locked host memory (PCIe-inclusive), proofs end in host memory; witness generation, the 3 SHA-256 "
                         "STARKs and the 3 Groth16 proofs of a block are outside the build and not in this number"}
 
@@ -324,20 +331,28 @@ def main():
     # "block proofs/sec (qbench)": every rank runs the native harness on its own GPU (jobs shard by block, no collective)
     qb = None
     if not args.no_qbench:
-        # the synthetic circuit pack (4 circuits + witnesses + the oracle's proofs of them) is written once, by rank 0
+        # the synthetic circuit pack (26 circuits, 64 witnesses, the oracle's proofs of 8 of them) is written once, by rank 0,
+        # into a fresh private directory whose name the other ranks learn through the control plane
         import shutil
         import tempfile
-        pack = os.path.join(tempfile.gettempdir(), "cityprover_pack_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
+        pack = None
         if rank == 0:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import make_circuit_pack
-            shutil.rmtree(pack, ignore_errors=True)
-            make_circuit_pack.make_pack(pack, n_circuits=4, db=12)
-        barrier()
-        mine = native_qbench(device, rank, pack)
-        barrier()
+            pack = tempfile.mkdtemp(prefix="cityprover_pack_")
+            make_circuit_pack.make_pack(pack, db=12, n_checked=8)
+        pack = D.broadcast_str(dist, pack)
+        # a rank whose harness fails must not leave the others in a barrier: the status is reduced first
+        mine, err = None, None
+        try:
+            mine = native_qbench(device, rank, pack)
+        except Exception as e:   # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
+        failed = D.sum_over_ranks(dist, 0.0 if err is None else 1.0)
         if rank == 0:
             shutil.rmtree(pack, ignore_errors=True)
+        if failed:
+            sys.exit("bench.py: the q-bench harness failed on %d rank(s)%s" % (int(failed), "" if err is None else " — this rank: " + err))
         qb = dict(mine)
         for key in ("blocks_per_s", "proofs_per_s", "throughput_mode_proofs_per_s"):
             qb[key] = D.sum_over_ranks(dist, mine[key])

@@ -374,6 +374,7 @@ ABI.update({
     "cp_zs_partial_products_dev": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp), _vp, _u64p, _u64p, _vp]),
     "cp_circuit_destroy": (None, [_vp]),
     "cp_circuit_cs_cap": (ctypes.c_int, [_vp, _u64p]),
+    "cp_circuits_batch_compatible": (ctypes.c_int, [_vp, _vp]),
     "cp_prove_tail": (ctypes.c_int, [_vp, _u64p, ctypes.c_size_t, _vp, _vp, _vp, ctypes.c_int, ctypes.c_uint64,
                                      ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)),
                                      ctypes.POINTER(ctypes.c_size_t)]),

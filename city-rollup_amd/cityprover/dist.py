@@ -54,3 +54,12 @@ def sum_over_ranks(dist, value):
     t = torch.tensor([float(value)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t[0])
+
+
+def broadcast_str(dist, value, src=0):
+    """rank `src`'s string on every rank (e.g. the private directory rank 0 wrote a fixture into)"""
+    if dist is None:
+        return value
+    obj = [value]
+    dist.broadcast_object_list(obj, src=src)
+    return obj[0]

@@ -256,6 +256,10 @@ int cp_circuit_set_public_input_targets(cp_circuit *circuit, const uint32_t *row
 int cp_circuit_public_inputs_from_wires(cp_circuit *circuit, const uint64_t *wires_values_host, uint64_t *public_inputs_out);
 /* the shape and digest a circuit was loaded with */
 int cp_circuit_shape(cp_circuit *circuit, cp_shape *shape_out, uint64_t digest_out[4]);
+/* 1 when proofs of the two circuits may share one cp_prove_batch* call (same shape up to the number of public inputs, same
+ * gate list and selector grouping: "one batch = one shape"), 0 when not, negative on a NULL argument. What a batching
+ * worker asks before it merges ready jobs of different circuits (cp_batcher asks the same internally). */
+int cp_circuits_batch_compatible(const cp_circuit *a, const cp_circuit *b);
 /* the circuit's constants_sigmas_cap (2^cap_height x 4), i.e. VerifierOnlyCircuitData */
 int cp_circuit_cs_cap(cp_circuit *circuit, uint64_t *cap_out_host);
 

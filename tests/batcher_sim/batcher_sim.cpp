@@ -33,6 +33,7 @@ struct cp_circuit {
   cp_shape sh;
   int num_selectors = 1;
   std::vector<quot::Gate> gates;
+  bool has_gates = true;
   int id;
 };
 namespace {

@@ -260,13 +260,17 @@ def uninterleave_row(rng, num_ops, to_b32):
 
 def build_gate_set(gate_set=CITY_COMMON, db=7, num_routed=80, num_wires=135, chunk=8, nc=2, seed=0, rate_bits=3,
                    cap_height=2, pow_bits=5, num_query_rounds=4, arity_bits=(2,), n_copies=8, weights=None,
-                   noop_fraction=0.1, backend=None):
+                   noop_fraction=0.1, backend=None, witness_seed=None):
     """weights: {gate type: relative row frequency} (default: uniform over the set's non-trivial gates).
-    backend: see synth_circuit.build (None = the oracle; tests only)."""
+    backend: see synth_circuit.build (None = the oracle; tests only).
+    witness_seed: None = one stream of randomness for circuit and witness (the historical behaviour); an integer = the CIRCUIT
+    (row types, constants, copy constraints) depends on `seed` alone and the WITNESS (public inputs, every free wire value) on
+    (seed, witness_seed): several satisfying witnesses of one circuit ("witness from seed = job index")."""
     use_oracle = backend is None
     if use_oracle:
         backend = OracleBackend()
     rng = np.random.default_rng(seed)
+    wrng = rng if witness_seed is None else np.random.default_rng([int(seed), int(witness_seed), 0x5EED])
     n = 1 << db
     assert chunk == 1 << rate_bits
     gates = sorted(gate_set, key=lambda g: (gate_degree(g), _ID[g[0]]))
@@ -290,7 +294,7 @@ def build_gate_set(gate_set=CITY_COMMON, db=7, num_routed=80, num_wires=135, chu
                                  rate_bits=rate_bits, cap_height=cap_height, pow_bits=pow_bits,
                                  num_query_rounds=num_query_rounds, arity_bits=arity_bits)
         ogates = O.make_gates(gate_list, nsel, k_is)
-    public_inputs = [int(x) for x in rng.integers(0, P, 5, dtype=np.uint64)]
+    public_inputs = [int(x) for x in wrng.integers(0, P, 5, dtype=np.uint64)]
     pi_hash = backend.hash_no_pad(public_inputs)
 
     # rows: PublicInput, Constant, one of every other gate, then a weighted random mix with Noop padding
@@ -312,7 +316,7 @@ def build_gate_set(gate_set=CITY_COMMON, db=7, num_routed=80, num_wires=135, chu
         sels[gate_list[g][1], i] = g
     c0 = rng.integers(0, P, n, dtype=np.uint64)
     c1 = rng.integers(0, P, n, dtype=np.uint64)
-    wires = rng.integers(0, P, (num_wires, n), dtype=np.uint64)
+    wires = wrng.integers(0, P, (num_wires, n), dtype=np.uint64)
     params = {g[0]: g for g in gates}
     for i, t in enumerate(types):
         _, a, b, c = params[t]
@@ -323,48 +327,48 @@ def build_gate_set(gate_set=CITY_COMMON, db=7, num_routed=80, num_wires=135, chu
         elif t == CONSTANT:
             row = [k0, k1][:a]
         elif t == ARITHMETIC:
-            row = arithmetic_row(rng, a, k0, k1)
+            row = arithmetic_row(wrng, a, k0, k1)
         elif t == ARITHMETIC_EXT:
-            row = arithmetic_ext_row(rng, a, k0, k1)
+            row = arithmetic_ext_row(wrng, a, k0, k1)
         elif t == MUL_EXT:
-            row = mul_ext_row(rng, a, k0)
+            row = mul_ext_row(wrng, a, k0)
         elif t == BASE_SUM:
-            row = base_sum_row(rng, a, b)
+            row = base_sum_row(wrng, a, b)
         elif t == RANDOM_ACCESS:
-            row = random_access_row(rng, a, b, c, [k0, k1])
+            row = random_access_row(wrng, a, b, c, [k0, k1])
         elif t == REDUCING:
-            row = reducing_row(rng, a, False)
+            row = reducing_row(wrng, a, False)
         elif t == REDUCING_EXT:
-            row = reducing_row(rng, a, True)
+            row = reducing_row(wrng, a, True)
         elif t == POSEIDON_MDS:
-            row = poseidon_mds_row(rng)
+            row = poseidon_mds_row(wrng)
         elif t == COSET_INTERPOLATION:
-            row = coset_interpolation_row(rng, a, b)
+            row = coset_interpolation_row(wrng, a, b)
         elif t == EXPONENTIATION:
-            row = exponentiation_row(rng, a)
+            row = exponentiation_row(wrng, a)
         elif t == COMPARISON:
-            x, y = int(rng.integers(0, 2**a)), int(rng.integers(0, 2**a))
-            row = comparison_row(x, x if rng.random() < 0.2 else y, a, b)
+            x, y = int(wrng.integers(0, 2**a)), int(wrng.integers(0, 2**a))
+            row = comparison_row(x, x if wrng.random() < 0.2 else y, a, b)
         elif t == U32_ARITHMETIC:
-            row = u32_arithmetic_row([tuple(int(v) for v in rng.integers(0, 2**32, 3)) for _ in range(a)])
+            row = u32_arithmetic_row([tuple(int(v) for v in wrng.integers(0, 2**32, 3)) for _ in range(a)])
         elif t == U32_RANGE_CHECK:
-            row = u32_range_check_row([int(v) for v in rng.integers(0, 2**32, a)])
+            row = u32_range_check_row([int(v) for v in wrng.integers(0, 2**32, a)])
         elif t == U32_ADD_MANY:
-            row = add_many_row(rng, a, b)
+            row = add_many_row(wrng, a, b)
         elif t == U32_SUBTRACTION:
-            row = subtraction_row(rng, a)
+            row = subtraction_row(wrng, a)
         elif t == U32_INTERLEAVE:
-            row = interleave_row(rng, a)
+            row = interleave_row(wrng, a)
         elif t == UNINTERLEAVE_TO_U32:
-            row = uninterleave_row(rng, a, False)
+            row = uninterleave_row(wrng, a, False)
         elif t == UNINTERLEAVE_TO_B32:
-            row = uninterleave_row(rng, a, True)
+            row = uninterleave_row(wrng, a, True)
         if row is not None:
             assert len(row) == gate_num_wires(params[t]), (t, len(row))
             wires[:len(row), i] = np.array(row, dtype=np.uint64)
     prow = [i for i, t in enumerate(types) if t == POSEIDON]
     if prow:
-        rows = backend.poseidon_rows(np.ascontiguousarray(wires[:12, prow].T), rng.integers(0, 2, len(prow), dtype=np.uint64))
+        rows = backend.poseidon_rows(np.ascontiguousarray(wires[:12, prow].T), wrng.integers(0, 2, len(prow), dtype=np.uint64))
         wires[:135, prow] = rows.T
 
     # copy constraints between free routed cells (columns the row's gate does not touch)

@@ -254,6 +254,45 @@ def test_one_block_end_to_end_with_byte_parity(golden_dir, tmp_path):
     assert "differ" in run(["-i", dump, "--pack", pack, "--contexts", "1"], ok=False)
 
 
+def test_dry_run_over_eight_device_slots(golden_dir):
+    """SURVEY.md section 8(e) without hardware: `--devices 0,...,7 --contexts 3` = 24 worker slots on one ready queue (the
+    in-process form of N worker processes on one Redis queue). Every block completes, every proving job is taken exactly once,
+    every device's slots get work, and the schedule still equals the dump's own records (--check-plan)."""
+    dump = os.path.join(golden_dir, "qbench_example.bin")
+    res = run(["-i", dump, "--dry-run", "--dry-run-job-us", "300", "--devices", "0,1,2,3,4,5,6,7", "--contexts", "3", "-n", "16",
+               "--blocks-in-flight", "16", "--batch", "4", "--check-plan"])
+    assert res["blocks_complete"] == 16 and res["jobs"] == 16 * 46 and res["proofs"] == 16 * 64 and res["workers"] == 24
+    per = res["dry_run_jobs_per_device"]
+    assert sorted(per) == [str(d) for d in range(8)] and sum(per.values()) == 16 * 46
+    assert min(per.values()) > 0, per
+    # one block alone cannot use eight devices at once (its critical path is ~9 dependent proofs), but it must still finish
+    one = run(["-i", dump, "--dry-run", "--dry-run-job-us", "300", "--devices", "0,1,2,3,4,5,6,7", "--contexts", "1", "--batch", "32"])
+    assert one["blocks_complete"] == 1 and sum(one["dry_run_jobs_per_device"].values()) == 46
+
+
+@pytest.mark.gpu
+def test_the_section_8d_workload_one_witness_per_job(golden_dir, tmp_path):
+    """one circuit per (job type, stage) the block schedules, one witness per job (seed = job
+    index) — 64 DISTINCT proofs of 26 distinct circuits per block. Eight of them carry the CPU oracle's bytes and must equal
+    them, the other 56 pass cp_verify before the clock starts, and every proof of the run equals the bytes that passed; ready
+    jobs of different types share launches (all circuits of this pack are batch-compatible)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_circuit_pack
+    pack = make_circuit_pack.make_pack(str(tmp_path / "pack"), db=7, small=True, n_checked=8, processes=1)
+    dump = os.path.join(golden_dir, "qbench_example.bin")
+    res = run(["-i", dump, "-n", "4", "--blocks-in-flight", "4", "--pack", pack, "--contexts", "2", "--batch", "16", "--check-plan"])
+    assert res["blocks_complete"] == 4 and res["proofs"] == 256 and res["proofs_byte_checked"] == 256
+    assert res["circuits"] == 26 and res["witnesses"] == 64 and res["batch_classes"] == 1
+    assert res["distinct_proofs"] == 64 and res["distinct_proofs_equal_to_recorded_bytes"] == 8 and res["distinct_proofs_cp_verified"] == 56
+    assert res["mean_batch"] > 2.0, res["mean_batch"]
+    # the three proofs the sighash jobs (type 33) make at stage 0 are three different byte strings
+    from cityprover import files
+    ws = [files.read_witness_file(os.path.join(pack, "type33_stage0_job%d.cpwit" % k))["wires"] for k in range(3)]
+    assert not (ws[0] == ws[1]).all() and not (ws[1] == ws[2]).all()
+    res = run(["--mode", "throughput", "--pack", pack, "--contexts", "2", "--batch", "8", "--iters", "3"])
+    assert res["distinct_proofs"] == 64 and res["proofs_byte_checked"] == 48
+
+
 @pytest.mark.gpu
 def test_product_shape_blocks_in_flight_and_throughput(golden_dir, tmp_path):
     """Product shape (n = 2^12, 135 wires, 28 queries, 16-bit PoW): 3 blocks in flight on 3 contexts, every one of the

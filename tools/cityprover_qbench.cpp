@@ -16,8 +16,9 @@
 //     --devices (default: every visible GPU) — pulling one shared ready queue (the in-process form of N worker processes
 //     on one Redis queue, city_rollup_core_worker/src/lib.rs:131-145); --contexts 1 --devices 0 --batch 1 is the
 //     reference's single-threaded loop, job for job in the same order;
-//   * a worker takes up to --batch ready jobs of ONE circuit type and proves them in one cp_prove_batch_host call (a job's
-//     `duration` is then the wall time of the batch it was part of);
+//   * a worker takes up to --batch ready jobs whose circuits may share a launch (cp_circuits_batch_compatible: one shape, one
+//     gate set — whatever their circuit TYPES) and proves them stage by stage, one cp_prove_batch_host call per stage and
+//     compatibility class (a job's `duration` is then the wall time of the batch it was part of);
 //   * --blocks-in-flight F replays F (dump, iteration) instances concurrently, each with its own proof store
 //     (BASELINE.json configs[3]: independent blocks); F = 1 is the reference's one-block-at-a-time loop;
 //   * circuits come from a circuit pack (tools/qbench/pack.h): `CircuitData` cannot be built without Rust, so every job
@@ -32,8 +33,10 @@
 //     second iteration on no group ever reaches its goal again and only leaf jobs run; here every iteration starts from
 //     fresh counters (--ref-counters keeps the reference's behaviour).
 //
-// Every proof is compared byte for byte with the proof recorded in its witness file (the CPU oracle's, or the Rust
-// prover's under nonce injection) when one is recorded. --dry-run runs the whole schedule without proving anything and
+// Checks: every job of a block proves its OWN witness (the pack binds one witness per job: SURVEY.md section 8(d) M1). Before
+// the clock starts every distinct (circuit, witness) pair is proved once: a proof whose witness file records bytes (the CPU
+// oracle's, or the Rust prover's under nonce injection) must equal them, every other one must pass cp_verify; in the timed
+// run every proof is compared byte for byte with the bytes that passed. --dry-run runs the whole schedule without proving anything and
 // without a GPU (tests of the planner and the queue semantics); --mode throughput is the raw proofs/s measurement;
 // --mode callers measures one-job-per-call threads (--callers T) merged by a cp_batcher (--batch = its max_batch, --linger-us);
 // --callers T in the default mode drains the DAG with T such threads per context instead of one batching thread.
@@ -73,6 +76,7 @@ struct Options {
   std::vector<std::string> inputs;
   std::string output, network = "dogeregtest", pack_dir, mode = "qbench", trace_path;
   int iterations = 1, contexts = 3, batch = 32, blocks_in_flight = 1, lanes = 1, iters = 8, callers = 0, linger_us = 0;
+  int dry_job_us = 0;   // --dry-run only: pretend a proving batch takes this long, so that the queue is shared among the worker slots
   int groth16_log = 0;  // > 0: the Groth16 job runs cp_groth16_prove_bls12381 on a synthetic key of 2^groth16_log constraints
   std::vector<int> devices;  // empty: all visible
   bool dry_run = false, ref_counters = false, check_plan = false;
@@ -103,6 +107,8 @@ struct Scheduler {
   std::string error;
   std::vector<BenchRecord> benchmarks;  // completion order
   std::vector<JobId> processed;        // every job popped, in pop order (barrier and notify jobs included)
+  int type_class[256] = {0};           // circuit type -> batch-compatibility class of its first stage's circuit
+  size_t launches = 0, launched_proofs = 0;  // cp_prove_batch_host calls of the timed run and the proofs they carried
 
   void enqueue(Instance *inst, const std::vector<JobId> &jobs) {
     std::lock_guard<std::mutex> l(m);
@@ -116,8 +122,9 @@ struct Scheduler {
     if (!failed) { failed = true; error = msg; }
     cv.notify_all();
   }
-  // Blocks until work is ready. Takes the front job and, when it is a proving job, up to max_batch - 1 further ready jobs of
-  // the same circuit type (FIFO among them). Returns false when the run is over (all instances complete, or a failure).
+  // Blocks until work is ready. Takes the front job and, when it is a proving job, up to max_batch - 1 further ready jobs
+  // whose circuits may share a launch with it (FIFO among them). Returns false when the run is over (all instances complete,
+  // or a failure).
   bool take(size_t max_batch, std::vector<QueueEntry> &out) {
     std::unique_lock<std::mutex> l(m);
     for (;;) {
@@ -139,7 +146,7 @@ struct Scheduler {
     const JobId first = out[0].job;
     if (first.topic == qb::GenerateStandardProof)
       for (auto it = queue.begin(); it != queue.end() && out.size() < max_batch;) {
-        if (it->job.topic == qb::GenerateStandardProof && it->job.circuit_type == first.circuit_type) {
+        if (it->job.topic == qb::GenerateStandardProof && type_class[it->job.circuit_type] == type_class[first.circuit_type]) {
           out.push_back(*it);
           it = queue.erase(it);
         } else {
@@ -250,7 +257,7 @@ struct Worker {
   const qb::Pack *pack = nullptr;
   std::vector<cp_circuit *> circuits;   // pack circuit index -> resident circuit of this context
   std::vector<uint64_t *> wires;        // pack witness index -> page-locked copy of the wire matrix
-  size_t parity_checked = 0, proofs = 0, groth16_proofs = 0;
+  size_t parity_checked = 0, proofs = 0, groth16_proofs = 0, launches = 0;
   Groth16Stage groth16;
   bool has_groth16 = false;
   cp_batcher *batcher = nullptr;  // --callers: several threads share this worker and prove one job per call through it
@@ -283,14 +290,23 @@ struct Worker {
       wires.push_back((uint64_t *)pinned);
     }
   }
-  // proves one (circuit, witness) binding `count` times as ONE batch; every proof is compared with the recorded bytes.
-  // Returns the proofs (all equal: same circuit, same witness, smallest proof-of-work witness).
-  std::vector<std::vector<uint8_t>> prove_stage(const qb::Binding &b, size_t count) {
-    const qb::Witness &wt = *pack->witnesses[b.witness];
-    std::vector<cp_circuit *> cc(count, circuits[b.circuit]);
-    std::vector<const uint64_t *> pis(count, wt.public_inputs.data()), ws(count, wires[b.witness]);
-    std::vector<size_t> npi(count, wt.public_inputs.size()), lens(count);
+  // one proof to make: a circuit of the pack on one of its witnesses
+  struct Item { int circuit, witness; };
+  // Proves `items` as ONE batch (they must be batch-compatible) and holds every proof against the bytes that passed the
+  // gate for its witness (Shared::expected; empty while the gate itself runs). Returns the proofs.
+  std::vector<std::vector<uint8_t>> prove_items(const std::vector<Item> &items, const std::vector<std::vector<uint8_t>> *expected) {
+    const size_t count = items.size();
+    std::vector<cp_circuit *> cc(count);
+    std::vector<const uint64_t *> pis(count), ws(count);
+    std::vector<size_t> npi(count), lens(count);
     std::vector<uint8_t *> out(count, nullptr);
+    for (size_t i = 0; i < count; i++) {
+      const qb::Witness &wt = *pack->witnesses[items[i].witness];
+      cc[i] = circuits[items[i].circuit];
+      pis[i] = wt.public_inputs.data();
+      npi[i] = wt.public_inputs.size();
+      ws[i] = wires[items[i].witness];
+    }
     if (batcher) {  // the calling thread is one of several sharing this worker: its message is the thread's, not the context's
       for (size_t i = 0; i < count; i++)
         if (cp_batcher_prove(batcher, cc[i], ws[i], pis[i], npi[i], 0, 0, &out[i], &lens[i]) != CP_OK)
@@ -300,20 +316,61 @@ struct Worker {
             "cp_prove_batch_host");
     }
     std::vector<std::vector<uint8_t>> res(count);
-    bool bad = false;
+    int bad = -1;
     size_t checked = 0;
     for (size_t i = 0; i < count; i++) {
       res[i].assign(out[i], out[i] + lens[i]);
       cp_free(out[i]);
-      if (!wt.expected_proof.empty()) {
-        bad = bad || res[i] != wt.expected_proof;
+      if (expected && !(*expected)[items[i].witness].empty()) {
+        if (res[i] != (*expected)[items[i].witness]) bad = (int)i;
         checked++;
       }
     }
     __atomic_fetch_add(&parity_checked, checked, __ATOMIC_RELAXED);  // plain counters, several threads with --callers
     __atomic_fetch_add(&proofs, count, __ATOMIC_RELAXED);
-    if (bad) throw std::runtime_error("proof bytes differ from the bytes recorded in the witness file (circuit " + pack->circuit_files[b.circuit] + ")");
+    __atomic_fetch_add(&launches, (size_t)1, __ATOMIC_RELAXED);
+    if (bad >= 0)
+      throw std::runtime_error("proof bytes differ from the bytes that passed the gate for this witness (circuit " + pack->circuit_files[items[bad].circuit] + ")");
     return res;
+  }
+  // The gate every distinct proof passes before the clock starts: all witnesses of a binding in one batch; a witness file
+  // that records a proof (the CPU oracle's / the Rust prover's) demands those bytes, every other proof must pass cp_verify.
+  // `expected` is filled by the first worker and only compared against by the others.
+  void gate(std::vector<std::vector<uint8_t>> &expected, size_t *oracle_checked, size_t *verified) {
+    for (const auto &kv : pack->by_type)
+      for (const auto &b : kv.second) {
+        std::vector<Item> items;
+        for (int w : b.witnesses) items.push_back({b.circuit, w});
+        const auto proofs_ = prove_items(items, nullptr);
+        for (size_t i = 0; i < items.size(); i++) {
+          const int w = items[i].witness;
+          if (!expected[w].empty()) {  // seen before (another worker, or a witness bound twice)
+            if (proofs_[i] != expected[w]) throw std::runtime_error("two provers disagree on the proof of witness " + std::to_string(w));
+            continue;
+          }
+          const qb::Witness &wt = *pack->witnesses[w];
+          if (!wt.expected_proof.empty()) {
+            if (proofs_[i] != wt.expected_proof)
+              throw std::runtime_error("proof bytes differ from the bytes recorded in the witness file (circuit " + pack->circuit_files[b.circuit] + ")");
+            if (oracle_checked) ++*oracle_checked;
+          } else {
+            if (cp_verify(circuits[b.circuit], proofs_[i].data(), proofs_[i].size()) != CP_OK)
+              throw std::runtime_error(std::string("cp_verify rejects a proof of ") + pack->circuit_files[b.circuit] + ": " + cp_last_error(ctx));
+            if (verified) ++*verified;
+          }
+          expected[w] = proofs_[i];
+        }
+      }
+  }
+  // batch-compatibility classes of the pack's circuits (cp_circuits_batch_compatible against one representative per class)
+  std::vector<int> circuit_classes() const {
+    std::vector<int> cls(circuits.size(), -1), rep;
+    for (size_t c = 0; c < circuits.size(); c++) {
+      for (size_t k = 0; k < rep.size() && cls[c] < 0; k++)
+        if (cp_circuits_batch_compatible(circuits[c], circuits[rep[k]]) == 1) cls[c] = (int)k;
+      if (cls[c] < 0) { cls[c] = (int)rep.size(); rep.push_back((int)c); }
+    }
+    return cls;
   }
   void close() {
     if (batcher) cp_batcher_destroy(batcher);
@@ -339,8 +396,24 @@ std::vector<uint8_t> zero_groth16_bincode() {
 }
 
 // process_job (actors/simple.rs:57-115) for a batch of jobs of one circuit type, or a single non-proving job
-void process_batch(const Options &opt, Scheduler &S, Worker *worker, const qb::Pack *pack, const std::vector<QueueEntry> &batch) {
+// what every worker of a run shares, read-only while it runs
+struct Shared {
+  const qb::Pack *pack = nullptr;
+  std::vector<int> circuit_class;                       // pack circuit -> batch-compatibility class
+  std::vector<std::vector<uint8_t>> expected;           // pack witness -> the proof bytes that passed the gate
+  std::vector<std::unordered_map<JobId, size_t, qb::JobIdHash>> ordinals;  // per dump: proving job -> its index among the block's jobs of its type
+};
+
+void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Shared &shared, const std::vector<QueueEntry> &batch) {
   const JobId first = batch[0].job;
+  const qb::Pack *pack = shared.pack;
+  const std::vector<int> &circuit_class = shared.circuit_class;
+  const std::vector<std::vector<uint8_t>> *expected = &shared.expected;
+  auto job_ordinal = [&](const QueueEntry &e) -> size_t {
+    const auto &m = shared.ordinals[e.inst->dump_index];
+    auto it = m.find(e.job);
+    return it == m.end() ? 0 : it->second;
+  };
   const double t0 = now_s();
   std::vector<std::vector<uint8_t>> outputs(batch.size());
   if (first.topic == qb::GenerateStandardProof) {
@@ -351,18 +424,43 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const qb::P
       for (const JobId &dep : qb::proof_dependencies(e.job, w))
         if (e.inst->store.get_bytes(dep).empty()) throw qb::StoreError("Proof " + dep.hex() + " needed by " + e.job.hex() + " is empty");
     }
-    const int n_stages = qb::proofs_per_job(first.circuit_type);
     if (!opt.dry_run) {
-      const auto &stages = pack->stages_for(first.circuit_type);
-      if ((int)stages.size() != n_stages)
-        throw std::runtime_error("the pack binds " + std::to_string(stages.size()) + " stages to circuit type " + std::to_string(first.circuit_type) +
-                                 ", the job proves " + std::to_string(n_stages));
-      for (int s = 0; s < n_stages; s++) {  // the stages of a job are a chain: stage s + 1 verifies the proof of stage s
-        auto proofs = worker->prove_stage(stages[s], batch.size());
-        if (s + 1 == n_stages) outputs = std::move(proofs);
+      // the stages of a job are a chain (stage s + 1 verifies the proof of stage s); the jobs of a batch may be of different
+      // types with different numbers of stages: stage s is proved for every job that has one, one launch per
+      // batch-compatibility class of the stage's circuit
+      int max_stages = 0;
+      std::vector<const std::vector<qb::Binding> *> st(batch.size());
+      for (size_t i = 0; i < batch.size(); i++) {
+        const uint8_t ct = batch[i].job.circuit_type;
+        st[i] = &pack->stages_for(ct);
+        if ((int)st[i]->size() != qb::proofs_per_job(ct))
+          throw std::runtime_error("the pack binds " + std::to_string(st[i]->size()) + " stages to circuit type " + std::to_string(ct) +
+                                   ", the job proves " + std::to_string(qb::proofs_per_job(ct)));
+        max_stages = std::max(max_stages, (int)st[i]->size());
+      }
+      for (int s = 0; s < max_stages; s++) {
+        std::vector<std::pair<int, size_t>> order;  // (class of the stage's circuit, position in the batch)
+        for (size_t i = 0; i < batch.size(); i++)
+          if (s < (int)st[i]->size()) order.push_back({circuit_class[(*st[i])[s].circuit], i});
+        std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+        for (size_t lo = 0; lo < order.size();) {
+          size_t hi = lo;
+          std::vector<Worker::Item> items;
+          while (hi < order.size() && order[hi].first == order[lo].first) {
+            const size_t i = order[hi].second;
+            const qb::Binding &b = (*st[i])[s];
+            items.push_back({b.circuit, b.witness_for(job_ordinal(batch[i]))});
+            hi++;
+          }
+          auto proofs = worker->prove_items(items, expected);
+          for (size_t k = lo; k < hi; k++)
+            if (s + 1 == (int)st[order[k].second]->size()) outputs[order[k].second] = std::move(proofs[k - lo]);
+          lo = hi;
+        }
       }
     } else {
       for (auto &o : outputs) o.assign(1, 0);  // placeholder: "an output exists"
+      if (opt.dry_job_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(opt.dry_job_us));
     }
     if (first.circuit_type == qb::WrapFinalSigHashProofBLS12381)
       for (size_t i = 0; i < outputs.size(); i++) {
@@ -405,11 +503,12 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const qb::P
   }
 }
 
-void worker_loop(const Options &opt, Scheduler &S, Worker *worker, const qb::Pack *pack, size_t take) {
+void worker_loop(const Options &opt, Scheduler &S, Worker *worker, const Shared &shared, size_t take, std::atomic<size_t> *jobs_of_slot) {
   std::vector<QueueEntry> batch;
   while (S.take(take, batch)) {
     try {
-      process_batch(opt, S, worker, pack, batch);
+      process_batch(opt, S, worker, shared, batch);
+      if (jobs_of_slot && batch[0].job.topic == qb::GenerateStandardProof) jobs_of_slot->fetch_add(batch.size());
     } catch (const std::exception &e) {
       S.fail(e.what());
     }
@@ -449,6 +548,34 @@ std::string json_escape(const std::string &s) {
   return o;
 }
 
+// every proving job of a block, found by walking the planned DAG from its leaves, numbered per circuit type in the order of
+// the 24-byte ids: the k-th job of a type proves the k-th witness the pack binds to that type
+std::unordered_map<JobId, size_t, qb::JobIdHash> job_ordinals(const qb::ProofStore &store, const std::vector<JobId> &leaves) {
+  std::unordered_map<JobId, size_t, qb::JobIdHash> seen;
+  std::deque<JobId> q(leaves.begin(), leaves.end());
+  std::vector<JobId> proving;
+  while (!q.empty()) {
+    const JobId j = q.front();
+    q.pop_front();
+    if (seen.count(j)) continue;
+    seen[j] = 0;
+    if (j.topic == qb::GenerateStandardProof) proving.push_back(j);
+    if (j.topic == qb::NotifyOrchestratorComplete) continue;
+    if (store.has(j.next_jobs_id_of_counter()))
+      for (const JobId &nj : store.get_next_jobs(j)) q.push_back(nj);
+  }
+  std::sort(proving.begin(), proving.end(), [](const JobId &a, const JobId &b) {
+    return a.circuit_type != b.circuit_type ? a.circuit_type < b.circuit_type : a.hex() < b.hex();
+  });
+  std::unordered_map<JobId, size_t, qb::JobIdHash> ord;
+  size_t k = 0;
+  for (size_t i = 0; i < proving.size(); i++) {
+    k = (i > 0 && proving[i].circuit_type == proving[i - 1].circuit_type) ? k + 1 : 0;
+    ord[proving[i]] = k;
+  }
+  return ord;
+}
+
 int run_qbench(const Options &opt) {
   if (opt.inputs.empty()) die("-i/--input: at least one dump");
   std::vector<qb::Dump> dumps;
@@ -479,6 +606,13 @@ int run_qbench(const Options &opt) {
 
   // circuit pack + workers
   qb::Pack pack;
+  Shared shared;
+  shared.pack = &pack;
+  for (size_t d = 0; d < dumps.size(); d++) {
+    size_t first_instance = d * (size_t)opt.iterations;
+    shared.ordinals.push_back(job_ordinals(instances[first_instance]->store, leaves[first_instance]));
+  }
+  size_t oracle_checked = 0, verified = 0;
   std::vector<Worker> workers;
   std::vector<int> devices = opt.devices;
   if (!opt.dry_run) {
@@ -500,16 +634,18 @@ int run_qbench(const Options &opt) {
         workers[w].index = (int)w;
         workers[w].open(pack, devices[w / (size_t)opt.contexts], opt.lanes);
       }
-      // warm-up = parity gate: every binding once on every worker (allocations, staging ring; bytes == recorded bytes)
+      // warm-up = the gate every distinct proof passes before the clock starts (allocations and the staging ring come with it)
+      shared.circuit_class = workers[0].circuit_classes();
+      shared.expected.assign(pack.witnesses.size(), {});
       for (auto &w : workers) {
-        for (const auto &kv : pack.by_type)
-          for (const auto &b : kv.second) w.prove_stage(b, 1);
+        w.gate(shared.expected, &oracle_checked, &verified);
         if (opt.groth16_log > 0) {
           w.groth16.open(w.ctx, opt.groth16_log);
           w.has_groth16 = true;
           w.groth16.prove(w.ctx, 0);
         }
       }
+      for (auto &w : workers) { w.parity_checked = 0; w.proofs = 0; w.launches = 0; }
     } catch (const std::exception &e) {
       die(e.what());
     }
@@ -523,9 +659,20 @@ int run_qbench(const Options &opt) {
       if (!w.batcher) die(std::string("cp_batcher_create: ") + cp_last_error(nullptr));
     }
   }
-  const size_t n_workers = opt.dry_run ? (size_t)std::max(1, opt.contexts) : workers.size() * per_worker;
+  const size_t n_workers = opt.dry_run ? (opt.devices.empty() ? (size_t)std::max(1, opt.contexts) : opt.devices.size() * (size_t)opt.contexts)
+                                       : workers.size() * per_worker;
 
   Scheduler S;
+  if (!opt.dry_run)
+    for (const auto &kv : pack.by_type)
+      if (kv.first >= 0 && !kv.second.empty()) S.type_class[kv.first] = shared.circuit_class[kv.second[0].circuit];
+  if (!opt.dry_run && pack.by_type.count(-1))
+    for (int t = 0; t < 256; t++)
+      if (!pack.by_type.count(t)) S.type_class[t] = shared.circuit_class[pack.by_type.at(-1)[0].circuit];
+  // --dry-run --devices a,b,...: the worker -> device assignment of a multi-GPU run without any GPU (one slot per device x context)
+  const size_t dry_slots = opt.dry_run && !opt.devices.empty() ? opt.devices.size() * (size_t)opt.contexts : 0;
+  std::vector<std::atomic<size_t>> slot_jobs(dry_slots ? dry_slots : 1);
+  for (auto &a : slot_jobs) a = 0;
   const double t_begin = now_s();
   // instances are started in waves of --blocks-in-flight; the next wave starts when the queue has drained
   size_t next = 0;
@@ -549,8 +696,8 @@ int run_qbench(const Options &opt) {
     std::vector<std::thread> threads;
     for (size_t w = 0; w < n_workers; w++)
       threads.emplace_back([&, w] {
-        worker_loop(opt, S, opt.dry_run ? nullptr : &workers[w / per_worker], opt.dry_run ? nullptr : &pack,
-                    opt.callers > 0 && !opt.dry_run ? 1 : (size_t)opt.batch);
+        worker_loop(opt, S, opt.dry_run ? nullptr : &workers[w / per_worker], shared,
+                    opt.callers > 0 && !opt.dry_run ? 1 : (size_t)opt.batch, dry_slots ? &slot_jobs[w] : nullptr);
       });
     for (auto &t : threads) t.join();
     if (opt.ref_counters && !S.failed && !instances[next]->complete) {
@@ -595,20 +742,36 @@ int run_qbench(const Options &opt) {
     jobs += inst->jobs_done;
     proofs += inst->proofs_done;
   }
-  size_t groth16_proofs = 0;
-  for (const auto &w : workers) { parity += w.parity_checked; groth16_proofs += w.groth16_proofs; }
+  size_t groth16_proofs = 0, launches = 0, launched = 0;
+  for (const auto &w : workers) { parity += w.parity_checked; groth16_proofs += w.groth16_proofs; launches += w.launches; launched += w.proofs; }
+  std::string per_device = "null";
+  if (dry_slots) {  // jobs taken by the worker slots of each device
+    per_device = "{";
+    for (size_t d = 0; d < opt.devices.size(); d++) {
+      size_t n = 0;
+      for (int c = 0; c < opt.contexts; c++) n += slot_jobs[d * (size_t)opt.contexts + (size_t)c].load();
+      per_device += (d ? ", \"" : "\"") + std::to_string(opt.devices[d]) + "\": " + std::to_string(n);
+    }
+    per_device += "}";
+  }
+  int n_classes = 0;
+  for (int c : shared.circuit_class) n_classes = std::max(n_classes, c + 1);
   const double wall = t_end - t_begin;
   std::string devs;
   for (size_t i = 0; i < devices.size(); i++) devs += (i ? "," : "") + std::to_string(devices[i]);
   printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"%s\", \"dumps\": %zu, \"iterations\": %d, \"blocks\": %zu, \"blocks_complete\": %zu, "
          "\"jobs\": %zu, \"proofs\": %zu, \"jobs_per_block\": %.1f, \"proofs_per_block\": %.1f, \"wall_s\": %.6f, \"blocks_per_s\": %.4f, "
          "\"proofs_per_s\": %.2f, \"mean_block_latency_ms\": %.2f, \"devices\": [%s], \"contexts_per_device\": %d, \"workers\": %zu, "
-         "\"callers_per_context\": %d, \"lanes_per_context\": %d, \"linger_us\": %d, \"max_batch\": %d, \"blocks_in_flight\": %d, \"proofs_byte_checked\": %zu, \"groth16_proofs\": %zu, \"groth16_log_constraints\": %d, \"pack\": \"%s\", \"timed\": \"from the first enqueue to the "
+         "\"callers_per_context\": %d, \"lanes_per_context\": %d, \"linger_us\": %d, \"max_batch\": %d, \"blocks_in_flight\": %d, \"proofs_byte_checked\": %zu, \"distinct_proofs\": %zu, \"distinct_proofs_equal_to_recorded_bytes\": %zu, \"distinct_proofs_cp_verified\": %zu, "
+         "\"circuits\": %zu, \"witnesses\": %zu, \"batch_classes\": %d, \"launches\": %zu, \"mean_batch\": %.2f, \"dry_run_jobs_per_device\": %s, "
+         "\"groth16_proofs\": %zu, \"groth16_log_constraints\": %d, \"pack\": \"%s\", \"timed\": \"from the first enqueue to the "
          "last completion; circuits resident, witnesses page-locked on the host (PCIe-inclusive), witness generation excluded\"}\n",
          opt.dry_run ? "dry-run" : "qbench", dumps.size(), opt.iterations, instances.size(), complete, jobs, proofs,
          instances.empty() ? 0.0 : (double)jobs / instances.size(), instances.empty() ? 0.0 : (double)proofs / instances.size(), wall,
          wall > 0 ? complete / wall : 0.0, wall > 0 ? proofs / wall : 0.0, complete ? latency_sum / complete * 1e3 : 0.0, devs.c_str(), opt.contexts,
-         n_workers, opt.dry_run ? 0 : opt.callers, opt.lanes, opt.linger_us, opt.batch, opt.blocks_in_flight, parity, groth16_proofs, opt.groth16_log, json_escape(opt.pack_dir).c_str());
+         n_workers, opt.dry_run ? 0 : opt.callers, opt.lanes, opt.linger_us, opt.batch, opt.blocks_in_flight, parity, oracle_checked + verified,
+         oracle_checked, verified, pack.circuit_files.size(), pack.witnesses.size(), n_classes, launches, launches ? (double)launched / launches : 0.0,
+         per_device.c_str(), groth16_proofs, opt.groth16_log, json_escape(opt.pack_dir).c_str());
   for (auto &w : workers) w.close();
   return complete == instances.size() || opt.ref_counters ? 0 : 1;
 }
@@ -627,16 +790,31 @@ int run_throughput(const Options &opt) {
   } catch (const std::exception &e) {
     die(std::string("circuit pack: ") + e.what());
   }
-  std::vector<qb::Binding> bindings;
-  for (const auto &kv : pack.by_type)
-    for (const auto &b : kv.second) bindings.push_back(b);
   std::vector<Worker> workers(devices.size() * (size_t)opt.contexts);
+  std::vector<std::vector<uint8_t>> expected(pack.witnesses.size());
+  std::vector<Worker::Item> pairs;  // every distinct (circuit, witness) of the pack's largest batch-compatibility class
+  size_t oracle_checked = 0, verified = 0;
   try {
     for (size_t w = 0; w < workers.size(); w++) {
       workers[w].index = (int)w;
       workers[w].open(pack, devices[w / (size_t)opt.contexts], opt.lanes);
-      for (const auto &b : bindings) workers[w].prove_stage(b, 1);
-      workers[w].prove_stage(bindings[0], (size_t)opt.batch);  // the staging buffers of the full batch size
+      workers[w].gate(expected, &oracle_checked, &verified);
+    }
+    const std::vector<int> cls = workers[0].circuit_classes();
+    std::vector<size_t> per_class;
+    for (size_t wi = 0; wi < pack.witnesses.size(); wi++) {
+      const int c = cls[pack.witness_circuit[wi]];
+      if ((size_t)c >= per_class.size()) per_class.resize(c + 1, 0);
+      per_class[c]++;
+    }
+    const int best = (int)(std::max_element(per_class.begin(), per_class.end()) - per_class.begin());
+    for (size_t wi = 0; wi < pack.witnesses.size(); wi++)
+      if (cls[pack.witness_circuit[wi]] == best) pairs.push_back({pack.witness_circuit[wi], (int)wi});
+    for (auto &w : workers) {
+      std::vector<Worker::Item> full;
+      for (int j = 0; j < opt.batch; j++) full.push_back(pairs[(size_t)j % pairs.size()]);
+      w.prove_items(full, &expected);  // the staging buffers of the full batch size
+      w.parity_checked = 0;
     }
   } catch (const std::exception &e) {
     die(e.what());
@@ -656,7 +834,11 @@ int run_throughput(const Options &opt) {
         cv.wait(l, [&] { return go; });
       }
       try {
-        for (int it = 0; it < opt.iters; it++) workers[w].prove_stage(bindings[(w + it) % bindings.size()], (size_t)opt.batch);
+        for (int it = 0; it < opt.iters; it++) {  // a batch = opt.batch consecutive distinct proofs of the pack, a different window every time
+          std::vector<Worker::Item> items;
+          for (int j = 0; j < opt.batch; j++) items.push_back(pairs[((w * (size_t)opt.iters + (size_t)it) * (size_t)opt.batch + (size_t)j) % pairs.size()]);
+          workers[w].prove_items(items, &expected);
+        }
       } catch (const std::exception &e) {
         std::lock_guard<std::mutex> l(m);
         error = e.what();
@@ -677,8 +859,9 @@ int run_throughput(const Options &opt) {
   for (const auto &w : workers) parity += w.parity_checked;
   printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"throughput\", \"devices\": %zu, \"contexts_per_device\": %d, \"lanes_per_context\": %d, "
          "\"max_batch\": %d, \"proofs\": %zu, \"wall_s\": %.6f, \"proofs_per_s\": %.2f, \"blocks_per_s\": %.3f, \"proofs_byte_checked\": %zu, "
+         "\"distinct_proofs\": %zu, \"distinct_proofs_equal_to_recorded_bytes\": %zu, \"distinct_proofs_cp_verified\": %zu, "
          "\"wires\": \"host (page-locked), PCIe-inclusive\"}\n",
-         devices.size(), opt.contexts, opt.lanes, opt.batch, proofs, dt, proofs / dt, proofs / dt / 64.0, parity);
+         devices.size(), opt.contexts, opt.lanes, opt.batch, proofs, dt, proofs / dt, proofs / dt / 64.0, parity, pairs.size(), oracle_checked, verified);
   for (auto &w : workers) w.close();
   return 0;
 }
@@ -700,15 +883,16 @@ int run_callers(const Options &opt_in) {
   } catch (const std::exception &e) {
     die(std::string("circuit pack: ") + e.what());
   }
-  std::vector<qb::Binding> bindings;
-  for (const auto &kv : pack.by_type)
-    for (const auto &b : kv.second) bindings.push_back(b);
+  std::vector<Worker::Item> bindings;  // every distinct (circuit, witness) pair of the pack
+  for (size_t wi = 0; wi < pack.witnesses.size(); wi++) bindings.push_back({pack.witness_circuit[wi], (int)wi});
   std::vector<Worker> workers(devices.size() * (size_t)opt.contexts);
   std::vector<cp_batcher *> batchers(workers.size(), nullptr);
+  std::vector<std::vector<uint8_t>> expected(pack.witnesses.size());
   try {
     for (size_t w = 0; w < workers.size(); w++) {
       workers[w].index = (int)w;
       workers[w].open(pack, devices[w / (size_t)opt.contexts], opt.lanes);
+      workers[w].gate(expected, nullptr, nullptr);   // recorded bytes or cp_verify: what the callers' proofs are compared with
       batchers[w] = cp_batcher_create(workers[w].ctx, (size_t)opt.batch, (unsigned)opt.linger_us);
       if (!batchers[w]) throw std::runtime_error(std::string("cp_batcher_create: ") + cp_last_error(nullptr));
     }
@@ -722,17 +906,18 @@ int run_callers(const Options &opt_in) {
     Worker &wk = workers[t % workers.size()];
     try {
       for (int it = 0; it < iters; it++) {
-        const qb::Binding &b = bindings[(t + (size_t)it) % bindings.size()];
+        const Worker::Item &b = bindings[(t + (size_t)it) % bindings.size()];
         const qb::Witness &wt = *pack.witnesses[b.witness];
         uint8_t *out = nullptr;
         size_t len = 0;
         if (cp_batcher_prove(batchers[t % workers.size()], wk.circuits[b.circuit], wk.wires[b.witness], wt.public_inputs.data(),
                              wt.public_inputs.size(), 0, 0, &out, &len) != CP_OK)
           throw std::runtime_error(std::string("cp_batcher_prove: ") + cp_last_error(nullptr));
-        const bool same = wt.expected_proof.empty() || (len == wt.expected_proof.size() && memcmp(out, wt.expected_proof.data(), len) == 0);
+        const std::vector<uint8_t> &want = expected[b.witness];
+        const bool same = len == want.size() && memcmp(out, want.data(), len) == 0;
         cp_free(out);
-        if (!same) throw std::runtime_error("proof bytes differ from the bytes recorded in the witness file");
-        if (!wt.expected_proof.empty()) parity++;
+        if (!same) throw std::runtime_error("proof bytes differ from the bytes that passed the gate for this witness");
+        parity++;
       }
     } catch (const std::exception &e) {
       std::lock_guard<std::mutex> l(m);
@@ -745,7 +930,7 @@ int run_callers(const Options &opt_in) {
     for (auto &t : threads) t.join();
     if (!error.empty()) die(error);
   };
-  run((int)bindings.size());  // warm-up: every caller through every binding (allocations, staging buffers of the batch sizes met)
+  run(std::min((int)bindings.size(), 8));  // warm-up: staging buffers of the batch sizes met
   std::vector<cp_batcher_stats> before(workers.size());
   for (size_t w = 0; w < workers.size(); w++) cp_batcher_get_stats(batchers[w], &before[w]);
   parity = 0;
@@ -797,6 +982,7 @@ int main(int argc, char **argv) {
     else if (a == "--trace") opt.trace_path = val();
     else if (a == "--groth16-log-size") opt.groth16_log = atoi(val().c_str());
     else if (a == "--dry-run") opt.dry_run = true;
+    else if (a == "--dry-run-job-us") opt.dry_job_us = atoi(val().c_str());
     else if (a == "--ref-counters") opt.ref_counters = true;
     else if (a == "--check-plan") opt.check_plan = true;
     else if (a == "--devices") {

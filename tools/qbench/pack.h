@@ -7,8 +7,10 @@
 // (job type, stage) comes with the wire matrix to prove.
 //
 // pack.manifest, one binding per line ('#' starts a comment):
-//     <circuit_type | default> <stage> <circuit file> <witness file>
-// stage s of a job of that type proves <circuit file> on <witness file>; `default` binds every type not listed.
+//     <circuit_type | default> <stage> <circuit file> <witness file> [<witness file> ...]
+// stage s of a job of that type proves <circuit file>; the k-th job of that type in a block (jobs ordered by their 24-byte
+// id) proves it on the (k mod number of witnesses)-th witness file — SURVEY.md section 8(d) M1: one witness per job, "seed =
+// job index". `default` binds every type not listed.
 //
 // .cpwit (cityprover/files.py writes the same): "CPWITNv1" | u32 version = 1 | u32 flags (bit 0: proof bytes present) |
 // u64 circuit_digest[4] | u32 num_wires, u32 degree_bits, u32 n_public_inputs, u32 0 | public inputs | wires
@@ -74,7 +76,11 @@ inline Witness load_witness(const std::string &path) {
   return w;
 }
 
-struct Binding { int circuit = -1, witness = -1; };  // indices into Pack::circuit_files / Pack::witnesses
+struct Binding {
+  int circuit = -1;             // index into Pack::circuit_files
+  std::vector<int> witnesses;   // indices into Pack::witnesses, one per job of this type in a block (at least one)
+  int witness_for(size_t job_ordinal) const { return witnesses[job_ordinal % witnesses.size()]; }
+};
 
 struct Pack {
   std::string dir;
@@ -107,7 +113,7 @@ inline Pack load_pack(const std::string &dir, bool with_witnesses = true) {
     std::string type, cfile, wfile;
     int stage;
     if (!(ls >> type)) continue;
-    if (!(ls >> stage >> cfile >> wfile) || stage < 0 || stage > 15) throw ParseError("pack.manifest:" + std::to_string(lineno) + ": expected <type> <stage> <circuit> <witness>");
+    if (!(ls >> stage >> cfile >> wfile) || stage < 0 || stage > 15) throw ParseError("pack.manifest:" + std::to_string(lineno) + ": expected <type> <stage> <circuit> <witness>...");
     int t = -1;
     if (type != "default") {
       char *end = nullptr;
@@ -116,16 +122,21 @@ inline Pack load_pack(const std::string &dir, bool with_witnesses = true) {
       t = (int)v;
     }
     if (!circ_idx.count(cfile)) { circ_idx[cfile] = (int)p.circuit_files.size(); p.circuit_files.push_back(dir + "/" + cfile); }
-    if (!wit_idx.count(wfile)) {
-      wit_idx[wfile] = (int)p.witnesses.size();
-      p.witnesses.push_back(with_witnesses ? std::make_shared<Witness>(load_witness(dir + "/" + wfile)) : nullptr);
-      p.witness_circuit.push_back(circ_idx[cfile]);
-    } else if (p.witness_circuit[wit_idx[wfile]] != circ_idx[cfile]) {
-      throw ParseError("pack.manifest:" + std::to_string(lineno) + ": witness " + wfile + " is bound to two circuits");
-    }
+    Binding b;
+    b.circuit = circ_idx[cfile];
+    do {
+      if (!wit_idx.count(wfile)) {
+        wit_idx[wfile] = (int)p.witnesses.size();
+        p.witnesses.push_back(with_witnesses ? std::make_shared<Witness>(load_witness(dir + "/" + wfile)) : nullptr);
+        p.witness_circuit.push_back(circ_idx[cfile]);
+      } else if (p.witness_circuit[wit_idx[wfile]] != circ_idx[cfile]) {
+        throw ParseError("pack.manifest:" + std::to_string(lineno) + ": witness " + wfile + " is bound to two circuits");
+      }
+      b.witnesses.push_back(wit_idx[wfile]);
+    } while (ls >> wfile);
     auto &st = p.by_type[t];
     if ((int)st.size() != stage) throw ParseError("pack.manifest:" + std::to_string(lineno) + ": stages of a type must be listed in order from 0");
-    st.push_back({circ_idx[cfile], wit_idx[wfile]});
+    st.push_back(b);
   }
   if (p.by_type.empty()) throw ParseError("pack.manifest binds nothing");
   return p;
