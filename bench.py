@@ -33,7 +33,55 @@ VALU_PEAK_TLOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # = 78.6 T lane-ops/s; only an al
 # the sources that define the kernels whose PMC counters are stored under profiles/: the stored counts are used only
 # when the hash of these files is the one they were collected with (tools/pmc_summary.py writes it)
 KERNEL_SOURCES = ["gl.h", "poseidon.h", "poseidon_tables.h", "merkle.h", "ntt.h", "ntt16.h"]
-PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
+PMC_QBENCH_JSON = os.path.join(ROOT, "profiles", "r03_pmc_qbench.json")
+
+
+def permutations_per_proof():
+    """Poseidon permutations of one proof at the product shape: leaf hashes of the three
+    oracles over the 2^15 LDE rows, their tree levels down to the 16-entry cap, the two FRI layers, the expected proof-of-work
+    search (2^16 candidates) and the transcript."""
+    N, cap = 1 << 15, 16
+    leaves = N * sum((k + 7) // 8 for k in (135, 20, 16))
+    levels = 3 * (N - cap)
+    fri = sum((n >> 4) * 4 + ((n >> 4) - cap) for n in (N, N >> 4))   # leaf = 16 ext = 32 felts = 4 permutations
+    return leaves + levels + fri + (1 << 16) + 115
+
+
+def qbench_roofline(qb, poseidon_rate):
+    """M1 against the roofline that bounds it: the proving path is Poseidon — integer-VALU issue — so proofs/s is priced in
+    permutation-equivalents against the permutation rate the leaf hash reaches in THIS run, with the whole path's VALU lane-ops
+    and HBM bytes per proof from a rocprofv3 --pmc pass of the harness (tools/profile_r03.sh -> profiles/r03_pmc_qbench.json,
+    used only when it was collected with the kernel sources as they are now)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    ppp = permutations_per_proof()
+    rate = qb["proofs_per_s"] * ppp
+    out = {"bound": "valu-issue (Poseidon)", "unit": "G permutation-equivalents/s", "permutations_per_proof": ppp,
+           "achieved": rate / 1e9, "peak": poseidon_rate / 1e9 if poseidon_rate else None,
+           "peak_note": "the permutation rate of merkle::k_leaf_hash_cols measured in this run (the headline step's dominant kernel)",
+           "frac": rate / poseidon_rate if poseidon_rate else None}
+    try:
+        import pmc_summary_qbench as P
+        d = json.load(open(PMC_QBENCH_JSON))
+        if d.get("kernel_source_hash") != P.source_hash():
+            out["pmc"] = "refused: profiles/r03_pmc_qbench.json is for other kernel sources (%s, now %s)" % (d.get("kernel_source_hash"), P.source_hash())
+            return out
+    except (OSError, ValueError, ImportError) as e:
+        out["pmc"] = "none: %s" % e
+        return out
+    pp = d["per_proof"]
+    lane_ops_s = pp["valu_lane_ops"] * qb["proofs_per_s"]
+    hbm_s = pp["hbm_bytes"] * qb["proofs_per_s"]
+    out["pmc"] = {"source": os.path.relpath(PMC_QBENCH_JSON, ROOT) + " (kernel source hash %s)" % d["kernel_source_hash"],
+                  "valu_lane_ops_per_proof": pp["valu_lane_ops"], "valu_T_lane_ops_per_s_at_this_rate": lane_ops_s / 1e12,
+                  "valu_frac_of_issue_peak": lane_ops_s / 1e12 / VALU_PEAK_TLOPS,
+                  "hbm_bytes_per_proof": pp["hbm_bytes"], "hbm_GBs_at_this_rate": hbm_s / 1e9, "hbm_frac": hbm_s / 1e9 / HBM_PEAK_GBS,
+                  "algorithmic_bytes_per_proof": 0.16 * (1 << 30), "traffic_over_algorithmic": pp["hbm_bytes"] / (0.16 * (1 << 30)),
+                  "kernel_busy_us_per_proof_one_context": pp["kernel_busy_us"], "quotient": d["quotient"],
+                  "quotient_kernels": {k: {kk: v.get(kk) for kk in ("hbm_bytes_per_proof", "algorithmic_bytes_per_proof", "traffic_over_algorithmic",
+                                                                       "busy_us_per_proof")}
+                                       for k, v in d["kernels"].items() if k.startswith("k_quot")}}
+    return out
 
 
 def kernel_source_hash():
@@ -208,6 +256,52 @@ def native_qbench(device, rank, pack):
                         "STARKs and the 3 Groth16 proofs of a block are outside the build and not in this number"}
 
 
+def all_ranks_or_exit(D, dist, fn, what, cleanup=None):
+    """fn() on every rank; a rank whose fn raises must not leave the others waiting in the next collective: the
+    failure flag is reduced first, and when any rank failed EVERY rank exits non-zero (the --gpus launcher then reports it)."""
+    res, err = None, None
+    try:
+        res = fn()
+    except Exception as e:   # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
+    failed = D.sum_over_ranks(dist, 0.0 if err is None else 1.0)
+    if cleanup:
+        cleanup()
+    if failed:
+        sys.exit("bench.py: %s failed on %d rank(s)%s" % (what, int(failed), "" if err is None else " — this rank: " + err))
+    return res
+
+
+def stub_main(args, D):
+    """CITYPROVER_BENCH_STUB=1: everything of a multi-rank run EXCEPT the GPU section — rank environment, rendezvous, the
+    barrier / max / sum / broadcast of the control plane, the all-ranks-or-exit rule, rank-0-only output — so that the
+    `--gpus N` path can be tested on a box without a GPU (tests/test_dist_gloo.py). CITYPROVER_BENCH_STUB_FAIL=<rank> makes that
+    rank's side measurement raise; CITYPROVER_BENCH_STUB_EXIT=<rank> makes it exit 3 at the very end."""
+    rank, local_rank, world = D.env_rank()
+    dist = D.init("gloo")
+    units = D.shard_units(world, rank, world)
+    D.barrier(dist)
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))   # the slowest rank sets the time
+    D.barrier(dist)
+    elapsed = D.max_over_ranks(dist, time.perf_counter() - t0)
+    token = D.broadcast_str(dist, "pack-of-rank-0" if rank == 0 else None)
+
+    def side():
+        if os.environ.get("CITYPROVER_BENCH_STUB_FAIL") == str(rank):
+            raise RuntimeError("stub failure on rank %d" % rank)
+        return {"units": len(units)}
+    mine = all_ranks_or_exit(D, dist, side, "the stub side measurement")
+    total_units = D.sum_over_ranks(dist, mine["units"])
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "elapsed_s": elapsed,
+                          "units": total_units, "broadcast": token, "local_rank": local_rank}))
+    if dist is not None:
+        dist.destroy_process_group()
+    if os.environ.get("CITYPROVER_BENCH_STUB_EXIT") == str(rank):
+        sys.exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,8 +334,10 @@ def main():
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
 
-    import cityprover as cp
     from cityprover import dist as D
+    if os.environ.get("CITYPROVER_BENCH_STUB"):
+        return stub_main(args, D)
+    import cityprover as cp
 
     rank, local_rank, world = D.env_rank()
     dist = D.init("gloo")  # control plane only: barrier + max-reduce of the timing, no data path
@@ -342,17 +438,8 @@ def main():
             pack = tempfile.mkdtemp(prefix="cityprover_pack_")
             make_circuit_pack.make_pack(pack, db=12, n_checked=8)
         pack = D.broadcast_str(dist, pack)
-        # a rank whose harness fails must not leave the others in a barrier: the status is reduced first
-        mine, err = None, None
-        try:
-            mine = native_qbench(device, rank, pack)
-        except Exception as e:   # noqa: BLE001
-            err = "%s: %s" % (type(e).__name__, e)
-        failed = D.sum_over_ranks(dist, 0.0 if err is None else 1.0)
-        if rank == 0:
-            shutil.rmtree(pack, ignore_errors=True)
-        if failed:
-            sys.exit("bench.py: the q-bench harness failed on %d rank(s)%s" % (int(failed), "" if err is None else " — this rank: " + err))
+        mine = all_ranks_or_exit(D, dist, lambda: native_qbench(device, rank, pack), "the q-bench harness",
+                                 cleanup=(lambda: shutil.rmtree(pack, ignore_errors=True)) if rank == 0 else None)
         qb = dict(mine)
         for key in ("blocks_per_s", "proofs_per_s", "throughput_mode_proofs_per_s"):
             qb[key] = D.sum_over_ranks(dist, mine[key])
@@ -466,7 +553,7 @@ def main():
             "poseidon_perms_per_s": (perms / (leaf_ms * 1e-3)) if leaf_ms else None,
             "merkle_levels_ms": lvl_ms / args.steps,
             "cpu_baseline": base,
-            "qbench": qb,
+            "qbench": dict(qb, roofline=qbench_roofline(qb, (perms / (leaf_ms * 1e-3)) if leaf_ms else None)) if qb else None,
             "groth16_kernels": g16,
             "stark_commit_fri": stark,
         }

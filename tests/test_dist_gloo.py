@@ -60,3 +60,42 @@ def test_single_process_is_a_noop():
     assert D.init() is None
     assert D.shard_units(5, 0, 1) == [0, 1, 2, 3, 4]
     assert D.max_over_ranks(None, 3.5) == 3.5
+
+
+def _bench(args, env_extra, timeout=300):
+    import subprocess
+    env = dict(os.environ, CITYPROVER_BENCH_STUB="1", **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_branch_spawns_its_ranks_and_only_rank_0_prints():
+    """`python bench.py --gpus N` without a launcher: N ranks of itself, one rendezvous on 127.0.0.1, the control
+    plane's barrier / max / sum / broadcast, ONE JSON line from rank 0 — with a stub in place of the GPU section
+    (CITYPROVER_BENCH_STUB), so that it runs here."""
+    import json
+    for n in (2, 8):
+        r = _bench(["--gpus", str(n), "--steps", "3", "--warmup", "1"], {})
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == n and out["units"] == float(n) and out["broadcast"] == "pack-of-rank-0" and out["local_rank"] == 0
+        assert out["elapsed_s"] >= 0.01 * n            # the slowest rank's time, not rank 0's
+
+
+def test_bench_gpus_branch_propagates_failures_without_hanging():
+    # a rank whose side measurement raises: EVERY rank leaves (nobody waits in the next collective), the launcher exits non-zero
+    r = _bench(["--gpus", "4"], {"CITYPROVER_BENCH_STUB_FAIL": "2"}, timeout=120)
+    assert r.returncode != 0 and "failed on 1 rank(s)" in r.stderr and "rank exit codes" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # a rank that exits non-zero at the very end: the line is there, the exit code says so all the same
+    r = _bench(["--gpus", "3"], {"CITYPROVER_BENCH_STUB_EXIT": "1"}, timeout=120)
+    assert r.returncode != 0 and "rank exit codes" in r.stderr and "3" in r.stderr
+    # the flag must agree with a launcher's world size
+    env = {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(os.environ, CITYPROVER_BENCH_STUB="1", **env),
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

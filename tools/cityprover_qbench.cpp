@@ -108,7 +108,7 @@ struct Scheduler {
   std::vector<BenchRecord> benchmarks;  // completion order
   std::vector<JobId> processed;        // every job popped, in pop order (barrier and notify jobs included)
   int type_class[256] = {0};           // circuit type -> batch-compatibility class of its first stage's circuit
-  size_t launches = 0, launched_proofs = 0;  // cp_prove_batch_host calls of the timed run and the proofs they carried
+  size_t n_workers = 1;                // threads draining the queue
 
   void enqueue(Instance *inst, const std::vector<JobId> &jobs) {
     std::lock_guard<std::mutex> l(m);
@@ -144,6 +144,16 @@ struct Scheduler {
     out.push_back(queue.front());
     queue.pop_front();
     const JobId first = out[0].job;
+    if (first.topic == qb::GenerateStandardProof && max_batch > 1 && n_workers > 1) {
+      // a short queue is SHARED among the workers instead of going to whoever woke first: with one block in flight, twenty
+      // ready leaves are three launches on three contexts at once, not one launch while two contexts idle; a long queue
+      // (many blocks in flight) still fills every launch to max_batch
+      size_t ready = 1;
+      for (const auto &e : queue)
+        if (e.job.topic == qb::GenerateStandardProof && type_class[e.job.circuit_type] == type_class[first.circuit_type]) ready++;
+      const size_t share = (ready + n_workers - 1) / n_workers;
+      if (share < max_batch) max_batch = share < 1 ? 1 : share;
+    }
     if (first.topic == qb::GenerateStandardProof)
       for (auto it = queue.begin(); it != queue.end() && out.size() < max_batch;) {
         if (it->job.topic == qb::GenerateStandardProof && type_class[it->job.circuit_type] == type_class[first.circuit_type]) {
@@ -416,6 +426,49 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
   };
   const double t0 = now_s();
   std::vector<std::vector<uint8_t>> outputs(batch.size());
+  std::vector<char> done(batch.size(), 0);
+  // the tail of process_job (actors/simple.rs:89-106) for one job of the batch: store the output, record the duration, count,
+  // release what waits for it. Called as soon as the job's LAST stage is proved — a one-proof job does not wait for the five
+  // stages of a sighash job that happened to share its launch.
+  auto finish = [&](size_t i) {
+    if (done[i]) return;
+    done[i] = 1;
+    Instance *inst = batch[i].inst;
+    const JobId job = batch[i].job;
+    if (job.topic == qb::GenerateStandardProof && job.circuit_type == qb::WrapFinalSigHashProofBLS12381) {
+      if (worker && worker->has_groth16) {  // the Groth16 prover kernels on a synthetic key (Groth16Stage)
+        outputs[i] = worker->groth16.prove(worker->ctx, job.goal_id * 16 + job.task_index);
+        worker->groth16_proofs++;
+      } else {
+        outputs[i] = zero_groth16_bincode();  // GROTH16_DISABLED_DEV_MODE (toolbox/root.rs:287-294)
+      }
+    }
+    const double t1 = now_s();
+    const uint64_t ms = (uint64_t)((t1 - t0) * 1e3);
+    std::vector<JobId> release;
+    {
+      std::lock_guard<std::mutex> l(inst->m);
+      if (job.topic == qb::GenerateStandardProof) {
+        inst->store.set_bytes(job.output_id(), outputs[i]);
+        inst->jobs_done++;
+        inst->proofs_done += (size_t)qb::proofs_per_job(job.circuit_type);
+      }
+      if (job.topic == qb::NotifyOrchestratorComplete) {
+        inst->complete = true;
+        inst->t_end = t1;
+      } else {
+        const uint32_t goal = inst->store.get_goal(job);
+        if (goal != 0 && inst->store.inc_counter(job.counter_id()) == goal) release = inst->store.get_next_jobs(job);
+      }
+    }
+    {
+      std::lock_guard<std::mutex> l(S.m);
+      if (job.topic == qb::GenerateStandardProof)
+        S.benchmarks.push_back({job, ms, t0, t1, worker ? worker->index : -1, (int)batch.size(), inst->index});
+      if (job.topic == qb::NotifyOrchestratorComplete) S.pending_instances--;
+    }
+    if (!release.empty()) S.enqueue(inst, release);
+  };
   if (first.topic == qb::GenerateStandardProof) {
     // inputs: the job's witness and every proof it names must be in the store (worker/traits.rs:74-83,164-202)
     for (const auto &e : batch) {
@@ -454,7 +507,10 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
           }
           auto proofs = worker->prove_items(items, expected);
           for (size_t k = lo; k < hi; k++)
-            if (s + 1 == (int)st[order[k].second]->size()) outputs[order[k].second] = std::move(proofs[k - lo]);
+            if (s + 1 == (int)st[order[k].second]->size()) {
+              outputs[order[k].second] = std::move(proofs[k - lo]);
+              finish(order[k].second);
+            }
           lo = hi;
         }
       }
@@ -462,45 +518,8 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
       for (auto &o : outputs) o.assign(1, 0);  // placeholder: "an output exists"
       if (opt.dry_job_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(opt.dry_job_us));
     }
-    if (first.circuit_type == qb::WrapFinalSigHashProofBLS12381)
-      for (size_t i = 0; i < outputs.size(); i++) {
-        if (worker && worker->has_groth16) {  // the Groth16 prover kernels on a synthetic key (Groth16Stage)
-          outputs[i] = worker->groth16.prove(worker->ctx, batch[i].job.goal_id * 16 + batch[i].job.task_index);
-          worker->groth16_proofs++;
-        } else {
-          outputs[i] = zero_groth16_bincode();  // GROTH16_DISABLED_DEV_MODE (toolbox/root.rs:287-294)
-        }
-      }
   }
-  const double t1 = now_s();
-  const uint64_t ms = (uint64_t)((t1 - t0) * 1e3);
-  for (size_t i = 0; i < batch.size(); i++) {
-    Instance *inst = batch[i].inst;
-    const JobId job = batch[i].job;
-    std::vector<JobId> release;
-    {
-      std::lock_guard<std::mutex> l(inst->m);
-      if (job.topic == qb::GenerateStandardProof) {
-        inst->store.set_bytes(job.output_id(), outputs[i]);
-        inst->jobs_done++;
-        inst->proofs_done += (size_t)qb::proofs_per_job(job.circuit_type);
-      }
-      if (job.topic == qb::NotifyOrchestratorComplete) {
-        inst->complete = true;
-        inst->t_end = t1;
-      } else {
-        const uint32_t goal = inst->store.get_goal(job);
-        if (goal != 0 && inst->store.inc_counter(job.counter_id()) == goal) release = inst->store.get_next_jobs(job);
-      }
-    }
-    {
-      std::lock_guard<std::mutex> l(S.m);
-      if (job.topic == qb::GenerateStandardProof)
-        S.benchmarks.push_back({job, ms, t0, t1, worker ? worker->index : -1, (int)batch.size(), inst->index});
-      if (job.topic == qb::NotifyOrchestratorComplete) S.pending_instances--;
-    }
-    if (!release.empty()) S.enqueue(inst, release);
-  }
+  for (size_t i = 0; i < batch.size(); i++) finish(i);
 }
 
 void worker_loop(const Options &opt, Scheduler &S, Worker *worker, const Shared &shared, size_t take, std::atomic<size_t> *jobs_of_slot) {
@@ -694,6 +713,7 @@ int run_qbench(const Options &opt) {
       S.enqueue(&inst, leaves[i]);
     }
     std::vector<std::thread> threads;
+    S.n_workers = n_workers;
     for (size_t w = 0; w < n_workers; w++)
       threads.emplace_back([&, w] {
         worker_loop(opt, S, opt.dry_run ? nullptr : &workers[w / per_worker], shared,

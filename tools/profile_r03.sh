@@ -1,0 +1,40 @@
+#!/bin/bash
+# rocprofv3 evidence of round 3 on the GPU box (run through gpurun from the repo root):
+#   1. --kernel-trace --stats of the bench command                      -> r03_bench_kernel_stats.csv (+ the bench line under rocprof)
+#   2-4. --pmc SQ group / FETCH_SIZE / WRITE_SIZE of the bench command  -> r03_pmc_bench.json
+#   5. --kernel-trace --stats of the native q-bench harness (8 blocks in flight, 3 contexts: the section 8(d) workload) -> r03_prove_kernel_stats.csv
+#   6-8. --pmc passes of the harness in throughput mode, ONE context    -> r03_pmc_qbench.json (per proof: VALU instructions, HBM bytes, quotient traffic)
+# Counter passes run alone (no trace flags: gpurun refuses the combination). The program itself follows `--`.
+set -e
+cd /tmp && export TMPDIR=/tmp
+R="$GRAFT_REPO_ROOT"; [ -z "$R" ] && R=/root/repo
+OUT="$R/gpurun_out/prof_r03"
+rm -rf "$OUT"; mkdir -p "$OUT"
+SQ="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
+if [ "$1" != "qbench-only" ]; then
+BENCH="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-qbench"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
+python3 "$R/tools/rocpd_top_kernels.py" "$OUT/trace" "rocprofv3 --kernel-trace --stats -- $BENCH" > "$OUT/r03_bench_kernel_stats.csv" || true
+PMCB="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-qbench"
+rocprofv3 --pmc $SQ -d "$OUT/pmc_sq" -o pmc --output-format csv -- $PMCB > /dev/null 2> "$OUT/pmc_sq.err"
+rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o pmc --output-format csv -- $PMCB > /dev/null 2> "$OUT/pmc_fetch.err"
+rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o pmc --output-format csv -- $PMCB > /dev/null 2> "$OUT/pmc_write.err"
+mkdir -p "$OUT/benchpmc" && mv "$OUT/pmc_sq" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/benchpmc/"
+python3 "$R/tools/pmc_summary.py" "$OUT/benchpmc" "$OUT/r03_pmc_bench.json" "rocprofv3 --pmc <group> -- $PMCB"
+fi
+# the whole-proof path
+python3 "$R/tools/make_circuit_pack.py" /tmp/prof_pack 0 12 > /dev/null
+QB="$R/tools/cityprover_qbench -i $R/tests/golden/qbench_example.bin -n 8 --blocks-in-flight 8 --pack /tmp/prof_pack --contexts 3 --batch 32"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace_qbench" -o qbench -- $QB > "$OUT/qbench_under_rocprof.json" 2> "$OUT/trace_qbench.err"
+python3 "$R/tools/rocpd_top_kernels.py" "$OUT/trace_qbench" "rocprofv3 --kernel-trace --stats -- tools/cityprover_qbench -i tests/golden/qbench_example.bin -n 8 --blocks-in-flight 8 --pack <section 8(d) pack> --contexts 3 --batch 32" > "$OUT/r03_prove_kernel_stats.csv" || true
+ITERS=4
+QT="$R/tools/cityprover_qbench --mode throughput --pack /tmp/prof_pack --contexts 1 --batch 32 --iters $ITERS"
+PROOFS=$((64 + 32 + 32 * ITERS))   # the gate (64 distinct proofs), one full warm-up batch, the timed batches
+rocprofv3 --pmc $SQ -d "$OUT/qpmc/sq" -o pmc --output-format csv -- $QT > "$OUT/qbench_under_pmc.json" 2> "$OUT/qpmc_sq.err"
+rocprofv3 --pmc FETCH_SIZE -d "$OUT/qpmc/fetch" -o pmc --output-format csv -- $QT > /dev/null 2> "$OUT/qpmc_fetch.err"
+rocprofv3 --pmc WRITE_SIZE -d "$OUT/qpmc/write" -o pmc --output-format csv -- $QT > /dev/null 2> "$OUT/qpmc_write.err"
+python3 "$R/tools/pmc_summary_qbench.py" "$OUT/qpmc" "$OUT/r03_pmc_qbench.json" $PROOFS "rocprofv3 --pmc <group> -- tools/cityprover_qbench --mode throughput --pack <section 8(d) pack> --contexts 1 --batch 32 --iters $ITERS"
+# keep the per-kernel counter CSVs small: one merged CSV per group
+for g in sq fetch write; do f=$(find "$OUT/qpmc/$g" -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/r03_qpmc_${g}_counter_collection.csv"; done
+find "$OUT" -name "*.db" -delete
+du -sh "$OUT"
