@@ -464,7 +464,7 @@ def main():
                "msm_g1_2^20_Mpoints_per_s": m20["Mpoints_per_s"], "msm_g2_2^18_ms": g2["ms"],
                "msm_g2_2^18_checked": g2["checked"], "msm_g2_2^20_ms": g2_20["ms"], "fr_ntt_2^20_forward_ms": f20["forward_ms"],
                "fr_ntt_2^20_inverse_ms": f20["inverse_ms"], "groth16_quotient_2^20_ms": f20["groth16_quotient_ms"],
-               "groth16_prove_2^20_ms": pr20["prove_ms"]}
+               "groth16_prove_2^20_ms": pr20["prove_ms"], "groth16_prove_2^20_checked": pr20["checked"]}
 
     # A13's polynomial-commitment half through the generic seams (cp_batch_commit_dev / cp_fri_prove) at the SHA-256 STARK's
     # shapes, side measurement on rank 0 with cp_fri_verify as its check — tools/bench_stark_fri.py

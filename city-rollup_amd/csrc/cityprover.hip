@@ -797,6 +797,7 @@ int cp_commit_dev(cp_ctx *ctx, const uint64_t *values, size_t k, int log_n, int 
 
 // ---- circuits + proof tail (transcript, openings, FRI, proof bytes) -------------------------------
 #include "fri.h"
+#include "transcript.h"
 #include "zs.h"
 #include "quotient.h"
 #include "prover_tail.inc"

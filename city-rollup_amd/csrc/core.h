@@ -54,6 +54,10 @@ struct cp_ctx {
   // pageable copies block inside the runtime and serialise the contexts of a process
   char *pin = nullptr;
   size_t pin_bytes = 0, pin_off = 0;
+  // device-to-host copies that have been enqueued into the staging area and not yet handed to their destinations: a proving
+  // call enqueues every output (caps, openings, query words, ...) behind its last kernel and synchronises ONCE (fetch_flush)
+  struct PendingFetch { void *host; const char *stage; size_t bytes; };
+  std::vector<PendingFetch> pending_fetches;
   // BLS12-381 F_r twiddle tables (fr_ntt.inc), keyed by (log_n, inverse)
   std::map<std::pair<int, int>, void *> fr_twiddles;
   void *fr_work = nullptr;  // grow-only work array of the F_r NTT

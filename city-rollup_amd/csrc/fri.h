@@ -108,10 +108,10 @@ __global__ __launch_bounds__(256) void k_combine(BatchRefs refs, const Ext *__re
 
 // q = (comp - comp(z)) / (X - z):  q[i] = z^-(i+1) * sum_{j>i} comp[j] z^j ;  q[n-1] = 0.
 // fin = fin * shift + q  (first == 1: fin = q). One workgroup per proof (grid = (1, B)).
-// zpow / zinvpow: tables of the proof's point (stride zstride per proof); fin: [proof][re | im][n].
+// zpow / zinvpow: tables of the proof's point (stride zstride per proof); shifts[proof*shift_stride]; fin: [proof][re | im][n].
 __global__ __launch_bounds__(256) void k_divide_linear_accumulate(const Ext *__restrict__ comp, const Ext *__restrict__ zpow,
                                                                   const Ext *__restrict__ zinvpow, size_t zstride, size_t n,
-                                                                  const Ext *__restrict__ shifts, int first,
+                                                                  const Ext *__restrict__ shifts, size_t shift_stride, int first,
                                                                   uint64_t *__restrict__ fin) {
   __shared__ Ext tot[256];
   const int t = threadIdx.x;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_divide_linear_accumulate(const Ext *__r
   zpow += proof * zstride;
   zinvpow += proof * zstride;
   uint64_t *fin_re = fin + proof * 2 * n, *fin_im = fin_re + n;
-  const Ext shift = shifts[proof];
+  const Ext shift = shifts[proof * shift_stride];
   const size_t per = (n + 255) / 256;
   const size_t lo = (size_t)t * per < n ? (size_t)t * per : n, hi = lo + per < n ? lo + per : n;
   Ext s{0, 0};

@@ -41,7 +41,8 @@ struct Args {
   const uint64_t *k_is;           // [R]
   const uint64_t *chal;           // [proof][2][nc]: betas, gammas
   const uint64_t *apow;           // [proof][nc][n_terms]: alpha_c^t
-  const uint64_t *pi_hash;        // [proof][4]
+  const uint64_t *pi_hash;        // public_inputs_hash of proof p at pi_hash + p*pi_stride (4 elements)
+  size_t pi_stride;
   const uint64_t *zh;             // [2^rb]  Z_H on the coset, and
   const uint64_t *zh_inv;         // [2^rb]  its inverses
   const uint64_t *omega_tab;      // power table of omega_N
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void k_quot_gate(Args a, int gi, int t0) {
     }
   } else {  // the generic constraint code shared with the host verifier (gates.h)
     const uint64_t *consts = cs + (size_t)a.num_selectors * N;
-    const uint64_t *pih = a.pi_hash + proof * 4;
+    const uint64_t *pih = a.pi_hash + proof * a.pi_stride;
     gates::eval_t<TYPE, uint64_t>(
         g, [&](int j) { return w[(size_t)j * N]; }, [&](int j) { return consts[(size_t)j * N]; },
         [&](int j) { return pih[j]; }, [&](int k, uint64_t v) { add_term(v, k); });

@@ -24,8 +24,9 @@ struct Args {
   size_t wires_proof_stride;
   const uint64_t *const *sigmas;  // per proof: [num_routed][n] values over <omega_n>
   const uint64_t *k_is;         // [num_routed]
-  const uint64_t *betas;        // [proof][nc]
-  const uint64_t *gammas;       // [proof][nc]
+  const uint64_t *betas;        // betas[proof*chal_stride + c]
+  const uint64_t *gammas;       // gammas[proof*chal_stride + c]
+  size_t chal_stride;           // nc for two separate [proof][nc] arrays, 2*nc for the transcript's [proof][betas | gammas]
   uint64_t *out;                // [proof][nc*(1+npp)][n], committed order
   size_t out_proof_stride;
   const uint64_t *omega_tab;    // power table of omega_n (ntt::pow_table layout)
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void k_chunk_products(Args a) {
   const size_t proof = blockIdx.z;
   const uint64_t *w = a.wires + proof * a.wires_proof_stride + i;
   const uint64_t *sg = a.sigmas[proof] + i;
-  const uint64_t beta = a.betas[proof * a.nc + c], gamma = a.gammas[proof * a.nc + c];
+  const uint64_t beta = a.betas[proof * a.chal_stride + c], gamma = a.gammas[proof * a.chal_stride + c];
   const uint64_t bx = gl::mul(beta, pow_tab(a.omega_tab, i));
   const int nchunks = a.npp + 1;
   uint64_t num[MAX_CHUNKS], den[MAX_CHUNKS];

@@ -106,6 +106,26 @@ def test_groth16_proof_matches_the_trapdoor(prover, log_n, n_pub, n_in):
         s.free()
 
 
+@pytest.mark.parametrize("log_n", [12, 18, 20])
+def test_groth16_proof_matches_the_trapdoor_at_the_sizes_it_is_timed(prover, log_n):
+    """The tiled digit sort, the heavy-bucket chunks (60 % of the witness is 0 / 1) and the two MSM chains on two contexts only run
+    at large sizes: the assembled (A, B, C) at 2^18 and 2^20 constraints against the closed-form discrete logarithms of the
+    synthetic key (tools/bench_groth16.py `run(check=True)`: every key point is [a i + b] G, so the expected logs are sums over
+    the witness and the quotient coefficients; the quotient itself is held against the polynomial identity at 2^18 by
+    tests/test_gpu_fr_ntt.py)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_groth16
+    res = bench_groth16.run(prover, log_n, reps=1, check=True)
+    assert res["checked"] is True
+    # the exact big-integer sums behind the check, against plain Python on a small slice
+    rng = np.random.default_rng(3)
+    k = rng.integers(0, 2**64, (3000, 4), dtype=np.uint64)
+    ints = [sum(int(k[i, j]) << (64 * j) for j in range(4)) for i in range(3000)]
+    assert bench_groth16.limbs_sum(k) == (sum(ints), sum(i * v for i, v in enumerate(ints)))
+    assert bench_groth16.limbs_sum(k, 17, 2999) == (sum(ints[17:2999]), sum(i * v for i, v in enumerate(ints[17:2999])))
+
+
 def test_groth16_prove_rejects_bad_arguments(prover):
     import cityprover as cp
     _, r, G1 = O.bls_constants()

@@ -15,7 +15,49 @@ import cityprover as cp  # noqa: E402
 from bench_msm import G, G2  # noqa: E402
 
 
-def run(prover, log_n, reps=3):
+R = (lambda x: x**4 - x**2 + 1)(-0xd201000000010000)   # the group order
+
+
+def limbs_sum(k, lo=0, hi=None):
+    """(sum_i k_i, sum_i i * k_i) over rows lo..hi of an (n, 4) uint64 limb array, i counted from 0 at row lo — exact, in numpy:
+    32-bit half-limbs, the index split at 2^10 so that no partial sum passes 2^63"""
+    k = k[lo:hi]
+    idx = np.arange(k.shape[0], dtype=np.uint64)
+    i_lo, i_hi = idx & np.uint64(1023), idx >> np.uint64(10)
+    s0 = s1 = 0
+    for j in range(4):
+        for h in range(2):
+            half = (k[:, j] >> np.uint64(32 * h)) & np.uint64(0xFFFFFFFF)
+            w = 1 << (64 * j + 32 * h)
+            s0 += int(half.sum(dtype=np.uint64)) * w
+            s1 += (int((half * i_lo).sum(dtype=np.uint64)) + (int((half * i_hi).sum(dtype=np.uint64)) << 10)) * w
+    return s0, s1
+
+
+def scalar_mul_g1(prover, log):
+    """[log] G through a one-point MSM (itself held against the CPU oracle by tests/test_gpu_msm.py)"""
+    one = cp.G1Points.synthetic(prover, G, 1, 1, 1)
+    de = prover.to_device(np.array([[(log >> (64 * j)) & (2**64 - 1) for j in range(4)]], dtype=np.uint64))
+    out = one.msm_dev(de.ptr)
+    de.free()
+    one.free()
+    return out
+
+
+def scalar_mul_g2(prover, log):
+    one = cp.G2Points.synthetic(prover, G2, 1, 1, 1)
+    de = prover.to_device(np.array([[(log >> (64 * j)) & (2**64 - 1) for j in range(4)]], dtype=np.uint64))
+    out = one.msm_dev(de.ptr)
+    de.free()
+    one.free()
+    return out
+
+
+def run(prover, log_n, reps=3, check=True):
+    """check: the three proof elements against the trapdoor of the synthetic key — every key point is [a i + b] G with known
+    (a, b), alpha = beta = delta = G, so the discrete logarithm of A, B and C is a closed form in the witness, the quotient
+    coefficients (read back from the device) and r, s:  A = 1 + sum w_i (3 i + 1) + r,  B = 1 + sum w_i (7 i + 3) + s,
+    C = sum_priv w_i (11 i' + 4) + sum h_j (13 j + 5) + s A + r B1 - r s  with B1 = 1 + sum w_i (5 i + 2) + s."""
     n = 1 << log_n
     rng = np.random.default_rng(log_n)
     w = rng.integers(0, 2**64, (n, 4), dtype=np.uint64)
@@ -38,18 +80,34 @@ def run(prover, log_n, reps=3):
     dw = prover.to_device(w)
     bufs = [prover.to_device(ev) for _ in range(3)]
     ts = []
+    rr, ss = 12345, 67890
     for _ in range(reps + 1):
         for b in bufs:
             b.upload(ev)
         prover.sync()
         t0 = time.perf_counter()
-        cp.groth16_prove(prover, pk, dw.ptr, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, 12345, 67890)
+        A, B, C = cp.groth16_prove(prover, pk, dw.ptr, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, rr, ss)
         ts.append(time.perf_counter() - t0)
+    checked = False
+    if check:
+        n_pub = n - pk.n_private
+        h = bufs[0].download().reshape(n, 4)          # the quotient's coefficients replace the first evaluation vector
+        w0, w1 = limbs_sum(w)
+        a_log = (1 + 3 * w1 + 1 * w0 + rr) % R
+        b_log = (1 + 7 * w1 + 3 * w0 + ss) % R
+        b1_log = (1 + 5 * w1 + 2 * w0 + ss) % R
+        p0, p1 = limbs_sum(w, n_pub, n)
+        h0, h1 = limbs_sum(h, 0, n - 1)
+        c_log = (11 * p1 + 4 * p0 + 13 * h1 + 5 * h0 + ss * a_log + rr * b1_log - rr * ss) % R
+        assert A == scalar_mul_g1(prover, a_log), "Groth16 A differs from the trapdoor's"
+        assert B == scalar_mul_g2(prover, b_log), "Groth16 B differs from the trapdoor's"
+        assert C == scalar_mul_g1(prover, c_log), "Groth16 C differs from the trapdoor's"
+        checked = True
     for d in [dw] + bufs:
         d.free()
     for s in sets:
         s.free()
-    return {"log_constraints": log_n, "wires": n, "prove_ms": sorted(ts[1:])[len(ts[1:]) // 2] * 1e3}
+    return {"log_constraints": log_n, "wires": n, "prove_ms": sorted(ts[1:])[len(ts[1:]) // 2] * 1e3, "checked": checked}
 
 
 if __name__ == "__main__":
