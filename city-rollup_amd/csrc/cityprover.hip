@@ -399,9 +399,18 @@ int cp_ctx_set_lanes(cp_ctx *ctx, int lanes) try {
     cp_ctx *lane = cp_ctx_create(ctx->device);
     if (!lane) return set_error(ctx, CP_ERR_HIP, "lane context: %s", cp_last_error(nullptr));
     lane->parent = ctx;
+    lane->transcript_mode = ctx->transcript_mode;
     ctx->lanes.push_back(lane);
   }
   ctx->n_lanes = lanes;
+  return CP_OK;
+} CP_CATCH(ctx)
+
+int cp_ctx_set_device_transcript(cp_ctx *ctx, int mode) try {
+  CHECK_CTX(ctx);
+  if (mode < -1 || mode > 1) return set_error(ctx, CP_ERR_INVALID_ARG, "mode must be -1 (automatic), 0 (host) or 1 (device)");
+  ctx->transcript_mode = mode;
+  for (cp_ctx *l : ctx->lanes) l->transcript_mode = mode;
   return CP_OK;
 } CP_CATCH(ctx)
 

@@ -42,6 +42,7 @@ struct cp_ctx {
   cp_ctx *parent = nullptr;
   std::vector<cp_ctx *> lanes;
   int n_lanes = 1;
+  int transcript_mode = -1;  // cp_ctx_set_device_transcript: -1 automatic (by batch size), 0 host, 1 device
   std::map<uint64_t, PowTable> pow_tables;  // keyed by base
   struct PreKey { int log_n, rate_bits; uint64_t shift; bool operator<(const PreKey &o) const {
     return std::tie(log_n, rate_bits, shift) < std::tie(o.log_n, o.rate_bits, o.shift); } };

@@ -72,6 +72,11 @@ void cp_ctx_destroy(cp_ctx *ctx);
  * bytes; ~20 % more proofs/s than lanes = 1 for one caller at B = 32. Callers that already run
  * several contexts from several threads should leave it at 1 (the default). lanes: 1..8. */
 int cp_ctx_set_lanes(cp_ctx *ctx, int lanes);
+/* Where the Fiat-Shamir transcripts of a proving call are hashed (plonky2's Challenger: a sequential chain of ~115 Poseidon
+ * permutations per proof). 1: on the device — a whole batch is enqueued without a host round trip, no host thread hashes;
+ * 0: on the host, one synchronisation per phase — faster for a LONE proof (a CPU core out-runs one wave on a sequential chain);
+ * -1 (default): by batch size (device from three proofs up). Same proof bytes in every mode. Lanes inherit the setting. */
+int cp_ctx_set_device_transcript(cp_ctx *ctx, int mode);
 /* last error message of `ctx`, or of the calling thread when ctx == NULL. Never NULL. */
 const char *cp_last_error(cp_ctx *ctx);
 /* Fault injection for tests of the error paths (the reference has none; a backend that lives inside

@@ -317,3 +317,33 @@ def test_internal_lanes_zero_knowledge(prover):
             c.close()
     finally:
         p2.close()
+
+
+@pytest.mark.parametrize("n_proofs", [1, 2, 5])
+def test_host_and_device_transcripts_give_the_same_bytes(n_proofs):
+    """The Fiat-Shamir transcripts are hashed on the device for a batch and on the host for one or two proofs
+    (cp_ctx_set_device_transcript; csrc/fri_engine.inc `Transcript`): forced either way, for every batch size, the proofs are the
+    oracle's bytes."""
+    import cityprover as cp
+    from synth_circuit import build as build_circuit
+    prover = cp.Prover(0)
+    c = build_circuit(db=7, num_routed=16, num_wires=20, chunk=8, rate_bits=3, arity_bits=(2, 2), seed=40 + n_proofs)
+    s = c["shape"]
+    sh = cp.standard_recursion_shape(
+        degree_bits=s.degree_bits, num_constants=s.num_constants, num_routed_wires=s.num_routed_wires, num_wires=s.num_wires,
+        num_challenges=s.num_challenges, num_partial_products=s.num_partial_products, quotient_degree_factor=s.quotient_degree_factor,
+        rate_bits=s.rate_bits, cap_height=s.cap_height, pow_bits=s.pow_bits, num_query_rounds=s.num_query_rounds,
+        arity_bits=tuple(s.arity_bits[i] for i in range(s.n_arity)), num_public_inputs=len(c["public_inputs"]))
+    circ = cp.Circuit(prover, sh, [9, 8, 7, 6], c["cs_values"])
+    cp.set_gates(circ, c["gate_list"], 1)
+    want, _ = O.prove_full(c["shape"], c["gates"], [9, 8, 7, 6], c["public_inputs"], c["cs_values"], c["wires"])
+    dw = prover.to_device(np.stack([c["wires"]] * n_proofs))
+    for mode in (0, 1, -1):
+        prover.set_device_transcript(mode)
+        got = cp.prove_batch_dev(prover, [circ] * n_proofs, [c["public_inputs"]] * n_proofs, dw.ptr)
+        assert all(g == want for g in got), f"mode {mode}"
+    with pytest.raises(cp.CityProverError):
+        prover.set_device_transcript(2)
+    dw.free()
+    circ.close()
+    prover.close()
