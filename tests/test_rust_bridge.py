@@ -6,6 +6,8 @@ import re
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -46,3 +48,77 @@ def test_rust_writers_use_the_library_layout():
     assert set(rust) == set(want)
     for name, suffix in want.items():
         assert rust[name] == ids["CP_GATE_" + suffix], name
+
+
+# ---- cp_gate_of: the parser of `Gate::id()` strings, mirrored in Python and fed the LITERAL ids --------------------------------
+def _rust_gate_table():
+    """name -> (type id, [field names of param, param2, param3]) read off rust/plonky2-hwa-patch/cityprover.rs"""
+    rs = open(os.path.join(ROOT, "rust", "plonky2-hwa-patch", "cityprover.rs")).read()
+    table = {}
+    for name, ty, rest in re.findall(r'"(\w+Gate)" => \((\d+),([^\n]*)\),', rs):
+        params = [p.strip() for p in rest.split(",")]
+        assert len(params) == 3, (name, params)
+        table[name] = (int(ty), [re.fullmatch(r'field\("(\w+)"\)', p).group(1) if p != "0" else None for p in params])
+    return table
+
+
+def cp_gate_of_py(gate_id, table):
+    """the Rust parser, statement for statement: first token = the type name, `field(x)` = the digits after the first "x: " """
+    name = re.split(r"[ <({]", gate_id, maxsplit=1)[0]
+
+    def field(f):
+        parts = gate_id.split(f + ": ")
+        if len(parts) < 2:
+            return 0
+        m = re.match(r"\d+", parts[1])
+        return int(m.group(0)) if m else 0
+    ty, fields = table[name]
+    return (ty,) + tuple(field(f) if f else 0 for f in fields)
+
+
+def test_gate_id_strings_parse_to_the_right_type_and_parameters():
+    """the id formats of the eight in-tree gates are reference-held — `fn id` = `format!("{self:?}")` (or with
+    `<D={D}>` for ComparisonGate) over the struct definitions in city_common_circuit/src/u32/gates/*.rs (e.g. range_check_u32.rs:
+    20-24,52-54; add_many_u32.rs:25-30,88-90; comparison.rs:28-33,97-99; interleave_u32.rs:32-35,85-87), i.e. Rust's derived Debug:
+    `Name { field: value, .., _phantom: PhantomData<type> }`. The upstream ids follow plonky2 0.2.2's `id()` implementations
+    (UPSTREAM-MEMORY). Each literal string must come out as (CP_GATE_* id, param, param2, param3)."""
+    t = _rust_gate_table()
+    hdr = open(os.path.join(ROOT, "include", "cityprover.h")).read()
+    ids = {m.group(1): int(m.group(2)) for m in re.finditer(r"CP_GATE_(\w+) = (\d+)", hdr)}
+    ph = "PhantomData<plonky2_field::goldilocks_field::GoldilocksField>"
+    cases = [
+        # in-tree (city_common_circuit/src/u32/gates): field order as declared
+        ("U32AddManyGate { num_addends: 3, num_ops: 5, _phantom: %s }" % ph, ("U32_ADD_MANY", 5, 3, 0)),
+        ("U32ArithmeticGate { num_ops: 3, _phantom: %s }" % ph, ("U32_ARITHMETIC", 3, 0, 0)),
+        ("ComparisonGate { num_bits: 32, num_chunks: 16, _phantom: %s }<D=2>" % ph, ("COMPARISON", 32, 16, 0)),
+        ("U32InterleaveGate { num_ops: 3 }", ("U32_INTERLEAVE", 3, 0, 0)),
+        ("U32RangeCheckGate { num_input_limbs: 7, _phantom: %s }" % ph, ("U32_RANGE_CHECK", 7, 0, 0)),
+        ("U32SubtractionGate { num_ops: 6, _phantom: %s }" % ph, ("U32_SUBTRACTION", 6, 0, 0)),
+        ("UninterleaveToU32Gate { num_ops: 2 }", ("UNINTERLEAVE_TO_U32", 2, 0, 0)),
+        ("UninterleaveToB32Gate { num_ops: 2 }", ("UNINTERLEAVE_TO_B32", 2, 0, 0)),
+        # upstream plonky2 0.2.2 (the city-common set of builder/pad_circuit.rs:31-55, + Noop / PublicInput / Exponentiation)
+        ("NoopGate", ("NOOP", 0, 0, 0)),
+        ("ConstantGate { num_consts: 2 }", ("CONSTANT", 2, 0, 0)),
+        ("PublicInputGate", ("PUBLIC_INPUT", 0, 0, 0)),
+        ("ArithmeticGate { num_ops: 20 }", ("ARITHMETIC", 20, 0, 0)),
+        ("PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>", ("POSEIDON", 0, 0, 0)),
+        ("ArithmeticExtensionGate { num_ops: 10 }", ("ARITHMETIC_EXT", 10, 0, 0)),
+        ("MulExtensionGate { num_ops: 13 }", ("MUL_EXT", 13, 0, 0)),
+        ("BaseSumGate { num_limbs: 63 } + Base: 2", ("BASE_SUM", 63, 2, 0)),
+        ("RandomAccessGate { bits: 4, num_copies: 4, num_extra_constants: 2, _phantom: %s }<D=2>" % ph, ("RANDOM_ACCESS", 4, 4, 2)),
+        ("ReducingGate { num_coeffs: 43 }", ("REDUCING", 43, 0, 0)),
+        ("ReducingExtensionGate { num_coeffs: 32 }", ("REDUCING_EXT", 32, 0, 0)),
+        ("PoseidonMdsGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>", ("POSEIDON_MDS", 0, 0, 0)),
+        ("CosetInterpolationGate { subgroup_bits: 4, degree: 6, barycentric_weights: [1, 2, 3], _phantom: %s }<D=2>" % ph,
+         ("COSET_INTERPOLATION", 4, 6, 0)),
+        ("ExponentiationGate { num_power_bits: 66, _phantom: %s }<D=2>" % ph, ("EXPONENTIATION", 66, 0, 0)),
+    ]
+    assert {c[1][0] for c in cases} == set(ids), "one literal id per gate type"
+    for gate_id, (suffix, p1, p2, p3) in cases:
+        assert cp_gate_of_py(gate_id, t) == (ids[suffix], p1, p2, p3), gate_id
+    # traps the parser must not fall into: "bits: " also ends "num_bits: " / "subgroup_bits: " / "num_power_bits: " (the first
+    # occurrence is taken — the gates that ask for "bits" have it first), "Base: " is not part of the type name
+    assert cp_gate_of_py("ComparisonGate { num_bits: 10, num_chunks: 5, _phantom: x }<D=2>", t)[1:3] == (10, 5)
+    assert cp_gate_of_py("BaseSumGate { num_limbs: 4 } + Base: 16", t)[1:3] == (4, 16)
+    with pytest.raises(KeyError):
+        cp_gate_of_py("LookupGate { num_slots: 40 }", t)     # the Rust side bails: the circuit stays on the CPU prover

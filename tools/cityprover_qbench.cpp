@@ -80,6 +80,7 @@ struct Options {
   int groth16_log = 0;  // > 0: the Groth16 job runs cp_groth16_prove_bls12381 on a synthetic key of 2^groth16_log constraints
   std::vector<int> devices;  // empty: all visible
   bool dry_run = false, ref_counters = false, check_plan = false;
+  bool skip_gate = false;  // --mode throughput only: no check of the proofs (counter-collection runs: every launch then carries a full batch)
 };
 
 // ---- one (dump, iteration) replay ---------------------------------------------------------------------------------
@@ -818,7 +819,7 @@ int run_throughput(const Options &opt) {
     for (size_t w = 0; w < workers.size(); w++) {
       workers[w].index = (int)w;
       workers[w].open(pack, devices[w / (size_t)opt.contexts], opt.lanes);
-      workers[w].gate(expected, &oracle_checked, &verified);
+      if (!opt.skip_gate) workers[w].gate(expected, &oracle_checked, &verified);
     }
     const std::vector<int> cls = workers[0].circuit_classes();
     std::vector<size_t> per_class;
@@ -1002,6 +1003,7 @@ int main(int argc, char **argv) {
     else if (a == "--trace") opt.trace_path = val();
     else if (a == "--groth16-log-size") opt.groth16_log = atoi(val().c_str());
     else if (a == "--dry-run") opt.dry_run = true;
+    else if (a == "--skip-gate") opt.skip_gate = true;
     else if (a == "--dry-run-job-us") opt.dry_job_us = atoi(val().c_str());
     else if (a == "--ref-counters") opt.ref_counters = true;
     else if (a == "--check-plan") opt.check_plan = true;

@@ -28,12 +28,12 @@ QB="$R/tools/cityprover_qbench -i $R/tests/golden/qbench_example.bin -n 8 --bloc
 rocprofv3 --kernel-trace --stats -d "$OUT/trace_qbench" -o qbench -- $QB > "$OUT/qbench_under_rocprof.json" 2> "$OUT/trace_qbench.err"
 python3 "$R/tools/rocpd_top_kernels.py" "$OUT/trace_qbench" "rocprofv3 --kernel-trace --stats -- tools/cityprover_qbench -i tests/golden/qbench_example.bin -n 8 --blocks-in-flight 8 --pack <section 8(d) pack> --contexts 3 --batch 32" > "$OUT/r03_prove_kernel_stats.csv" || true
 ITERS=4
-QT="$R/tools/cityprover_qbench --mode throughput --pack /tmp/prof_pack --contexts 1 --batch 32 --iters $ITERS"
-PROOFS=$((64 + 32 + 32 * ITERS))   # the gate (64 distinct proofs), one full warm-up batch, the timed batches
+QT="$R/tools/cityprover_qbench --mode throughput --skip-gate --pack /tmp/prof_pack --contexts 1 --batch 32 --iters $ITERS"
+PROOFS=$((32 + 32 * ITERS))   # one full warm-up batch and the timed batches: every launch of the run carries 32 proofs (no gate: the counter run measures, the other runs check)
 rocprofv3 --pmc $SQ -d "$OUT/qpmc/sq" -o pmc --output-format csv -- $QT > "$OUT/qbench_under_pmc.json" 2> "$OUT/qpmc_sq.err"
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/qpmc/fetch" -o pmc --output-format csv -- $QT > /dev/null 2> "$OUT/qpmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE -d "$OUT/qpmc/write" -o pmc --output-format csv -- $QT > /dev/null 2> "$OUT/qpmc_write.err"
-python3 "$R/tools/pmc_summary_qbench.py" "$OUT/qpmc" "$OUT/r03_pmc_qbench.json" $PROOFS "rocprofv3 --pmc <group> -- tools/cityprover_qbench --mode throughput --pack <section 8(d) pack> --contexts 1 --batch 32 --iters $ITERS"
+python3 "$R/tools/pmc_summary_qbench.py" "$OUT/qpmc" "$OUT/r03_pmc_qbench.json" $PROOFS "rocprofv3 --pmc <group> -- tools/cityprover_qbench --mode throughput --skip-gate --pack <section 8(d) pack> --contexts 1 --batch 32 --iters $ITERS"
 # keep the per-kernel counter CSVs small: one merged CSV per group
 for g in sq fetch write; do f=$(find "$OUT/qpmc/$g" -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/r03_qpmc_${g}_counter_collection.csv"; done
 find "$OUT" -name "*.db" -delete
