@@ -256,6 +256,64 @@ def native_qbench(device, rank, pack):
                         "STARKs and the 3 Groth16 proofs of a block are outside the build and not in this number"}
 
 
+def power_and_clock(prover, cp, data_ptr, cap_ptr, k, log_n, seconds=1.5):
+    """Board power and shader clock under the two loads of the step (is the 2.0-2.1 GHz the leaf hash runs at a
+    power cap?): `rocm-smi --showpower --showclocks --json` sampled from a side thread while the leaf hash, then the NTT passes,
+    run back to back for `seconds`. Returns {load: {power_W: [...], sclk_MHz: [...]}} or a note when rocm-smi is not usable."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return {"note": "rocm-smi not found"}
+    n = 1 << log_n
+
+    def sample():
+        try:
+            r = subprocess.run([exe, "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+            d = json.loads(r.stdout)
+        except Exception as e:   # noqa: BLE001
+            return {"error": str(e)[:200]}
+        card = d.get("card0") or (list(d.values())[0] if d else {})
+        out = {}
+        for key, val in card.items():
+            m = re.search(r"[-+]?[0-9]*[.]?[0-9]+", str(val))
+            if not m:
+                continue
+            if "ower" in key and "W" in key:
+                out.setdefault("power_W", float(m.group(0)))
+            if key.lower().startswith("sclk"):
+                out.setdefault("sclk_MHz", float(m.group(0)))
+        return out
+
+    res = {}
+    for name, fn in (("idle", None), ("leaf_hash", lambda: prover.merkle_cols_dev(data_ptr, n, k, CAP_H, cap_ptr)),
+                     ("ntt_passes", lambda: prover.ntt_dev(data_ptr, log_n, k, n, cp.NTT_BITREV_OUT))):
+        samples, stop = [], threading.Event()
+
+        def poll():
+            while not stop.is_set():
+                samples.append(sample())
+        th = threading.Thread(target=poll)
+        th.start()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < (seconds if fn else 0.5):
+            if fn:
+                for _ in range(8):
+                    fn()
+                prover.sync()
+            else:
+                time.sleep(0.05)
+        stop.set()
+        th.join()
+        res[name] = {"power_W": [x["power_W"] for x in samples if "power_W" in x], "sclk_MHz": [x["sclk_MHz"] for x in samples if "sclk_MHz" in x],
+                     "samples": len(samples)}
+        if samples and "error" in samples[0] and not res[name]["power_W"]:
+            res[name]["error"] = samples[0]["error"]
+    return res
+
+
 def all_ranks_or_exit(D, dist, fn, what, cleanup=None):
     """fn() on every rank; a rank whose fn raises must not leave the others waiting in the next collective: the
     failure flag is reduced first, and when any rank failed EVERY rank exits non-zero (the --gpus launcher then reports it)."""
@@ -421,6 +479,9 @@ def main():
                     "lde_algorithmic_bytes_per_poly": 8.0 * n * (1 + 8)}
         src.free()
         dst.free()
+    pw = None
+    if rank == 0 and (k, log_n) == (COLS, LOG_N) and not args.no_qbench:
+        pw = power_and_clock(prover, cp, data.ptr, cap.ptr, k, log_n)
     data.free()
     data = None
 
@@ -556,6 +617,7 @@ def main():
             "qbench": dict(qb, roofline=qbench_roofline(qb, (perms / (leaf_ms * 1e-3)) if leaf_ms else None)) if qb else None,
             "groth16_kernels": g16,
             "stark_commit_fri": stark,
+            "power_and_clock": pw,
         }
         print(json.dumps(out))
     cap.free()

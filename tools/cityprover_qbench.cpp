@@ -145,10 +145,12 @@ struct Scheduler {
     out.push_back(queue.front());
     queue.pop_front();
     const JobId first = out[0].job;
-    if (first.topic == qb::GenerateStandardProof && max_batch > 1 && n_workers > 1) {
-      // a short queue is SHARED among the workers instead of going to whoever woke first: with one block in flight, twenty
-      // ready leaves are three launches on three contexts at once, not one launch while two contexts idle; a long queue
-      // (many blocks in flight) still fills every launch to max_batch
+    static const bool share_short_queues = !getenv("CITYPROVER_QBENCH_NO_SHARE");
+    if (first.topic == qb::GenerateStandardProof && max_batch > 1 && n_workers > 1 && share_short_queues && pending_instances < n_workers) {
+      // With FEWER BLOCKS IN FLIGHT THAN WORKERS the run is about latency, and a short queue is shared among the workers instead
+      // of going to whoever woke first: one block alone, twenty ready leaves, is three launches on three contexts at once, not
+      // one launch while two contexts idle (78 ms against 85 ms per block). With more blocks in flight the run is about
+      // throughput and every launch takes all it can: splitting then costs 6-8 % (profiles/r03_qbench_queue_sharing.txt).
       size_t ready = 1;
       for (const auto &e : queue)
         if (e.job.topic == qb::GenerateStandardProof && type_class[e.job.circuit_type] == type_class[first.circuit_type]) ready++;
