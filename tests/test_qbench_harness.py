@@ -20,6 +20,7 @@ def build_harness():
     from cityprover import build
     build.build()
     srcs = [EXE + ".cpp", os.path.join(ROOT, "tools", "qbench", "jobs.h"), os.path.join(ROOT, "tools", "qbench", "pack.h"),
+            os.path.join(ROOT, "tools", "qbench", "redis.h"),
             os.path.join(ROOT, "include", "cityprover.h")]
     if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(s) for s in srcs):
         tmp = "%s.%d.tmp" % (EXE, os.getpid())

@@ -39,7 +39,10 @@
 // run every proof is compared byte for byte with the bytes that passed. --dry-run runs the whole schedule without proving anything and
 // without a GPU (tests of the planner and the queue semantics); --mode throughput is the raw proofs/s measurement;
 // --mode callers measures one-job-per-call threads (--callers T) merged by a cp_batcher (--batch = its max_batch, --linger-us);
-// --callers T in the default mode drains the DAG with T such threads per context instead of one batching thread.
+// --callers T in the default mode drains the DAG with T such threads per context instead of one batching thread;
+// --mode redis-worker --redis HOST:PORT [--drain] [--max-jobs N] is one `l2-worker` of a live deployment: jobs from the RSMQ
+// "JOB" queue, witnesses / proofs / counters in the Redis proof store (tools/qbench/redis.h), one job at a time as the
+// reference's worker loop does (city_rollup_core_worker/src/lib.rs:104-146).
 // Build: g++ -O2 -std=c++17 -Iinclude tools/cityprover_qbench.cpp -Lcity-rollup_amd -lcityprover_hip
 //            -Wl,-rpath,'$ORIGIN/../city-rollup_amd' -lpthread -o tools/cityprover_qbench
 #include <algorithm>
@@ -61,6 +64,7 @@
 #include "cityprover.h"
 #include "qbench/jobs.h"
 #include "qbench/pack.h"
+#include "qbench/redis.h"
 
 namespace {
 
@@ -75,6 +79,9 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 struct Options {
   std::vector<std::string> inputs;
   std::string output, network = "dogeregtest", pack_dir, mode = "qbench", trace_path;
+  std::string redis_uri;  // --mode redis-worker: the deployment's Redis (proof store + RSMQ queues)
+  bool drain = false;     // redis-worker: leave when the JOB queue is empty instead of polling for ever
+  int max_jobs = 0;       // redis-worker: leave after this many jobs (0: no limit)
   int iterations = 1, contexts = 3, batch = 32, blocks_in_flight = 1, lanes = 1, iters = 8, callers = 0, linger_us = 0;
   int dry_job_us = 0;   // --dry-run only: pretend a proving batch takes this long, so that the queue is shared among the worker slots
   int groth16_log = 0;  // > 0: the Groth16 job runs cp_groth16_prove_bls12381 on a synthetic key of 2^groth16_log constraints
@@ -980,6 +987,82 @@ int run_callers(const Options &opt_in) {
   return 0;
 }
 
+// ---- a worker of a LIVE deployment: `city-rollup-cli l2-worker` (city_rollup_core_worker/src/lib.rs:104-146) on the GPU ----------
+// The reference's loop, job for job: RSMQ pop_message("JOB") -> serde_json QProvingJobDataID (event_processor.rs:30-40) ->
+// process_job (actors/simple.rs:57-115) against the Redis proof store (city_redis_store/src/lib.rs:53-112) -> HINCRBY the
+// group counter and, at the goal, send_message the next jobs; NotifyOrchestratorComplete -> a CoreJobCompleted message on
+// NOTIFICATIONS. Circuits and witnesses come from the pack, as everywhere in this harness (CircuitData cannot be built, and
+// witness generation is outside the build); the job's INPUTS are checked in the store exactly as the dump replay checks them.
+// --dry-run proves nothing and needs no GPU (tests/test_qbench_redis.py runs it against an in-process fake server).
+int run_redis_worker(const Options &opt) {
+  if (opt.redis_uri.empty()) die("--redis HOST:PORT is required");
+  qb::RespClient conn;
+  conn.connect(opt.redis_uri);
+  qb::RedisStore store(conn);
+  qb::RsmqQueue queue(conn);
+  qb::Pack pack;
+  Worker worker;
+  std::vector<std::vector<uint8_t>> expected;
+  if (!opt.dry_run) {
+    if (opt.pack_dir.empty()) die("--pack DIR is required");
+    if (cp_device_count() <= 0) die("no HIP device visible: this library has no CPU fallback (use --dry-run to exercise the loop only)");
+    pack = qb::load_pack(opt.pack_dir);
+    worker.open(pack, opt.devices.empty() ? 0 : opt.devices[0], opt.lanes);
+    expected.assign(pack.witnesses.size(), {});
+    worker.gate(expected, nullptr, nullptr);
+  }
+  size_t jobs = 0, proving_jobs = 0, proofs = 0, released = 0, notifications = 0, polls = 0;
+  const double t0 = now_s();
+  for (;;) {
+    if (opt.max_jobs > 0 && (int)jobs >= opt.max_jobs) break;
+    std::string body;
+    if (!queue.pop("JOB", body)) {
+      if (opt.drain) break;
+      polls++;
+      std::this_thread::sleep_for(std::chrono::milliseconds(250));  // event_processor.rs:36
+      continue;
+    }
+    const JobId job = qb::job_from_json(body);
+    jobs++;
+    if (job.topic == qb::GenerateStandardProof) {
+      const std::vector<uint8_t> w = store.get_bytes(job);  // the witness must be there, and every proof it names
+      for (const JobId &dep : qb::proof_dependencies(job, w))
+        if (store.get_bytes(dep).empty()) throw qb::StoreError("Proof " + dep.hex() + " needed by " + job.hex() + " is empty");
+      std::vector<uint8_t> output(1, 0);
+      const int n_stages = qb::proofs_per_job(job.circuit_type);
+      if (!opt.dry_run) {
+        const auto &stages = pack.stages_for(job.circuit_type);
+        if ((int)stages.size() != n_stages) throw std::runtime_error("the pack binds the wrong number of stages to circuit type " + std::to_string(job.circuit_type));
+        for (int s = 0; s < n_stages; s++) {
+          auto pr = worker.prove_items({{stages[s].circuit, stages[s].witness_for(job.task_index)}}, &expected);
+          if (s + 1 == n_stages) output = std::move(pr[0]);
+        }
+      }
+      if (job.circuit_type == qb::WrapFinalSigHashProofBLS12381) output = zero_groth16_bincode();  // GROTH16_DISABLED_DEV_MODE
+      store.set_bytes(job.output_id(), output);
+      proving_jobs++;
+      proofs += (size_t)n_stages;
+    }
+    if (job.topic == qb::NotifyOrchestratorComplete) {
+      queue.send("NOTIFICATIONS", "0");  // serde_json of QueueNotification::CoreJobCompleted (serde_repr u8)
+      notifications++;
+      continue;
+    }
+    const uint32_t goal = store.get_goal(job);
+    if (goal != 0 && store.inc_counter(job.counter_id()) == goal)
+      for (const JobId &nj : store.get_next_jobs(job)) {
+        queue.send("JOB", qb::job_to_json(nj));
+        released++;
+      }
+  }
+  const double wall = now_s() - t0;
+  printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"redis-worker\", \"dry_run\": %s, \"redis\": \"%s\", \"jobs\": %zu, \"proving_jobs\": %zu, "
+         "\"proofs\": %zu, \"jobs_released\": %zu, \"notifications\": %zu, \"idle_polls\": %zu, \"queue_left\": %lld, \"wall_s\": %.6f}\n",
+         opt.dry_run ? "true" : "false", json_escape(opt.redis_uri).c_str(), jobs, proving_jobs, proofs, released, notifications, polls, queue.size("JOB"), wall);
+  if (!opt.dry_run) worker.close();
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -1006,6 +1089,9 @@ int main(int argc, char **argv) {
     else if (a == "--groth16-log-size") opt.groth16_log = atoi(val().c_str());
     else if (a == "--dry-run") opt.dry_run = true;
     else if (a == "--skip-gate") opt.skip_gate = true;
+    else if (a == "--redis") opt.redis_uri = val();
+    else if (a == "--drain") opt.drain = true;
+    else if (a == "--max-jobs") opt.max_jobs = atoi(val().c_str());
     else if (a == "--dry-run-job-us") opt.dry_job_us = atoi(val().c_str());
     else if (a == "--ref-counters") opt.ref_counters = true;
     else if (a == "--check-plan") opt.check_plan = true;
@@ -1036,8 +1122,9 @@ int main(int argc, char **argv) {
     if (opt.mode == "qbench") return run_qbench(opt);
     if (opt.mode == "throughput") return run_throughput(opt);
     if (opt.mode == "callers") return run_callers(opt);
+    if (opt.mode == "redis-worker") return run_redis_worker(opt);
   } catch (const std::exception &e) {
     die(e.what());
   }
-  die("--mode must be qbench, throughput or callers");
+  die("--mode must be qbench, throughput, callers or redis-worker");
 }
