@@ -78,6 +78,11 @@ def qbench_roofline(qb, poseidon_rate):
                   "hbm_bytes_per_proof": pp["hbm_bytes"], "hbm_GBs_at_this_rate": hbm_s / 1e9, "hbm_frac": hbm_s / 1e9 / HBM_PEAK_GBS,
                   "algorithmic_bytes_per_proof": 0.16 * (1 << 30), "traffic_over_algorithmic": pp["hbm_bytes"] / (0.16 * (1 << 30)),
                   "kernel_busy_us_per_proof_one_context": pp["kernel_busy_us"], "quotient": d["quotient"],
+                  # a SIMD issues one wave64 VALU instruction per four cycles (the leaf hash measures 4.0: roofline.cycles_per_valu_...):
+                  # the proofs/s at which the instructions of a proof fill all 1 024 SIMDs at 2.4 GHz, and how close the runs come
+                  "issue_ceiling_proofs_per_s": 1024 * 2.4e9 / 4.0 / pp["valu_instructions"],
+                  "frac_of_issue_ceiling": qb["proofs_per_s"] * pp["valu_instructions"] * 4.0 / (1024 * 2.4e9),
+                  "frac_of_issue_ceiling_throughput_mode": (qb.get("throughput_mode_proofs_per_s") or 0) * pp["valu_instructions"] * 4.0 / (1024 * 2.4e9) or None,
                   "quotient_kernels": {k: {kk: v.get(kk) for kk in ("hbm_bytes_per_proof", "algorithmic_bytes_per_proof", "traffic_over_algorithmic",
                                                                        "busy_us_per_proof")}
                                        for k, v in d["kernels"].items() if k.startswith("k_quot")}}
@@ -206,7 +211,7 @@ def cpu_port_proof(prover, cores):
 
 def native_qbench(device, rank, pack):
     """Second half of BASELINE.json's metric, "block proofs/sec (qbench)", from the native harness (tools/cityprover_qbench:
-    the reference's q-bench loop on a worker pool above the C ABI): the example dump replayed with 32 blocks in flight,
+    the reference's q-bench loop on a worker pool above the C ABI): the example dump replayed with 64 (and 32) blocks in flight,
     one block alone, and the raw proofs/s mode — every proof compared with the oracle's bytes recorded in the pack."""
     import subprocess
     import tempfile
@@ -220,11 +225,15 @@ def native_qbench(device, rank, pack):
                 raise RuntimeError("cityprover_qbench failed: " + r.stderr[-500:])
             return json.loads(r.stdout.strip().splitlines()[-1])
         out_json = os.path.join(tmp, "out.json")
-        many = run(["-i", dump, "-o", out_json, "-n", "128", "--blocks-in-flight", "32", "--contexts", "3", "--batch", "32", "--check-plan"])
+        # BASELINE.json configs[3] is a batch of 64 independent blocks: 64 in flight on this GPU. A worker takes up to 128 ready jobs
+        # per launch: with the cap at 32 three workers cut a long ready queue into small launches (26.6 blocks/s, mean batch 13,
+        # against 33.5 and 45: profiles/r03_qbench_batch_matrix.jsonl) — and a block is not finished LATER for it (1.18 -> 0.97 s at 32 in flight)
+        many = run(["-i", dump, "-o", out_json, "-n", "256", "--blocks-in-flight", "64", "--contexts", "3", "--batch", "128", "--check-plan"])
         per_job = json.load(open(out_json))
-        one = run(["-i", dump, "--contexts", "3", "--batch", "32"])
+        many32 = run(["-i", dump, "-n", "128", "--blocks-in-flight", "32", "--contexts", "3", "--batch", "128"])
+        one = run(["-i", dump, "--contexts", "3", "--batch", "128"])
         serial = run(["-i", dump, "--contexts", "1", "--batch", "1"])
-        thr = run(["--mode", "throughput", "--contexts", "3", "--batch", "32", "--iters", "8"])
+        thr = run(["--mode", "throughput", "--contexts", "3", "--batch", "64", "--iters", "8"])
         # the reference's loops unchanged (one job per pop, one proof per call) as 128 threads sharing one context through cp_batcher
         # (rank 0 only: a side measurement, and 128 threads per rank would be a thousand on an 8-GPU node)
         callers = run(["-i", dump, "-n", "64", "--blocks-in-flight", "32", "--contexts", "1", "--lanes", "4", "--callers", "128",
@@ -235,17 +244,21 @@ def native_qbench(device, rank, pack):
             "distinct_proofs_per_block": many["distinct_proofs"], "distinct_circuits": many["circuits"],
             "distinct_proofs_equal_to_oracle_bytes": many["distinct_proofs_equal_to_recorded_bytes"],
             "distinct_proofs_cp_verified": many["distinct_proofs_cp_verified"], "mean_batch": many["mean_batch"],
-            "launches": many["launches"], "one_block_mean_batch": one["mean_batch"],
+            "launches": many["launches"], "mean_block_latency_ms": many["mean_block_latency_ms"],
+            "with_32_blocks_in_flight": {"blocks_per_s": many32["blocks_per_s"], "proofs_per_s": many32["proofs_per_s"],
+                                         "mean_batch": many32["mean_batch"], "mean_block_latency_ms": many32["mean_block_latency_ms"]},
+            "one_block_mean_batch": one["mean_batch"],
             "one_block_latency_ms": one["mean_block_latency_ms"],
             "reference_loop_block_ms": serial["mean_block_latency_ms"],
-            "throughput_mode_proofs_per_s": thr["proofs_per_s"], "contexts_per_gpu": 3, "max_batch": 32,
+            "throughput_mode_proofs_per_s": thr["proofs_per_s"], "contexts_per_gpu": 3, "max_batch": 128,
             "one_job_per_call_threads": None if callers is None else {
                 "blocks_per_s": callers["blocks_per_s"], "proofs_per_s": callers["proofs_per_s"], "threads": 128, "lanes": 4,
                 "linger_us": 300, "proofs_byte_checked": callers["proofs_byte_checked"],
                 "note": "rank 0's GPU only; --callers 128 --lanes 4: the DAG drained by one-job-per-call threads merged by "
                         "cp_batcher (include/cityprover.h) instead of a batching worker"},
-            "harness": "tools/cityprover_qbench -i tests/golden/qbench_example.bin (the reference's own q-bench dump) -n 128 "
-                       "--blocks-in-flight 32 --contexts 3 --batch 32; one_block = the same dump alone; reference_loop = one "
+            "harness": "tools/cityprover_qbench -i tests/golden/qbench_example.bin (the reference's own q-bench dump) -n 256 "
+                       "--blocks-in-flight 64 --contexts 3 --batch 128 (BASELINE.json configs[3]: a batch of 64 independent blocks; "
+                       "with_32_blocks_in_flight = -n 128 --blocks-in-flight 32); one_block = the same dump alone; reference_loop = one "
                        "context, one job at a time (the reference's single-threaded loop)",
             "workload": "SURVEY.md section 8(d) M1: the example block's 46 jobs = 64 DISTINCT plonky2 proofs per block — one synthetic "
                         "shape-equivalent circuit per (job type, stage) (26 circuits), one witness per job (seed = job index); n = 2^12, 135 "
@@ -578,6 +591,14 @@ def main():
             roof["frac"] = roof["achieved"] / roof["peak"]
             if clk:
                 roof["frac_at_measured_clock"] = roof["achieved"] / roof["peak_at_measured_clock"]
+            # what the kernel actually issues: with the shader clock rocm-smi reports while it runs (the clock estimated under
+            # the counter pass is the counter pass's), cycles a SIMD spends per wave64 VALU instruction. A SIMD issues one per
+            # four cycles at full rate; tools/ubench_valu.hip measures 4.3-5.0 for the VOP3 integer forms of this mix.
+            sclk = sorted((pw or {}).get("leaf_hash", {}).get("sclk_MHz") or [])
+            if sclk:
+                mhz = sclk[len(sclk) // 2]
+                roof["sclk_MHz_while_running"] = mhz
+                roof["cycles_per_valu_instruction_per_simd"] = leaf_ms * 1e-3 * mhz * 1e6 / (pl["SQ_INSTS_VALU"] / 1024.0)
         else:
             roof = {"kernel": "leaf_hash_cols", "bound": "hbm", "unit": "GB/s", "achieved": hbm["achieved_GBs"], "peak": HBM_PEAK_GBS,
                     "frac": hbm["frac"], "traffic": None, "algorithmic_bytes": leaf_bytes,

@@ -82,7 +82,7 @@ struct Options {
   std::string redis_uri;  // --mode redis-worker: the deployment's Redis (proof store + RSMQ queues)
   bool drain = false;     // redis-worker: leave when the JOB queue is empty instead of polling for ever
   int max_jobs = 0;       // redis-worker: leave after this many jobs (0: no limit)
-  int iterations = 1, contexts = 3, batch = 32, blocks_in_flight = 1, lanes = 1, iters = 8, callers = 0, linger_us = 0;
+  int iterations = 1, contexts = 3, batch = 128, blocks_in_flight = 1, lanes = 1, iters = 8, callers = 0, linger_us = 0;
   int dry_job_us = 0;   // --dry-run only: pretend a proving batch takes this long, so that the queue is shared among the worker slots
   int groth16_log = 0;  // > 0: the Groth16 job runs cp_groth16_prove_bls12381 on a synthetic key of 2^groth16_log constraints
   std::vector<int> devices;  // empty: all visible

@@ -4,6 +4,8 @@
 #   2-4. --pmc SQ group / FETCH_SIZE / WRITE_SIZE of the bench command  -> r03_pmc_bench.json
 #   5. --kernel-trace --stats of the native q-bench harness (8 blocks in flight, 3 contexts: the section 8(d) workload) -> r03_prove_kernel_stats.csv
 #   6-8. --pmc passes of the harness in throughput mode, ONE context    -> r03_pmc_qbench.json (per proof: VALU instructions, HBM bytes, quotient traffic)
+#   9. --kernel-trace --stats of the G1 / G2 MSMs at 2^20               -> r03_msm_kernel_stats.csv; one proof alone -> r03_prove_profile_1.json;
+#      STARK-shaped commit + FRI -> r03_stark_commit_fri.json; NTT staged-store A/B -> r03_ntt_staged_store_ab.jsonl
 # Counter passes run alone (no trace flags: gpurun refuses the combination). The program itself follows `--`.
 set -e
 cd /tmp && export TMPDIR=/tmp
@@ -34,6 +36,15 @@ rocprofv3 --pmc $SQ -d "$OUT/qpmc/sq" -o pmc --output-format csv -- $QT > "$OUT/
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/qpmc/fetch" -o pmc --output-format csv -- $QT > /dev/null 2> "$OUT/qpmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE -d "$OUT/qpmc/write" -o pmc --output-format csv -- $QT > /dev/null 2> "$OUT/qpmc_write.err"
 python3 "$R/tools/pmc_summary_qbench.py" "$OUT/qpmc" "$OUT/r03_pmc_qbench.json" $PROOFS "rocprofv3 --pmc <group> -- tools/cityprover_qbench --mode throughput --skip-gate --pack <section 8(d) pack> --contexts 1 --batch 32 --iters $ITERS"
+# the MSM kernels at 2^20 (G1 and G2): per-kernel time beside the code-object metadata of profiles/r03_msm_kernel_meta.csv
+rocprofv3 --kernel-trace --stats -d "$OUT/trace_msm" -o msm -- python3 "$R/tools/bench_msm.py" 20 > "$OUT/r03_msm_bench.json" 2> "$OUT/trace_msm.err"
+python3 "$R/tools/rocpd_top_kernels.py" "$OUT/trace_msm" "rocprofv3 --kernel-trace --stats -- python3 tools/bench_msm.py 20" > "$OUT/r03_msm_kernel_stats.csv" || true
+# one proof alone: per-kernel and per-host-phase milliseconds (host transcript for a single proof, device transcript from 8 up)
+python3 "$R/tools/prove_profile_one.py" > "$OUT/r03_prove_profile_1.json" 2> "$OUT/prove_profile_1.err"
+python3 "$R/tools/bench_stark_fri.py" > "$OUT/r03_stark_commit_fri.json" 2> "$OUT/stark_fri.err" || true
+python3 "$R/tools/bench_ntt.py" > "$OUT/r03_ntt_staged_store_ab.jsonl" 2> "$OUT/ntt_ab.err" || true
+CITYPROVER_NTT_STAGED_STORE=0 python3 "$R/tools/bench_ntt.py" >> "$OUT/r03_ntt_staged_store_ab.jsonl" 2>> "$OUT/ntt_ab.err" || true
+python3 "$R/tools/kernel_meta.py" msm --csv > "$OUT/r03_msm_kernel_meta.csv" 2>/dev/null || true
 # keep the per-kernel counter CSVs small: one merged CSV per group
 for g in sq fetch write; do f=$(find "$OUT/qpmc/$g" -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/r03_qpmc_${g}_counter_collection.csv"; done
 find "$OUT" -name "*.db" -delete
