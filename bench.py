@@ -234,10 +234,10 @@ def native_qbench(device, rank, pack):
         one = run(["-i", dump, "--contexts", "3", "--batch", "128"])
         serial = run(["-i", dump, "--contexts", "1", "--batch", "1"])
         thr = run(["--mode", "throughput", "--contexts", "3", "--batch", "64", "--iters", "8"])
-        # the reference's loops unchanged (one job per pop, one proof per call) as 128 threads sharing one context through cp_batcher
-        # (rank 0 only: a side measurement, and 128 threads per rank would be a thousand on an 8-GPU node)
-        callers = run(["-i", dump, "-n", "64", "--blocks-in-flight", "32", "--contexts", "1", "--lanes", "4", "--callers", "128",
-                       "--batch", "32", "--linger-us", "300"]) if rank == 0 else None
+        # the reference's loops unchanged (one job per pop, one proof per call) as 192 threads sharing one context through cp_batcher
+        # (rank 0 only: a side measurement, and 192 threads per rank would be fifteen hundred on an 8-GPU node)
+        callers = run(["-i", dump, "-n", "128", "--blocks-in-flight", "64", "--contexts", "1", "--lanes", "4", "--callers", "192",
+                       "--batch", "64", "--linger-us", "300"]) if rank == 0 else None
     return {"blocks_per_s": many["blocks_per_s"], "proofs_per_s": many["proofs_per_s"], "blocks_in_flight": many["blocks_in_flight"],
             "jobs_per_block": many["jobs_per_block"], "proofs_per_block": many["proofs_per_block"],
             "proofs_byte_checked": many["proofs_byte_checked"], "job_records_written": len(per_job),
@@ -252,9 +252,9 @@ def native_qbench(device, rank, pack):
             "reference_loop_block_ms": serial["mean_block_latency_ms"],
             "throughput_mode_proofs_per_s": thr["proofs_per_s"], "contexts_per_gpu": 3, "max_batch": 128,
             "one_job_per_call_threads": None if callers is None else {
-                "blocks_per_s": callers["blocks_per_s"], "proofs_per_s": callers["proofs_per_s"], "threads": 128, "lanes": 4,
+                "blocks_per_s": callers["blocks_per_s"], "proofs_per_s": callers["proofs_per_s"], "threads": 192, "lanes": 4, "max_batch": 64,
                 "linger_us": 300, "proofs_byte_checked": callers["proofs_byte_checked"],
-                "note": "rank 0's GPU only; --callers 128 --lanes 4: the DAG drained by one-job-per-call threads merged by "
+                "note": "rank 0's GPU only; 64 blocks in flight, --callers 192 --lanes 4 --batch 64: the DAG drained by one-job-per-call threads merged by "
                         "cp_batcher (include/cityprover.h) instead of a batching worker"},
             "harness": "tools/cityprover_qbench -i tests/golden/qbench_example.bin (the reference's own q-bench dump) -n 256 "
                        "--blocks-in-flight 64 --contexts 3 --batch 128 (BASELINE.json configs[3]: a batch of 64 independent blocks; "
