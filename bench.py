@@ -343,6 +343,27 @@ def all_ranks_or_exit(D, dist, fn, what, cleanup=None):
     return res
 
 
+_JSON_OUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout. Libraries below us write there too (gloo prints "[Gloo] Rank 0 is connected to
+    ..." from C++ when a process group forms), so a rank keeps a private handle on the real stdout for its JSON line and points
+    file descriptor 1 at stderr for everybody else, itself included."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _JSON_OUT
+
+
+def emit(obj):
+    out = claim_stdout()
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def stub_main(args, D):
     """CITYPROVER_BENCH_STUB=1: everything of a multi-rank run EXCEPT the GPU section — rank environment, rendezvous, the
     barrier / max / sum / broadcast of the control plane, the all-ranks-or-exit rule, rank-0-only output — so that the
@@ -365,8 +386,8 @@ def stub_main(args, D):
     mine = all_ranks_or_exit(D, dist, side, "the stub side measurement")
     total_units = D.sum_over_ranks(dist, mine["units"])
     if rank == 0:
-        print(json.dumps({"metric": "stub", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "elapsed_s": elapsed,
-                          "units": total_units, "broadcast": token, "local_rank": local_rank}))
+        emit({"metric": "stub", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "elapsed_s": elapsed,
+              "units": total_units, "broadcast": token, "local_rank": local_rank})
     if dist is not None:
         dist.destroy_process_group()
     if os.environ.get("CITYPROVER_BENCH_STUB_EXIT") == str(rank):
@@ -405,6 +426,7 @@ def main():
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
 
+    claim_stdout()
     from cityprover import dist as D
     if os.environ.get("CITYPROVER_BENCH_STUB"):
         return stub_main(args, D)
@@ -640,7 +662,7 @@ def main():
             "stark_commit_fri": stark,
             "power_and_clock": pw,
         }
-        print(json.dumps(out))
+        emit(out)
     cap.free()
     prover.close()
     if dist is not None:

@@ -80,6 +80,8 @@ def test_bench_gpus_branch_spawns_its_ranks_and_only_rank_0_prints():
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, r.stdout
+        # the contract is ONE line on stdout: gloo's "[Gloo] Rank 0 is connected ..." chatter must go to stderr
+        assert r.stdout.strip().splitlines() == lines, r.stdout
         out = json.loads(lines[0])
         assert out["n_gpus"] == n and out["units"] == float(n) and out["broadcast"] == "pack-of-rank-0" and out["local_rank"] == 0
         assert out["elapsed_s"] >= 0.01 * n            # the slowest rank's time, not rank 0's
