@@ -117,6 +117,7 @@ struct Scheduler {
   std::vector<JobId> processed;        // every job popped, in pop order (barrier and notify jobs included)
   int type_class[256] = {0};           // circuit type -> batch-compatibility class of its first stage's circuit
   size_t n_workers = 1;                // threads draining the queue
+  size_t busy = 0;                     // of them, holding work (between the take() that returned it and their next take())
 
   void enqueue(Instance *inst, const std::vector<JobId> &jobs) {
     std::lock_guard<std::mutex> l(m);
@@ -135,6 +136,8 @@ struct Scheduler {
   // or a failure).
   bool take(size_t max_batch, std::vector<QueueEntry> &out) {
     std::unique_lock<std::mutex> l(m);
+    static thread_local bool holds_work = false;  // a worker is busy from the take() that gave it work to its next take()
+    if (holds_work) { busy--; holds_work = false; }
     for (;;) {
       if (failed) return false;
       if (!queue.empty()) break;
@@ -161,7 +164,11 @@ struct Scheduler {
       size_t ready = 1;
       for (const auto &e : queue)
         if (e.job.topic == qb::GenerateStandardProof && type_class[e.job.circuit_type] == type_class[first.circuit_type]) ready++;
-      const size_t share = (ready + n_workers - 1) / n_workers;
+      // ... among the workers that hold no work right now (this one included): the first of three takes a third, the second half
+      // of what is left, the third the rest — with ready / n_workers for everyone the shares shrank with the queue (23 ready
+      // leaves went out as 8 + 5 + 4 and six waited for the next free worker: profiles/r03_one_block_timeline.txt)
+      const size_t takers = n_workers > busy ? n_workers - busy : 1;
+      const size_t share = (ready + takers - 1) / takers;
       if (share < max_batch) max_batch = share < 1 ? 1 : share;
     }
     if (first.topic == qb::GenerateStandardProof)
@@ -175,6 +182,8 @@ struct Scheduler {
       }
     for (const auto &e : out) processed.push_back(e.job);
     in_flight += out.size();
+    busy++;
+    holds_work = true;
     return true;
   }
   void finished(size_t n) {
