@@ -99,9 +99,28 @@ struct Instance {
   bool complete = false;
   size_t jobs_done = 0, proofs_done = 0;
   double t_start = 0, t_end = 0;
+  std::unordered_map<JobId, int, qb::JobIdHash> tail_memo;  // counter id -> proofs on the longest chain after a job of that group
+
+  // Proofs on the longest dependency chain from `job` to the end of the block, `job` included: what the block's latency is
+  // made of when few jobs are ready. Read off the plan's own records (the next-jobs list of the job's group). Call with `m` held.
+  int chain_length(const JobId &job) {
+    if (job.topic == qb::NotifyOrchestratorComplete) return 0;
+    const int own = job.topic == qb::GenerateStandardProof ? qb::proofs_per_job(job.circuit_type) : 0;
+    const JobId key = job.counter_id();
+    auto it = tail_memo.find(key);
+    if (it == tail_memo.end()) {
+      int best = 0;
+      tail_memo[key] = 0;  // a cycle in a malformed plan ends here
+      if (store.has(job.next_jobs_id_of_counter()))
+        for (const JobId &n : store.get_next_jobs(job)) best = std::max(best, chain_length(n));
+      it = tail_memo.find(key);
+      it->second = best;
+    }
+    return own + it->second;
+  }
 };
 
-struct QueueEntry { Instance *inst; JobId job; };
+struct QueueEntry { Instance *inst; JobId job; int chain = 0; };
 struct BenchRecord { JobId job; uint64_t duration_ms; double t0, t1; int worker, batch; size_t instance; };
 
 // the shared ready queue (CityEventProcessorMemory::job_queue) + the bookkeeping of the run
@@ -120,9 +139,15 @@ struct Scheduler {
   size_t busy = 0;                     // of them, holding work (between the take() that returned it and their next take())
 
   void enqueue(Instance *inst, const std::vector<JobId> &jobs) {
+    std::vector<int> chain(jobs.size());
+    {
+      std::lock_guard<std::mutex> li(inst->m);
+      for (size_t i = 0; i < jobs.size(); i++) chain[i] = inst->chain_length(jobs[i]);
+    }
     std::lock_guard<std::mutex> l(m);
-    for (const JobId &j : jobs) {
-      queue.push_back({inst, j});
+    for (size_t i = 0; i < jobs.size(); i++) {
+      const JobId &j = jobs[i];
+      queue.push_back({inst, j, chain[i]});
       cv.notify_one();  // one sleeper per job: with a hundred worker threads, waking them all for every job is what costs
     }
   }
@@ -152,10 +177,15 @@ struct Scheduler {
       cv.wait(l);
     }
     out.clear();
+    static const bool share_short_queues = !getenv("CITYPROVER_QBENCH_NO_SHARE");
+    static const bool longest_chain_first = !getenv("CITYPROVER_QBENCH_FIFO");
+    if (longest_chain_first && share_short_queues && max_batch > 1 && n_workers > 1 && pending_instances < n_workers)
+      // latency mode (below): the ready job with the longest chain of dependent proofs behind it goes first — the five-stage
+      // introspection jobs the planner enqueues ahead of the leaves have a shorter way to the end of the block than the leaves
+      std::stable_sort(queue.begin(), queue.end(), [](const QueueEntry &a, const QueueEntry &b) { return a.chain > b.chain; });
     out.push_back(queue.front());
     queue.pop_front();
     const JobId first = out[0].job;
-    static const bool share_short_queues = !getenv("CITYPROVER_QBENCH_NO_SHARE");
     if (first.topic == qb::GenerateStandardProof && max_batch > 1 && n_workers > 1 && share_short_queues && pending_instances < n_workers) {
       // With FEWER BLOCKS IN FLIGHT THAN WORKERS the run is about latency, and a short queue is shared among the workers instead
       // of going to whoever woke first: one block alone, twenty ready leaves, is three launches on three contexts at once, not
