@@ -103,6 +103,28 @@ def test_worker_pool_iterations_and_blocks_in_flight(golden_dir, tmp_path):
     assert set(Counter(b["job_id"] for b in bench).values()) == {6}
 
 
+def test_sliding_window_of_blocks(golden_dir, tmp_path):
+    """--sliding: a block that completes starts the next one (a window of --blocks-in-flight blocks instead of waves); every
+    block completes, every job runs exactly once per block, and never more blocks than the window are open at a time."""
+    dump = os.path.join(golden_dir, "qbench_example.bin")
+    out, trace = str(tmp_path / "out.json"), str(tmp_path / "trace.jsonl")
+    res = run(["-i", dump, "-o", out, "-n", "9", "--dry-run", "--dry-run-job-us", "200", "--contexts", "3", "--batch", "8",
+               "--blocks-in-flight", "3", "--sliding", "--trace", trace])
+    assert res["blocks"] == 9 and res["blocks_complete"] == 9 and res["jobs"] == 9 * 46 and res["proofs"] == 9 * 64
+    from collections import Counter
+    assert set(Counter(b["job_id"] for b in json.load(open(out))).values()) == {9}
+    popped = [json.loads(l) for l in open(trace) if '"popped"' in l]
+    open_blocks, worst = 0, 0
+    for p in popped:          # a block opens with its first leaf (the first introspection job) and closes with its notify job
+        if (p["topic"], p["circuit_type"], p["task_index"]) == (0, 33, 0):
+            open_blocks += 1
+        if p["topic"] == 3:
+            open_blocks -= 1
+        worst = max(worst, open_blocks)
+    assert worst <= 3 and open_blocks == 0
+    assert "--sliding and --ref-counters" in run(["-i", dump, "--dry-run", "--sliding", "--ref-counters"], ok=False)
+
+
 def test_reference_counter_quirk(golden_dir, tmp_path):
     """The reference never resets `counters` between iterations (memory_proof_store/mod.rs:77-83; qbench.rs:44-61): from
     the second iteration on no group reaches its goal and only the 23 leaf jobs run. --ref-counters reproduces that."""

@@ -54,6 +54,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -87,6 +88,7 @@ struct Options {
   int groth16_log = 0;  // > 0: the Groth16 job runs cp_groth16_prove_bls12381 on a synthetic key of 2^groth16_log constraints
   std::vector<int> devices;  // empty: all visible
   bool dry_run = false, ref_counters = false, check_plan = false;
+  bool sliding = false;    // --sliding: a window of --blocks-in-flight blocks (a block that completes starts the next) instead of waves
   bool skip_gate = false;  // --mode throughput only: no check of the proofs (counter-collection runs: every launch then carries a full batch)
 };
 
@@ -120,7 +122,9 @@ struct Instance {
   }
 };
 
-struct QueueEntry { Instance *inst; JobId job; int chain = 0; };
+// one STAGE of a job: a job of k proofs (proofs_per_job) goes through the queue k times, stage s + 1 after stage s is proved, so
+// that a worker is never held by the later stages of a long job and every launch can take whatever stages are ready
+struct QueueEntry { Instance *inst; JobId job; int chain = 0; int stage = 0; double t_first = 0; };
 struct BenchRecord { JobId job; uint64_t duration_ms; double t0, t1; int worker, batch; size_t instance; };
 
 // the shared ready queue (CityEventProcessorMemory::job_queue) + the bookkeeping of the run
@@ -134,9 +138,11 @@ struct Scheduler {
   std::string error;
   std::vector<BenchRecord> benchmarks;  // completion order
   std::vector<JobId> processed;        // every job popped, in pop order (barrier and notify jobs included)
-  int type_class[256] = {0};           // circuit type -> batch-compatibility class of its first stage's circuit
+  int stage_class[256][8] = {{0}};     // (circuit type, stage) -> batch-compatibility class of that stage's circuit
+  int cls(const QueueEntry &e) const { return stage_class[e.job.circuit_type][e.stage < 8 ? e.stage : 7]; }
   size_t n_workers = 1;                // threads draining the queue
   size_t busy = 0;                     // of them, holding work (between the take() that returned it and their next take())
+  std::function<void()> on_block_complete;  // --sliding: starts the next block
 
   void enqueue(Instance *inst, const std::vector<JobId> &jobs) {
     std::vector<int> chain(jobs.size());
@@ -150,6 +156,12 @@ struct Scheduler {
       queue.push_back({inst, j, chain[i]});
       cv.notify_one();  // one sleeper per job: with a hundred worker threads, waking them all for every job is what costs
     }
+  }
+  // the next stage of a job whose stage has just been proved: ahead of what has not started yet
+  void requeue(const QueueEntry &e) {
+    std::lock_guard<std::mutex> l(m);
+    queue.push_front(e);
+    cv.notify_one();
   }
   void fail(const std::string &msg) {
     std::lock_guard<std::mutex> l(m);
@@ -179,9 +191,14 @@ struct Scheduler {
     out.clear();
     static const bool share_short_queues = !getenv("CITYPROVER_QBENCH_NO_SHARE");
     static const bool longest_chain_first = !getenv("CITYPROVER_QBENCH_FIFO");
-    if (longest_chain_first && share_short_queues && max_batch > 1 && n_workers > 1 && pending_instances < n_workers)
-      // latency mode (below): the ready job with the longest chain of dependent proofs behind it goes first — the five-stage
-      // introspection jobs the planner enqueues ahead of the leaves have a shorter way to the end of the block than the leaves
+    if (longest_chain_first && max_batch > 1 && n_workers > 1)
+      // Order of service: the ready job with the longest chain of dependent proofs behind it first — the five-stage
+      // introspection jobs the planner enqueues ahead of the leaves have a shorter way to the end of the block than the leaves.
+      // One block alone: 71 -> 67 ms; with many blocks in flight never slower than first-in-first-out
+      // (profiles/r03_qbench_chain_ab.jsonl). NOT "the older block first": blocks that advance in step fill the launches
+      // (mean launch 75 proofs at 64 blocks in flight); served oldest-first they drift apart, ready jobs trickle in and the
+      // launches shrink to 9 (34 -> 28 blocks/s, profiles/r03_qbench_window_ab_oldest_first.jsonl).
+      // CITYPROVER_QBENCH_FIFO=1 restores the queue order.
       std::stable_sort(queue.begin(), queue.end(), [](const QueueEntry &a, const QueueEntry &b) { return a.chain > b.chain; });
     out.push_back(queue.front());
     queue.pop_front();
@@ -193,7 +210,7 @@ struct Scheduler {
       // throughput and every launch takes all it can: splitting then costs 6-8 % (profiles/r03_qbench_queue_sharing.txt).
       size_t ready = 1;
       for (const auto &e : queue)
-        if (e.job.topic == qb::GenerateStandardProof && type_class[e.job.circuit_type] == type_class[first.circuit_type]) ready++;
+        if (e.job.topic == qb::GenerateStandardProof && cls(e) == cls(out[0])) ready++;
       // ... among the workers that hold no work right now (this one included): the first of three takes a third, the second half
       // of what is left, the third the rest — with ready / n_workers for everyone the shares shrank with the queue (23 ready
       // leaves went out as 8 + 5 + 4 and six waited for the next free worker: profiles/r03_one_block_timeline.txt)
@@ -203,14 +220,15 @@ struct Scheduler {
     }
     if (first.topic == qb::GenerateStandardProof)
       for (auto it = queue.begin(); it != queue.end() && out.size() < max_batch;) {
-        if (it->job.topic == qb::GenerateStandardProof && type_class[it->job.circuit_type] == type_class[first.circuit_type]) {
+        if (it->job.topic == qb::GenerateStandardProof && cls(*it) == cls(out[0])) {
           out.push_back(*it);
           it = queue.erase(it);
         } else {
           ++it;
         }
       }
-    for (const auto &e : out) processed.push_back(e.job);
+    for (const auto &e : out)
+      if (e.stage == 0) processed.push_back(e.job);
     in_flight += out.size();
     busy++;
     holds_work = true;
@@ -474,6 +492,8 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
     return it == m.end() ? 0 : it->second;
   };
   const double t0 = now_s();
+  static const bool whole_jobs = getenv("CITYPROVER_QBENCH_WHOLE_JOBS") != nullptr;  // A/B: a worker keeps a job through all its stages
+  auto t_first = [&](size_t i) { return batch[i].stage == 0 ? t0 : batch[i].t_first; };  // when the job's first stage started
   std::vector<std::vector<uint8_t>> outputs(batch.size());
   std::vector<char> done(batch.size(), 0);
   // the tail of process_job (actors/simple.rs:89-106) for one job of the batch: store the output, record the duration, count,
@@ -493,7 +513,7 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
       }
     }
     const double t1 = now_s();
-    const uint64_t ms = (uint64_t)((t1 - t0) * 1e3);
+    const uint64_t ms = (uint64_t)((t1 - t_first(i)) * 1e3);
     std::vector<JobId> release;
     {
       std::lock_guard<std::mutex> l(inst->m);
@@ -513,14 +533,16 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
     {
       std::lock_guard<std::mutex> l(S.m);
       if (job.topic == qb::GenerateStandardProof)
-        S.benchmarks.push_back({job, ms, t0, t1, worker ? worker->index : -1, (int)batch.size(), inst->index});
+        S.benchmarks.push_back({job, ms, t_first(i), t1, worker ? worker->index : -1, (int)batch.size(), inst->index});
       if (job.topic == qb::NotifyOrchestratorComplete) S.pending_instances--;
     }
+    if (job.topic == qb::NotifyOrchestratorComplete && S.on_block_complete) S.on_block_complete();  // this job still counts as in flight
     if (!release.empty()) S.enqueue(inst, release);
   };
   if (first.topic == qb::GenerateStandardProof) {
     // inputs: the job's witness and every proof it names must be in the store (worker/traits.rs:74-83,164-202)
     for (const auto &e : batch) {
+      if (e.stage != 0) continue;  // checked when the job's first stage was taken
       std::lock_guard<std::mutex> l(e.inst->m);
       const std::vector<uint8_t> &w = e.inst->store.get_bytes(e.job);
       for (const JobId &dep : qb::proof_dependencies(e.job, w))
@@ -539,6 +561,27 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
           throw std::runtime_error("the pack binds " + std::to_string(st[i]->size()) + " stages to circuit type " + std::to_string(ct) +
                                    ", the job proves " + std::to_string(qb::proofs_per_job(ct)));
         max_stages = std::max(max_stages, (int)st[i]->size());
+      }
+      if (!whole_jobs) {
+        // ONE stage of every job of the batch (take() put stages of one compatibility class together): a job whose last stage
+        // this was is finished, the others go back to the queue with their next stage
+        std::vector<Worker::Item> items;
+        for (size_t i = 0; i < batch.size(); i++) {
+          if (batch[i].stage >= (int)st[i]->size()) throw std::runtime_error("stage out of range for " + batch[i].job.hex());
+          const qb::Binding &b = (*st[i])[(size_t)batch[i].stage];
+          items.push_back({b.circuit, b.witness_for(job_ordinal(batch[i]))});
+        }
+        auto proofs = worker->prove_items(items, expected);
+        for (size_t i = 0; i < batch.size(); i++) {
+          if (batch[i].stage + 1 == (int)st[i]->size()) {
+            outputs[i] = std::move(proofs[i]);
+            finish(i);
+          } else {
+            done[i] = 1;  // not finished: its next stage is a queue entry of its own
+            S.requeue({batch[i].inst, batch[i].job, batch[i].chain > 0 ? batch[i].chain - 1 : 0, batch[i].stage + 1, t_first(i)});
+          }
+        }
+        max_stages = 0;
       }
       for (int s = 0; s < max_stages; s++) {
         std::vector<std::pair<int, size_t>> order;  // (class of the stage's circuit, position in the batch)
@@ -732,18 +775,46 @@ int run_qbench(const Options &opt) {
 
   Scheduler S;
   if (!opt.dry_run)
-    for (const auto &kv : pack.by_type)
-      if (kv.first >= 0 && !kv.second.empty()) S.type_class[kv.first] = shared.circuit_class[kv.second[0].circuit];
-  if (!opt.dry_run && pack.by_type.count(-1))
-    for (int t = 0; t < 256; t++)
-      if (!pack.by_type.count(t)) S.type_class[t] = shared.circuit_class[pack.by_type.at(-1)[0].circuit];
+    for (int t = 0; t < 256; t++) {
+      if (!pack.by_type.count(t) && !pack.by_type.count(-1)) continue;
+      const auto &st = pack.stages_for((uint8_t)t);
+      for (size_t k = 0; k < 8; k++) S.stage_class[t][k] = st.empty() ? 0 : shared.circuit_class[st[k < st.size() ? k : st.size() - 1].circuit];
+    }
   // --dry-run --devices a,b,...: the worker -> device assignment of a multi-GPU run without any GPU (one slot per device x context)
   const size_t dry_slots = opt.dry_run && !opt.devices.empty() ? opt.devices.size() * (size_t)opt.contexts : 0;
   std::vector<std::atomic<size_t>> slot_jobs(dry_slots ? dry_slots : 1);
   for (auto &a : slot_jobs) a = 0;
   const double t_begin = now_s();
-  // instances are started in waves of --blocks-in-flight; the next wave starts when the queue has drained
   size_t next = 0;
+  if (opt.sliding) {
+    // a WINDOW of --blocks-in-flight blocks: the block that completes starts the next one, so the sequential tail of one block
+    // (seven dependent proofs) runs beside the leaves of another — the steady state of a worker that is fed continuously
+    if (opt.ref_counters) die("--sliding and --ref-counters do not go together");
+    std::atomic<size_t> to_start{0};
+    auto start_next = [&] {
+      const size_t i = to_start.fetch_add(1);
+      if (i >= instances.size()) return;
+      Instance &inst = *instances[i];
+      inst.t_start = now_s();
+      {
+        std::lock_guard<std::mutex> l(S.m);
+        S.pending_instances++;
+      }
+      S.enqueue(&inst, leaves[i]);
+    };
+    S.on_block_complete = start_next;
+    S.n_workers = n_workers;
+    for (int k = 0; k < opt.blocks_in_flight; k++) start_next();
+    std::vector<std::thread> threads;
+    for (size_t w = 0; w < n_workers; w++)
+      threads.emplace_back([&, w] {
+        worker_loop(opt, S, opt.dry_run ? nullptr : &workers[w / per_worker], shared,
+                    opt.callers > 0 && !opt.dry_run ? 1 : (size_t)opt.batch, dry_slots ? &slot_jobs[w] : nullptr);
+      });
+    for (auto &t : threads) t.join();
+    next = instances.size();
+  }
+  // (default) instances are started in waves of --blocks-in-flight; the next wave starts when the queue has drained
   while (next < instances.size() && !S.failed) {
     const size_t wave_end = std::min(instances.size(), next + (size_t)opt.blocks_in_flight);
     {
@@ -831,14 +902,14 @@ int run_qbench(const Options &opt) {
   printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"%s\", \"dumps\": %zu, \"iterations\": %d, \"blocks\": %zu, \"blocks_complete\": %zu, "
          "\"jobs\": %zu, \"proofs\": %zu, \"jobs_per_block\": %.1f, \"proofs_per_block\": %.1f, \"wall_s\": %.6f, \"blocks_per_s\": %.4f, "
          "\"proofs_per_s\": %.2f, \"mean_block_latency_ms\": %.2f, \"devices\": [%s], \"contexts_per_device\": %d, \"workers\": %zu, "
-         "\"callers_per_context\": %d, \"lanes_per_context\": %d, \"linger_us\": %d, \"max_batch\": %d, \"blocks_in_flight\": %d, \"proofs_byte_checked\": %zu, \"distinct_proofs\": %zu, \"distinct_proofs_equal_to_recorded_bytes\": %zu, \"distinct_proofs_cp_verified\": %zu, "
+         "\"callers_per_context\": %d, \"lanes_per_context\": %d, \"linger_us\": %d, \"max_batch\": %d, \"blocks_in_flight\": %d, \"window\": \"%s\", \"proofs_byte_checked\": %zu, \"distinct_proofs\": %zu, \"distinct_proofs_equal_to_recorded_bytes\": %zu, \"distinct_proofs_cp_verified\": %zu, "
          "\"circuits\": %zu, \"witnesses\": %zu, \"batch_classes\": %d, \"launches\": %zu, \"mean_batch\": %.2f, \"dry_run_jobs_per_device\": %s, "
          "\"groth16_proofs\": %zu, \"groth16_log_constraints\": %d, \"pack\": \"%s\", \"timed\": \"from the first enqueue to the "
          "last completion; circuits resident, witnesses page-locked on the host (PCIe-inclusive), witness generation excluded\"}\n",
          opt.dry_run ? "dry-run" : "qbench", dumps.size(), opt.iterations, instances.size(), complete, jobs, proofs,
          instances.empty() ? 0.0 : (double)jobs / instances.size(), instances.empty() ? 0.0 : (double)proofs / instances.size(), wall,
          wall > 0 ? complete / wall : 0.0, wall > 0 ? proofs / wall : 0.0, complete ? latency_sum / complete * 1e3 : 0.0, devs.c_str(), opt.contexts,
-         n_workers, opt.dry_run ? 0 : opt.callers, opt.lanes, opt.linger_us, opt.batch, opt.blocks_in_flight, parity, oracle_checked + verified,
+         n_workers, opt.dry_run ? 0 : opt.callers, opt.lanes, opt.linger_us, opt.batch, opt.blocks_in_flight, opt.sliding ? "sliding" : "waves", parity, oracle_checked + verified,
          oracle_checked, verified, pack.circuit_files.size(), pack.witnesses.size(), n_classes, launches, launches ? (double)launched / launches : 0.0,
          per_device.c_str(), groth16_proofs, opt.groth16_log, json_escape(opt.pack_dir).c_str());
   for (auto &w : workers) w.close();
@@ -1128,6 +1199,7 @@ int main(int argc, char **argv) {
     else if (a == "--groth16-log-size") opt.groth16_log = atoi(val().c_str());
     else if (a == "--dry-run") opt.dry_run = true;
     else if (a == "--skip-gate") opt.skip_gate = true;
+    else if (a == "--sliding") opt.sliding = true;
     else if (a == "--redis") opt.redis_uri = val();
     else if (a == "--drain") opt.drain = true;
     else if (a == "--max-jobs") opt.max_jobs = atoi(val().c_str());
