@@ -16,11 +16,15 @@
 //     --devices (default: every visible GPU) — pulling one shared ready queue (the in-process form of N worker processes
 //     on one Redis queue, city_rollup_core_worker/src/lib.rs:131-145); --contexts 1 --devices 0 --batch 1 is the
 //     reference's single-threaded loop, job for job in the same order;
-//   * a worker takes up to --batch ready jobs whose circuits may share a launch (cp_circuits_batch_compatible: one shape, one
-//     gate set — whatever their circuit TYPES) and proves them stage by stage, one cp_prove_batch_host call per stage and
-//     compatibility class (a job's `duration` is then the wall time of the batch it was part of);
+//   * a worker takes up to --batch ready STAGES of jobs whose circuits may share a launch (cp_circuits_batch_compatible: one
+//     shape, one gate set — whatever their circuit TYPES) and proves them in one cp_prove_batch_host call; a job of k proofs
+//     (proofs_per_job) goes through the queue k times, its next stage ahead of what has not started (a job's `duration` runs
+//     from the start of its first stage to the end of its last). The ready stage with the longest chain of dependent proofs
+//     behind it is served first; a short queue is shared among the workers that hold no work (Scheduler::take);
 //   * --blocks-in-flight F replays F (dump, iteration) instances concurrently, each with its own proof store
-//     (BASELINE.json configs[3]: independent blocks); F = 1 is the reference's one-block-at-a-time loop;
+//     (BASELINE.json configs[3]: independent blocks), in waves of F (--sliding: a window of F, a block that completes
+//     starts the next — measured slower: blocks out of step leave small launches); F = 1 is the reference's
+//     one-block-at-a-time loop;
 //   * circuits come from a circuit pack (tools/qbench/pack.h): `CircuitData` cannot be built without Rust, so every job
 //     type is bound to circuit files + witnesses — dumped from the real worker, or the synthetic shape-equivalent ones —
 //     and witness generation is not part of what is timed. The DATA dependencies are real all the same: a
