@@ -119,10 +119,10 @@ GL_HD void mul_wide(uint64_t a, uint64_t b, uint64_t &lo, uint64_t &hi) {
   lo = pack(lo32(p00), lo32(r));
   hi = (uint64_t)a1 * b1 + pack(hi32(r), cbit);
 #else
-  const uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
-  const uint64_t p11 = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);
-  lo = pack(lo32(p00), lo32(p10));
-  hi = p11;
+  (void)p01;
+  const u128 p = (u128)a * b;  // the host has the instruction
+  lo = (uint64_t)p;
+  hi = (uint64_t)(p >> 64);
 #endif
 }
 

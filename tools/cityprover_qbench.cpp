@@ -207,11 +207,12 @@ struct Scheduler {
     out.push_back(queue.front());
     queue.pop_front();
     const JobId first = out[0].job;
-    if (first.topic == qb::GenerateStandardProof && max_batch > 1 && n_workers > 1 && share_short_queues && pending_instances < n_workers) {
-      // With FEWER BLOCKS IN FLIGHT THAN WORKERS the run is about latency, and a short queue is shared among the workers instead
-      // of going to whoever woke first: one block alone, twenty ready leaves, is three launches on three contexts at once, not
-      // one launch while two contexts idle (78 ms against 85 ms per block). With more blocks in flight the run is about
-      // throughput and every launch takes all it can: splitting then costs 6-8 % (profiles/r03_qbench_queue_sharing.txt).
+    if (first.topic == qb::GenerateStandardProof && max_batch > 1 && n_workers > 1 && share_short_queues) {
+      // A queue that the free workers could empty between them is SHARED among them instead of going to whoever woke first: one
+      // block alone, twenty-three ready stages, is three launches on three contexts at once, not one launch while two contexts
+      // idle (67 ms against 80 ms per block); with 4 blocks in flight +14 %, with 8 +2.5 %, from 16 up the queue is long enough
+      // for full launches and nothing changes (profiles/r03_qbench_share_ab.jsonl; with round 2's cap of 32 proofs per launch
+      // the rule cost 6-8 % there and was limited to runs with fewer blocks than workers).
       size_t ready = 1;
       for (const auto &e : queue)
         if (e.job.topic == qb::GenerateStandardProof && cls(e) == cls(out[0])) ready++;
