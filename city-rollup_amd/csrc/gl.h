@@ -12,6 +12,13 @@
 #include <stdint.h>
 
 #define GL_HD __host__ __device__ __forceinline__
+// device code takes the hand-scheduled `asm` forms below; GL_PORTABLE (experiments: tools/ubench_leaf_latency.hip) builds the
+// portable C forms for the device too
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_PORTABLE)
+#define GL_DEVICE_ASM 1
+#else
+#define GL_DEVICE_ASM 0
+#endif
 
 namespace gl {
 
@@ -65,7 +72,7 @@ GL_HD uint64_t add_lazy(uint64_t a, uint64_t b) {
 
 // lo + top * (2^32 - 1) as a lazy u64 (top * 2^64 == top * (2^32 - 1))
 GL_HD uint64_t fold_top(uint64_t lo, uint32_t top) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if GL_DEVICE_ASM
   // one multiply-add; its carry-out (one wrap of 2^64 == + EPS) selects the repair. The repaired sum cannot wrap again:
   // lo + top (2^32 - 1) < 2^65 - 2^33, so after one wrap it is below 2^64 - 2^33.
   uint64_t r, cy;
@@ -82,7 +89,7 @@ GL_HD uint64_t fold_top(uint64_t lo, uint32_t top) {
 // every wrap of 2^64 repaid by -+EPS
 GL_HD uint64_t reduce128_lazy(uint64_t lo, uint64_t hi) {
   const uint32_t w2 = lo32(hi), w3 = hi32(hi);
-#if defined(__HIP_DEVICE_COMPILE__)
+#if GL_DEVICE_ASM
   // lo - w3 borrows only when lo < w3 < 2^32 (a 2^-32 event for a product): the repair (- EPS for the 2^64 that was lent)
   // sits behind a wave-uniform branch instead of costing three instructions on every multiplication
   uint32_t tl, th, m;
@@ -108,7 +115,7 @@ GL_HD void mul_wide(uint64_t a, uint64_t b, uint64_t &lo, uint64_t &hi) {
   const uint32_t a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
   const uint64_t p00 = (uint64_t)a0 * b0;
   const uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);  // < 2^64
-#if defined(__HIP_DEVICE_COMPILE__)
+#if GL_DEVICE_ASM
   // the third multiply-add takes the whole second one as its addend; its carry-out replaces two zero-extending moves
   // and a 64-bit addition
   uint64_t r, cr;
