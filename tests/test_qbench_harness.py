@@ -125,6 +125,26 @@ def test_sliding_window_of_blocks(golden_dir, tmp_path):
     assert "--sliding and --ref-counters" in run(["-i", dump, "--dry-run", "--sliding", "--ref-counters"], ok=False)
 
 
+def test_stage_units_in_the_dry_run(golden_dir, tmp_path):
+    """--dry-run-stages: every stage of a job is a queue entry of its own (as in a real run). The block still completes with 46
+    jobs = 64 proofs, each job is recorded once, the pop order lists every job once (first stages only), and a job's recorded
+    duration spans all its stages."""
+    dump = os.path.join(golden_dir, "qbench_example.bin")
+    out, trace = str(tmp_path / "out.json"), str(tmp_path / "trace.jsonl")
+    res = run(["-i", dump, "-o", out, "--dry-run", "--dry-run-stages", "--dry-run-job-us", "1000", "--contexts", "3", "--batch", "8",
+               "-n", "2", "--trace", trace])
+    assert res["blocks_complete"] == 2 and res["jobs"] == 92 and res["proofs"] == 128
+    bench = json.load(open(out))
+    from collections import Counter
+    assert len(bench) == 92 and set(Counter(b["job_id"] for b in bench).values()) == {2}
+    rows = [json.loads(l) for l in open(trace)]
+    assert sum(1 for r in rows if "popped" in r) == 2 * 60
+    timed = [r for r in rows if "job_id" in r]
+    five = [r for r in timed if r["circuit_type"] == 33]          # the sighash introspection jobs: five proofs each
+    one = [r for r in timed if r["circuit_type"] == 0]            # the register-user leaves: one proof each
+    assert min(r["end_ms"] - r["start_ms"] for r in five) >= 4.5 and max(r["end_ms"] - r["start_ms"] for r in one) < 4.5
+
+
 def test_reference_counter_quirk(golden_dir, tmp_path):
     """The reference never resets `counters` between iterations (memory_proof_store/mod.rs:77-83; qbench.rs:44-61): from
     the second iteration on no group reaches its goal and only the 23 leaf jobs run. --ref-counters reproduces that."""
@@ -223,7 +243,11 @@ def test_scheduler_under_thread_sanitizer(golden_dir, tmp_path):
         raise AssertionError(r.stderr[-3000:])
     dump = os.path.join(golden_dir, "qbench_example.bin")
     for args in (["--contexts", "32", "--batch", "1", "-n", "16", "--blocks-in-flight", "4"],
-                 ["--contexts", "16", "--batch", "4", "-n", "8", "--blocks-in-flight", "8"]):
+                 ["--contexts", "16", "--batch", "4", "-n", "8", "--blocks-in-flight", "8"],
+                 # the stage machinery (a job of k proofs passes through the queue k times: requeue, longest chain first,
+                 # shared short queues) and the sliding window, with simulated launch times so that the workers interleave
+                 ["--contexts", "6", "--batch", "8", "-n", "12", "--blocks-in-flight", "3", "--dry-run-stages", "--dry-run-job-us", "200"],
+                 ["--contexts", "6", "--batch", "8", "-n", "12", "--blocks-in-flight", "3", "--dry-run-stages", "--dry-run-job-us", "200", "--sliding"]):
         r = subprocess.run([exe, "-i", dump, "--dry-run"] + args, capture_output=True, text=True, timeout=300)
         assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
         assert r.returncode == 0, r.stderr[-1000:]

@@ -88,6 +88,7 @@ struct Options {
   bool drain = false;     // redis-worker: leave when the JOB queue is empty instead of polling for ever
   int max_jobs = 0;       // redis-worker: leave after this many jobs (0: no limit)
   int iterations = 1, contexts = 3, batch = 128, blocks_in_flight = 1, lanes = 1, iters = 8, callers = 0, linger_us = 0;
+  bool dry_stages = false;  // --dry-run-stages: every stage of a job is a queue entry, as in a real run
   int dry_job_us = 0;   // --dry-run only: pretend a proving batch takes this long, so that the queue is shared among the worker slots
   int groth16_log = 0;  // > 0: the Groth16 job runs cp_groth16_prove_bls12381 on a synthetic key of 2^groth16_log constraints
   std::vector<int> devices;  // empty: all visible
@@ -614,6 +615,12 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
     } else {
       for (auto &o : outputs) o.assign(1, 0);  // placeholder: "an output exists"
       if (opt.dry_job_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(opt.dry_job_us));
+      if (opt.dry_stages)  // the stage machinery without a GPU: a job of k proofs goes through the queue k times
+        for (size_t i = 0; i < batch.size(); i++)
+          if (batch[i].stage + 1 < qb::proofs_per_job(batch[i].job.circuit_type)) {
+            done[i] = 1;
+            S.requeue({batch[i].inst, batch[i].job, batch[i].chain > 0 ? batch[i].chain - 1 : 0, batch[i].stage + 1, t_first(i)});
+          }
     }
   }
   for (size_t i = 0; i < batch.size(); i++) finish(i);
@@ -1209,6 +1216,7 @@ int main(int argc, char **argv) {
     else if (a == "--drain") opt.drain = true;
     else if (a == "--max-jobs") opt.max_jobs = atoi(val().c_str());
     else if (a == "--dry-run-job-us") opt.dry_job_us = atoi(val().c_str());
+    else if (a == "--dry-run-stages") opt.dry_stages = true;
     else if (a == "--ref-counters") opt.ref_counters = true;
     else if (a == "--check-plan") opt.check_plan = true;
     else if (a == "--devices") {
