@@ -122,6 +122,31 @@ def test_two_workers_share_the_queue(golden_dir):
         assert r.store.queue_bodies("NOTIFICATIONS") == [b"0"] and r.store.queue_bodies("JOB") == []
 
 
+def test_rounds_of_several_messages(golden_dir):
+    """--redis-batch N: a round takes up to N messages that are in the queue and does the jobs together (on the GPU: shared
+    launches). Same outputs, same counters, one notification; fewer rounds than messages; the order of service is a
+    permutation of the reference's."""
+    with FakeRedis() as r:
+        load_block(r, golden_dir)
+        p = worker(r.uri, "--redis-batch", "8")
+        assert p.returncode == 0, p.stderr
+        res = json.loads(p.stdout.strip().splitlines()[-1])
+        assert res["jobs"] == 60 and res["proving_jobs"] == 46 and res["proofs"] == 64 and res["notifications"] == 1 and res["queue_left"] == 0
+        assert res["redis_batch"] == 8 and 8 <= res["rounds"] < 60
+        want = expected_pop_order(golden_dir)
+        assert sorted(job_tuple(b) for b in r.store.popped[b"rsmq:JOB"]) == sorted(want)
+        proofs = r.store.hashes[b"proofs"]
+        assert {key_of(j, 8) for j in want if j[0] == 0} <= set(proofs)
+        dag = json.load(open(os.path.join(golden_dir, "example_job_dag.json")))
+        for g in dag:
+            assert int(r.store.hashes[b"proof_counters"][key_of(tuple(g["group"]) + (0,), 16)]) == g["goal"]
+        assert r.store.queue_bodies("NOTIFICATIONS") == [b"0"]
+    with FakeRedis() as r:       # --max-jobs is honoured inside a round too
+        load_block(r, golden_dir)
+        p = worker(r.uri, "--redis-batch", "8", "--max-jobs", "13")
+        assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["jobs"] == 13
+
+
 def test_max_jobs_and_resume(golden_dir):
     """a worker that stops (here: --max-jobs) leaves a state another one picks up: nothing is held outside Redis"""
     with FakeRedis() as r:
@@ -195,3 +220,14 @@ def test_redis_worker_proves_the_block_on_the_gpu(golden_dir, tmp_path):
         outs = [k for k in proofs if k[22] == 8]
         assert len(outs) == 46 and all(len(proofs[k]) > 1_000 for k in outs if k[9] != 36)
         assert r.store.queue_bodies("NOTIFICATIONS") == [b"0"]
+        one_by_one = {k: proofs[k] for k in outs}
+    # rounds of up to 16 messages: shared launches, the same bytes for every job
+    with FakeRedis() as r:
+        load_block(r, golden_dir)
+        p = subprocess.run([EXE, "--mode", "redis-worker", "--redis", r.uri, "--pack", pack, "--drain", "--redis-batch", "16"],
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr
+        res = json.loads(p.stdout.strip().splitlines()[-1])
+        assert res["jobs"] == 60 and res["proofs"] == 64 and res["rounds"] < 40 and res["launches"] < 64
+        proofs = r.store.hashes[b"proofs"]
+        assert {k: proofs[k] for k in proofs if k[22] == 8} == one_by_one

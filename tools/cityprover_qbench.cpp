@@ -87,6 +87,7 @@ struct Options {
   std::string redis_uri;  // --mode redis-worker: the deployment's Redis (proof store + RSMQ queues)
   bool drain = false;     // redis-worker: leave when the JOB queue is empty instead of polling for ever
   int max_jobs = 0;       // redis-worker: leave after this many jobs (0: no limit)
+  int redis_batch = 1;    // redis-worker: messages taken per round (1 = the reference's loop)
   int iterations = 1, contexts = 3, batch = 128, blocks_in_flight = 1, lanes = 1, iters = 8, callers = 0, linger_us = 0;
   bool dry_stages = false;  // --dry-run-stages: every stage of a job is a queue entry, as in a real run
   int dry_job_us = 0;   // --dry-run only: pretend a proving batch takes this long, so that the queue is shared among the worker slots
@@ -1133,54 +1134,98 @@ int run_redis_worker(const Options &opt) {
     expected.assign(pack.witnesses.size(), {});
     worker.gate(expected, nullptr, nullptr);
   }
-  size_t jobs = 0, proving_jobs = 0, proofs = 0, released = 0, notifications = 0, polls = 0;
+  size_t jobs = 0, proving_jobs = 0, proofs = 0, released = 0, notifications = 0, polls = 0, rounds = 0, launches = 0;
+  // --redis-batch N (default 1: the reference's loop, one job per pop): a round takes up to N messages that are in the queue
+  // NOW and proves their jobs together — stage by stage, one launch per stage and batch-compatibility class — before it does the
+  // bookkeeping of each in pop order. A job is only ever in the queue after everything it depends on has been stored, so the
+  // jobs of a round are independent of each other.
+  const size_t take = opt.redis_batch > 1 ? (size_t)opt.redis_batch : 1;
+  std::vector<int> cls;
+  if (!opt.dry_run) cls = worker.circuit_classes();
   const double t0 = now_s();
   for (;;) {
-    if (opt.max_jobs > 0 && (int)jobs >= opt.max_jobs) break;
-    std::string body;
-    if (!queue.pop("JOB", body)) {
-      if (opt.drain) break;
+    std::vector<JobId> round;
+    while (round.size() < take && !(opt.max_jobs > 0 && jobs + round.size() >= (size_t)opt.max_jobs)) {
+      std::string body;
+      if (!queue.pop("JOB", body)) break;
+      round.push_back(qb::job_from_json(body));
+    }
+    if (round.empty()) {
+      if (opt.drain || (opt.max_jobs > 0 && (int)jobs >= opt.max_jobs)) break;
       polls++;
       std::this_thread::sleep_for(std::chrono::milliseconds(250));  // event_processor.rs:36
       continue;
     }
-    const JobId job = qb::job_from_json(body);
-    jobs++;
-    if (job.topic == qb::GenerateStandardProof) {
+    rounds++;
+    std::vector<std::vector<uint8_t>> outputs(round.size(), std::vector<uint8_t>(1, 0));
+    std::vector<size_t> proving;
+    for (size_t i = 0; i < round.size(); i++) {
+      const JobId &job = round[i];
+      if (job.topic != qb::GenerateStandardProof) continue;
       const std::vector<uint8_t> w = store.get_bytes(job);  // the witness must be there, and every proof it names
       for (const JobId &dep : qb::proof_dependencies(job, w))
         if (store.get_bytes(dep).empty()) throw qb::StoreError("Proof " + dep.hex() + " needed by " + job.hex() + " is empty");
-      std::vector<uint8_t> output(1, 0);
-      const int n_stages = qb::proofs_per_job(job.circuit_type);
-      if (!opt.dry_run) {
-        const auto &stages = pack.stages_for(job.circuit_type);
-        if ((int)stages.size() != n_stages) throw std::runtime_error("the pack binds the wrong number of stages to circuit type " + std::to_string(job.circuit_type));
-        for (int s = 0; s < n_stages; s++) {
-          auto pr = worker.prove_items({{stages[s].circuit, stages[s].witness_for(job.task_index)}}, &expected);
-          if (s + 1 == n_stages) output = std::move(pr[0]);
+      proving.push_back(i);
+    }
+    if (!opt.dry_run && !proving.empty()) {
+      int max_stages = 0;
+      for (size_t i : proving) {
+        const int n_stages = qb::proofs_per_job(round[i].circuit_type);
+        if ((int)pack.stages_for(round[i].circuit_type).size() != n_stages)
+          throw std::runtime_error("the pack binds the wrong number of stages to circuit type " + std::to_string(round[i].circuit_type));
+        max_stages = std::max(max_stages, n_stages);
+      }
+      for (int s = 0; s < max_stages; s++) {
+        std::vector<std::pair<int, size_t>> order;  // (class of the stage's circuit, job)
+        for (size_t i : proving) {
+          const auto &st = pack.stages_for(round[i].circuit_type);
+          if (s < (int)st.size()) order.push_back({cls[st[(size_t)s].circuit], i});
+        }
+        std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+        for (size_t lo = 0; lo < order.size();) {
+          size_t hi = lo;
+          std::vector<Worker::Item> items;
+          while (hi < order.size() && order[hi].first == order[lo].first) {
+            const JobId &job = round[order[hi].second];
+            const qb::Binding &b = pack.stages_for(job.circuit_type)[(size_t)s];
+            items.push_back({b.circuit, b.witness_for(job.task_index)});
+            hi++;
+          }
+          auto pr = worker.prove_items(items, &expected);
+          launches++;
+          for (size_t k = lo; k < hi; k++)
+            if (s + 1 == (int)pack.stages_for(round[order[k].second].circuit_type).size()) outputs[order[k].second] = std::move(pr[k - lo]);
+          lo = hi;
         }
       }
-      if (job.circuit_type == qb::WrapFinalSigHashProofBLS12381) output = zero_groth16_bincode();  // GROTH16_DISABLED_DEV_MODE
-      store.set_bytes(job.output_id(), output);
-      proving_jobs++;
-      proofs += (size_t)n_stages;
     }
-    if (job.topic == qb::NotifyOrchestratorComplete) {
-      queue.send("NOTIFICATIONS", "0");  // serde_json of QueueNotification::CoreJobCompleted (serde_repr u8)
-      notifications++;
-      continue;
-    }
-    const uint32_t goal = store.get_goal(job);
-    if (goal != 0 && store.inc_counter(job.counter_id()) == goal)
-      for (const JobId &nj : store.get_next_jobs(job)) {
-        queue.send("JOB", qb::job_to_json(nj));
-        released++;
+    for (size_t i = 0; i < round.size(); i++) {  // the tail of process_job for each, in pop order
+      const JobId &job = round[i];
+      jobs++;
+      if (job.topic == qb::GenerateStandardProof) {
+        if (job.circuit_type == qb::WrapFinalSigHashProofBLS12381) outputs[i] = zero_groth16_bincode();  // GROTH16_DISABLED_DEV_MODE
+        store.set_bytes(job.output_id(), outputs[i]);
+        proving_jobs++;
+        proofs += (size_t)qb::proofs_per_job(job.circuit_type);
       }
+      if (job.topic == qb::NotifyOrchestratorComplete) {
+        queue.send("NOTIFICATIONS", "0");  // serde_json of QueueNotification::CoreJobCompleted (serde_repr u8)
+        notifications++;
+        continue;
+      }
+      const uint32_t goal = store.get_goal(job);
+      if (goal != 0 && store.inc_counter(job.counter_id()) == goal)
+        for (const JobId &nj : store.get_next_jobs(job)) {
+          queue.send("JOB", qb::job_to_json(nj));
+          released++;
+        }
+    }
   }
   const double wall = now_s() - t0;
   printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"redis-worker\", \"dry_run\": %s, \"redis\": \"%s\", \"jobs\": %zu, \"proving_jobs\": %zu, "
-         "\"proofs\": %zu, \"jobs_released\": %zu, \"notifications\": %zu, \"idle_polls\": %zu, \"queue_left\": %lld, \"wall_s\": %.6f}\n",
-         opt.dry_run ? "true" : "false", json_escape(opt.redis_uri).c_str(), jobs, proving_jobs, proofs, released, notifications, polls, queue.size("JOB"), wall);
+         "\"proofs\": %zu, \"jobs_released\": %zu, \"notifications\": %zu, \"idle_polls\": %zu, \"queue_left\": %lld, \"redis_batch\": %zu, \"rounds\": %zu, \"launches\": %zu, \"wall_s\": %.6f, \"proofs_per_s\": %.2f}\n",
+         opt.dry_run ? "true" : "false", json_escape(opt.redis_uri).c_str(), jobs, proving_jobs, proofs, released, notifications, polls, queue.size("JOB"), take,
+         rounds, launches, wall, wall > 0 ? proofs / wall : 0.0);
   if (!opt.dry_run) worker.close();
   return 0;
 }
@@ -1215,6 +1260,7 @@ int main(int argc, char **argv) {
     else if (a == "--redis") opt.redis_uri = val();
     else if (a == "--drain") opt.drain = true;
     else if (a == "--max-jobs") opt.max_jobs = atoi(val().c_str());
+    else if (a == "--redis-batch") opt.redis_batch = atoi(val().c_str());
     else if (a == "--dry-run-job-us") opt.dry_job_us = atoi(val().c_str());
     else if (a == "--dry-run-stages") opt.dry_stages = true;
     else if (a == "--ref-counters") opt.ref_counters = true;
