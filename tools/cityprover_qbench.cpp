@@ -1135,91 +1135,92 @@ int run_redis_worker(const Options &opt) {
     worker.gate(expected, nullptr, nullptr);
   }
   size_t jobs = 0, proving_jobs = 0, proofs = 0, released = 0, notifications = 0, polls = 0, rounds = 0, launches = 0;
-  // --redis-batch N (default 1: the reference's loop, one job per pop): a round takes up to N messages that are in the queue
-  // NOW and proves their jobs together — stage by stage, one launch per stage and batch-compatibility class — before it does the
-  // bookkeeping of each in pop order. A job is only ever in the queue after everything it depends on has been stored, so the
-  // jobs of a round are independent of each other.
+  // --redis-batch N (default 1: the reference's loop, one job per pop): the worker keeps up to N jobs open. A round (1) takes
+  // messages that are in the queue NOW until N jobs are open, (2) proves ONE stage of every open job — one launch per
+  // batch-compatibility class, (3) does the bookkeeping of the jobs whose last stage that was (output, counter, next jobs: they
+  // can be in the very next round's launch) and keeps the others for their next stage. A job is only ever in the queue after
+  // everything it depends on has been stored, so open jobs are independent of each other.
   const size_t take = opt.redis_batch > 1 ? (size_t)opt.redis_batch : 1;
   std::vector<int> cls;
   if (!opt.dry_run) cls = worker.circuit_classes();
+  struct Open { JobId job; int stage; };
+  std::vector<Open> open;
+  // the tail of process_job (actors/simple.rs:89-115) for one job
+  auto complete = [&](const JobId &job, std::vector<uint8_t> output) {
+    jobs++;
+    if (job.topic == qb::GenerateStandardProof) {
+      if (job.circuit_type == qb::WrapFinalSigHashProofBLS12381) output = zero_groth16_bincode();  // GROTH16_DISABLED_DEV_MODE
+      store.set_bytes(job.output_id(), output);
+      proving_jobs++;
+      proofs += (size_t)qb::proofs_per_job(job.circuit_type);
+    }
+    if (job.topic == qb::NotifyOrchestratorComplete) {
+      queue.send("NOTIFICATIONS", "0");  // serde_json of QueueNotification::CoreJobCompleted (serde_repr u8)
+      notifications++;
+      return;
+    }
+    const uint32_t goal = store.get_goal(job);
+    if (goal != 0 && store.inc_counter(job.counter_id()) == goal)
+      for (const JobId &nj : store.get_next_jobs(job)) {
+        queue.send("JOB", qb::job_to_json(nj));
+        released++;
+      }
+  };
+  size_t taken = 0;
   const double t0 = now_s();
   for (;;) {
-    std::vector<JobId> round;
-    while (round.size() < take && !(opt.max_jobs > 0 && jobs + round.size() >= (size_t)opt.max_jobs)) {
+    while (open.size() < take && !(opt.max_jobs > 0 && taken >= (size_t)opt.max_jobs)) {
       std::string body;
       if (!queue.pop("JOB", body)) break;
-      round.push_back(qb::job_from_json(body));
+      const JobId job = qb::job_from_json(body);
+      taken++;
+      if (job.topic != qb::GenerateStandardProof) {  // barrier and notify jobs: nothing to prove
+        complete(job, {});
+        continue;
+      }
+      const std::vector<uint8_t> w = store.get_bytes(job);  // the witness must be there, and every proof it names
+      for (const JobId &dep : qb::proof_dependencies(job, w))
+        if (store.get_bytes(dep).empty()) throw qb::StoreError("Proof " + dep.hex() + " needed by " + job.hex() + " is empty");
+      if (!opt.dry_run && (int)pack.stages_for(job.circuit_type).size() != qb::proofs_per_job(job.circuit_type))
+        throw std::runtime_error("the pack binds the wrong number of stages to circuit type " + std::to_string(job.circuit_type));
+      open.push_back({job, 0});
     }
-    if (round.empty()) {
-      if (opt.drain || (opt.max_jobs > 0 && (int)jobs >= opt.max_jobs)) break;
+    if (open.empty()) {
+      if (opt.drain || (opt.max_jobs > 0 && taken >= (size_t)opt.max_jobs)) {
+        if (queue.size("JOB") == 0 || (opt.max_jobs > 0 && taken >= (size_t)opt.max_jobs)) break;
+        continue;  // barrier jobs released more work while this round was taking messages
+      }
       polls++;
       std::this_thread::sleep_for(std::chrono::milliseconds(250));  // event_processor.rs:36
       continue;
     }
     rounds++;
-    std::vector<std::vector<uint8_t>> outputs(round.size(), std::vector<uint8_t>(1, 0));
-    std::vector<size_t> proving;
-    for (size_t i = 0; i < round.size(); i++) {
-      const JobId &job = round[i];
-      if (job.topic != qb::GenerateStandardProof) continue;
-      const std::vector<uint8_t> w = store.get_bytes(job);  // the witness must be there, and every proof it names
-      for (const JobId &dep : qb::proof_dependencies(job, w))
-        if (store.get_bytes(dep).empty()) throw qb::StoreError("Proof " + dep.hex() + " needed by " + job.hex() + " is empty");
-      proving.push_back(i);
-    }
-    if (!opt.dry_run && !proving.empty()) {
-      int max_stages = 0;
-      for (size_t i : proving) {
-        const int n_stages = qb::proofs_per_job(round[i].circuit_type);
-        if ((int)pack.stages_for(round[i].circuit_type).size() != n_stages)
-          throw std::runtime_error("the pack binds the wrong number of stages to circuit type " + std::to_string(round[i].circuit_type));
-        max_stages = std::max(max_stages, n_stages);
-      }
-      for (int s = 0; s < max_stages; s++) {
-        std::vector<std::pair<int, size_t>> order;  // (class of the stage's circuit, job)
-        for (size_t i : proving) {
-          const auto &st = pack.stages_for(round[i].circuit_type);
-          if (s < (int)st.size()) order.push_back({cls[st[(size_t)s].circuit], i});
+    std::vector<std::vector<uint8_t>> stage_out(open.size(), std::vector<uint8_t>(1, 0));
+    if (!opt.dry_run) {
+      std::vector<std::pair<int, size_t>> order;  // (class of the stage's circuit, open job)
+      for (size_t i = 0; i < open.size(); i++) order.push_back({cls[pack.stages_for(open[i].job.circuit_type)[(size_t)open[i].stage].circuit], i});
+      std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+      for (size_t lo = 0; lo < order.size();) {
+        size_t hi = lo;
+        std::vector<Worker::Item> items;
+        while (hi < order.size() && order[hi].first == order[lo].first) {
+          const Open &o = open[order[hi].second];
+          const qb::Binding &b = pack.stages_for(o.job.circuit_type)[(size_t)o.stage];
+          items.push_back({b.circuit, b.witness_for(o.job.task_index)});
+          hi++;
         }
-        std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
-        for (size_t lo = 0; lo < order.size();) {
-          size_t hi = lo;
-          std::vector<Worker::Item> items;
-          while (hi < order.size() && order[hi].first == order[lo].first) {
-            const JobId &job = round[order[hi].second];
-            const qb::Binding &b = pack.stages_for(job.circuit_type)[(size_t)s];
-            items.push_back({b.circuit, b.witness_for(job.task_index)});
-            hi++;
-          }
-          auto pr = worker.prove_items(items, &expected);
-          launches++;
-          for (size_t k = lo; k < hi; k++)
-            if (s + 1 == (int)pack.stages_for(round[order[k].second].circuit_type).size()) outputs[order[k].second] = std::move(pr[k - lo]);
-          lo = hi;
-        }
+        auto pr = worker.prove_items(items, &expected);
+        launches++;
+        for (size_t k = lo; k < hi; k++) stage_out[order[k].second] = std::move(pr[k - lo]);
+        lo = hi;
       }
     }
-    for (size_t i = 0; i < round.size(); i++) {  // the tail of process_job for each, in pop order
-      const JobId &job = round[i];
-      jobs++;
-      if (job.topic == qb::GenerateStandardProof) {
-        if (job.circuit_type == qb::WrapFinalSigHashProofBLS12381) outputs[i] = zero_groth16_bincode();  // GROTH16_DISABLED_DEV_MODE
-        store.set_bytes(job.output_id(), outputs[i]);
-        proving_jobs++;
-        proofs += (size_t)qb::proofs_per_job(job.circuit_type);
-      }
-      if (job.topic == qb::NotifyOrchestratorComplete) {
-        queue.send("NOTIFICATIONS", "0");  // serde_json of QueueNotification::CoreJobCompleted (serde_repr u8)
-        notifications++;
-        continue;
-      }
-      const uint32_t goal = store.get_goal(job);
-      if (goal != 0 && store.inc_counter(job.counter_id()) == goal)
-        for (const JobId &nj : store.get_next_jobs(job)) {
-          queue.send("JOB", qb::job_to_json(nj));
-          released++;
-        }
+    std::vector<Open> still;
+    for (size_t i = 0; i < open.size(); i++) {
+      if (open[i].stage + 1 == qb::proofs_per_job(open[i].job.circuit_type)) complete(open[i].job, std::move(stage_out[i]));
+      else still.push_back({open[i].job, open[i].stage + 1});
     }
+    open.swap(still);
   }
   const double wall = now_s() - t0;
   printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"redis-worker\", \"dry_run\": %s, \"redis\": \"%s\", \"jobs\": %zu, \"proving_jobs\": %zu, "
