@@ -109,12 +109,6 @@ int upload_constants(cp_ctx *ctx) {
   HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_RCD), POSEIDON_RCD, sizeof POSEIDON_RCD));
   HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DDK), POSEIDON_DOMD_K, sizeof POSEIDON_DOMD_K));
   HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_DDLAST), POSEIDON_DOMD_LAST, sizeof POSEIDON_DOMD_LAST));
-  // the sparse partial rounds of the twelve-lane permutation (poseidon_coop.h)
-  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(pcoop::d_FFIRST), POSEIDON_FAST_FIRST, sizeof POSEIDON_FAST_FIRST));
-  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(pcoop::d_FK), POSEIDON_FAST_K, sizeof POSEIDON_FAST_K));
-  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(pcoop::d_FVS), POSEIDON_FAST_VS, sizeof POSEIDON_FAST_VS));
-  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(pcoop::d_FWH), POSEIDON_FAST_WHATS, sizeof POSEIDON_FAST_WHATS));
-  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(pcoop::d_FINIT), POSEIDON_FAST_INIT, sizeof POSEIDON_FAST_INIT));
   return CP_OK;
 }
 

@@ -27,115 +27,38 @@ __device__ __forceinline__ uint32_t mds_coef(int e, int j) {
   return C[d] + ((e == 0 && j == 0) ? 8u : 0u);
 }
 
-// The sparse ("fast") form of the 22 partial rounds, poseidon_tables.h POSEIDON_FAST_* (gen_tables.py `fast_partial`, checked
-// against the textbook rounds by tests/test_tables.py): after   s += FIRST ; s[1..] <- INIT s[1..]   a partial round is
-//     s0 <- s0^7 + K[i] ;  d = 25 s0 + sum_j WHAT[i][j] s[1+j] ;  s[1+j] += VS[i][j] s0 ;  s[0] = d
-// In the twelve-lane form that is what a partial round should be: the eleven products WHAT[i][j] s[1+j] do not depend on the
-// S-box, so lanes 1..11 make them (one modular product each) WHILE lane 0 runs its chain of four, lane 0 adds them up, and the
-// new s0 reaches the other lanes by ds_bpermute for their one multiply-add — ~600 cycles against ~1 000 for the textbook round,
-// whose full 12 x 12 MDS (LDS exchange, twelve-term dot product) follows the S-box on the critical path.
-__constant__ uint64_t d_FFIRST[12], d_FK[22], d_FVS[242], d_FWH[242], d_FINIT[121];
-
-// textbook full round: constant, S-box, MDS through LDS
-__device__ __forceinline__ uint64_t full_round(uint64_t x, uint64_t rc, uint64_t *mine, int e, bool lane_used, const uint32_t (&coef)[GROUP]) {
-  x = poseidon::sbox_lazy(poseidon::add_const_lazy(x, rc));
-  if (lane_used) mine[e] = x;  // lanes 60..63 shadow group 0 / element 0 and must not write
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // dot product in two 64-bit accumulators (low / high words of the lazy u64 elements): 12 x 41 x 2^32 < 2^41
-  uint64_t lo = 0, hi = 0;
-#pragma unroll
-  for (int j = 0; j < GROUP; j++) {
-    const uint64_t s = mine[j];
-    lo += (uint64_t)(uint32_t)s * coef[j];
-    hi += (uint64_t)(uint32_t)(s >> 32) * coef[j];
-  }
-  __builtin_amdgcn_wave_barrier();  // every lane has read the state before anyone overwrites it
-  // value = lo + hi * 2^32 < 2^74
-  const uint64_t l = lo + (hi << 32);
-  const uint64_t h = (hi >> 32) + (l < lo);
-  return gl::reduce128_lazy(l, h);
-}
-
-// the value `v` of lane `src` (a lane index of this wave), 64 bits
-__device__ __forceinline__ uint64_t from_lane(int src, uint64_t v) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)v);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)(v >> 32));
-  return gl::pack(lo, hi);
-}
-
 // One permutation per 12-lane group. x: this lane's element (any u64 representative on entry), returns the canonical
 // element. sh: the wave's LDS exchange area, STATES_PER_WAVE * 12 u64, 16-byte aligned. All 64 lanes of the wave must
 // call this together (lanes 60..63 and groups without a state carry dummies).
 __device__ __forceinline__ uint64_t permute(uint64_t x, int g, int e, bool lane_used, uint64_t *sh, const uint32_t (&coef)[GROUP]) {
   uint64_t *mine = sh + g * GROUP;
-  const int leader = (int)(threadIdx.x & 63) - e;  // lane of element 0 of this group
-  const int j = e >= 1 ? e - 1 : 0;                // this lane's column of the sparse tables (lane 0 loads column 0 and ignores it)
-  // the constants of this lane's element are per-lane (divergent) loads: fetched one round ahead, so that their latency (a few
-  // hundred cycles from L2) hides under the S-box instead of heading every round
+  // the round constant of this lane's element is a per-lane (divergent) load: fetched one round ahead, so that its
+  // latency (a few hundred cycles from L2) hides under the S-box instead of heading every round
   uint64_t rc_next = poseidon::d_RC[e];
 #pragma unroll 1
-  for (int r = 0; r < poseidon::HALF_FULL; r++) {
-    const uint64_t rc_cur = rc_next;
-    rc_next = r + 1 < poseidon::HALF_FULL ? poseidon::d_RC[(r + 1) * GROUP + e] : d_FFIRST[e];
-    x = full_round(x, rc_cur, mine, e, lane_used, coef);
-  }
-  // ---- into the sparse form: s += FIRST ; s[1..] <- INIT s[1..] ----
-  x = poseidon::add_const_lazy(x, rc_next);
-  {
-    uint64_t row[GROUP - 1];
-#pragma unroll
-    for (int c = 0; c < GROUP - 1; c++) row[c] = d_FINIT[j * (GROUP - 1) + c];
-    if (lane_used) mine[e] = x;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint64_t t[GROUP - 1];
-#pragma unroll
-    for (int c = 0; c < GROUP - 1; c++) t[c] = poseidon::mul_lazy(mine[1 + c], row[c]);  // eleven independent products
-    __builtin_amdgcn_wave_barrier();
-    const uint64_t y = gl::add_lazy(gl::add_lazy(gl::add_lazy(gl::add_lazy(t[0], t[1]), gl::add_lazy(t[2], t[3])),
-                                                 gl::add_lazy(gl::add_lazy(t[4], t[5]), gl::add_lazy(t[6], t[7]))),
-                                    gl::add_lazy(gl::add_lazy(t[8], t[9]), t[10]));
-    if (e >= 1) x = y;
-  }
-  // ---- 22 sparse partial rounds ----
-  uint64_t wh_next = d_FWH[j], vs_next = d_FVS[j];
-#pragma unroll 1
-  for (int i = 0; i < poseidon::PARTIAL; i++) {
-    const uint64_t wh = wh_next, vs = vs_next;
-    const int nx = (i + 1 < poseidon::PARTIAL ? i + 1 : i) * (GROUP - 1) + j;
-    wh_next = d_FWH[nx];
-    vs_next = d_FVS[nx];
-    // lanes 1..11: their term of the dot product, which does not wait for the S-box
-    const uint64_t p = poseidon::mul_lazy(x, wh);
-    if (lane_used && e >= 1) mine[e] = p;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint64_t s0 = 0, d = 0;
-    if (e == 0) {
-      uint64_t t[GROUP - 1];
-#pragma unroll
-      for (int c = 0; c < GROUP - 1; c++) t[c] = mine[1 + c];  // in flight while the S-box runs
-      s0 = poseidon::add_const_lazy(poseidon::sbox_lazy(x), d_FK[i]);
-      const uint64_t sum = gl::add_lazy(gl::add_lazy(gl::add_lazy(gl::add_lazy(t[0], t[1]), gl::add_lazy(t[2], t[3])),
-                                                     gl::add_lazy(gl::add_lazy(t[4], t[5]), gl::add_lazy(t[6], t[7]))),
-                                        gl::add_lazy(gl::add_lazy(t[8], t[9]), t[10]));
-      d = gl::add_lazy(poseidon::mul_lazy(s0, 25), sum);  // 25 = MDS[0][0] = 17 + 8
-    }
-    __builtin_amdgcn_wave_barrier();  // lane 0 has read the terms before anyone overwrites them
-    const uint64_t s0g = from_lane(leader, s0);
-    x = e == 0 ? d : gl::add_lazy(x, poseidon::mul_lazy(s0g, vs));
-  }
-  // ---- the last four full rounds ----
-  rc_next = poseidon::d_RC[(poseidon::HALF_FULL + poseidon::PARTIAL) * GROUP + e];
-#pragma unroll 1
-  for (int r = poseidon::HALF_FULL + poseidon::PARTIAL; r < poseidon::ROUNDS; r++) {
+  for (int r = 0; r < poseidon::ROUNDS; r++) {
     const uint64_t rc_cur = rc_next;
     rc_next = poseidon::d_RC[(r + 1 < poseidon::ROUNDS ? r + 1 : r) * GROUP + e];
-    x = full_round(x, rc_cur, mine, e, lane_used, coef);
+    x = poseidon::add_const_lazy(x, rc_cur);
+    const bool full = r < poseidon::HALF_FULL || r >= poseidon::HALF_FULL + poseidon::PARTIAL;
+    if (full || e == 0) x = poseidon::sbox_lazy(x);
+    if (lane_used) mine[e] = x;  // lanes 60..63 shadow group 0 / element 0 and must not write
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // dot product in two 64-bit accumulators (low / high words of the lazy u64 elements): 12 x 41 x 2^32 < 2^41
+    uint64_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < GROUP; j++) {
+      const uint64_t s = mine[j];
+      lo += (uint64_t)(uint32_t)s * coef[j];
+      hi += (uint64_t)(uint32_t)(s >> 32) * coef[j];
+    }
+    __builtin_amdgcn_wave_barrier();  // every lane has read the state before anyone overwrites it
+    // value = lo + hi * 2^32 < 2^74
+    const uint64_t l = lo + (hi << 32);
+    const uint64_t h = (hi >> 32) + (l < lo);
+    x = gl::reduce128_lazy(l, h);
   }
   return gl::canon(x);
 }
