@@ -42,7 +42,10 @@ __device__ __forceinline__ uint64_t pow_tab(const uint64_t *T, uint64_t e) {
   return r;
 }
 
-// grid = (n/256, nc, B)
+// grid = (n/256, nc, B). NCH bounds the number of chunks (npp + 1) at compile time: with every loop over the chunk arrays fully
+// unrolled they live in registers (the product shape has 10 chunks: 80 routed wires in chunks of 8); indexed by a run-time loop
+// variable they were 784 bytes of scratch per lane. NCH = MAX_CHUNKS is the general kernel.
+template <int NCH>
 __global__ __launch_bounds__(256) void k_chunk_products(Args a) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
@@ -53,8 +56,10 @@ __global__ __launch_bounds__(256) void k_chunk_products(Args a) {
   const uint64_t beta = a.betas[proof * a.chal_stride + c], gamma = a.gammas[proof * a.chal_stride + c];
   const uint64_t bx = gl::mul(beta, pow_tab(a.omega_tab, i));
   const int nchunks = a.npp + 1;
-  uint64_t num[MAX_CHUNKS], den[MAX_CHUNKS];
-  for (int t = 0; t < nchunks; t++) {
+  uint64_t num[NCH], den[NCH];
+#pragma unroll
+  for (int t = 0; t < NCH; t++) {
+    if (t >= nchunks) break;
     uint64_t pn = 1, pd = 1;
     for (int j = t * a.chunk; j < a.num_routed && j < (t + 1) * a.chunk; j++) {
       uint64_t wv = w[(size_t)j * a.n];
@@ -66,23 +71,29 @@ __global__ __launch_bounds__(256) void k_chunk_products(Args a) {
     den[t] = pd;
   }
   // Montgomery batch inversion of den[0..nchunks): one inversion per row
-  uint64_t pre[MAX_CHUNKS];
+  uint64_t pre[NCH];
   uint64_t acc = 1;
-  for (int t = 0; t < nchunks; t++) { pre[t] = acc; acc = gl::mul(acc, den[t]); }
+#pragma unroll
+  for (int t = 0; t < NCH; t++)
+    if (t < nchunks) { pre[t] = acc; acc = gl::mul(acc, den[t]); }
   uint64_t inv = gl::inv(acc);
   uint64_t *out = a.out + proof * a.out_proof_stride;
   uint64_t *Z = out + (size_t)c * a.n;
   uint64_t *PP = out + ((size_t)a.nc + (size_t)c * a.npp) * a.n;
   uint64_t row = 1;
-  for (int t = nchunks - 1; t >= 0; t--) {
-    uint64_t dinv = gl::mul(inv, pre[t]);
-    inv = gl::mul(inv, den[t]);
-    num[t] = gl::mul(num[t], dinv);  // chunk product t
-  }
-  for (int t = 0; t < nchunks; t++) {
-    row = gl::mul(row, num[t]);
-    if (t < a.npp) PP[(size_t)t * a.n + i] = num[t];
-  }
+#pragma unroll
+  for (int t = NCH - 1; t >= 0; t--)
+    if (t < nchunks) {
+      uint64_t dinv = gl::mul(inv, pre[t]);
+      inv = gl::mul(inv, den[t]);
+      num[t] = gl::mul(num[t], dinv);  // chunk product t
+    }
+#pragma unroll
+  for (int t = 0; t < NCH; t++)
+    if (t < nchunks) {
+      row = gl::mul(row, num[t]);
+      if (t < a.npp) PP[(size_t)t * a.n + i] = num[t];
+    }
   Z[i] = row;  // product of all chunks of this row
   // the last chunk product is recovered in k_scan_rows as row / prod(first npp chunks) — not needed:
   // pp_t only involve chunks 0..npp-1 and Z(g x) = Z(x) * row.
