@@ -55,6 +55,11 @@ struct Args {
   int log_N, rb;
   int ncst, R, W, nc, npp, chunk, n_gates, num_selectors, n_terms;
   int flip;                       // 1: odd gate launches walk the batch backwards (see k_quot_gate)
+  // small batches (k_quot_all): every piece writes its own slice, parts[(piece * B + proof) * out_stride + c * N + s], piece =
+  // gate index or n_gates for the permutation argument; k_quot_finish adds the n_parts slices instead of reading `acc`
+  uint64_t *parts;
+  int n_parts;
+  int t0_gates;                   // index of the first gate constraint among the terms
   Gate gates[MAX_GATES];
 };
 
@@ -79,11 +84,9 @@ __global__ __launch_bounds__(256) void k_fill_l0(uint64_t *out, size_t N, int lo
   out[s] = gl::mul(zh[i & ((1u << rb) - 1)], gl::inv(gl::mul(n_field, gl::sub(x, 1))));
 }
 
-// grid = (N/256, B). L_0(x)(Z(x)-1) for every challenge, then the partial-product checks: terms 0 .. nc*(npp+2)
-__global__ __launch_bounds__(256) void k_quot_perm(Args a) {
-  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;  // storage (bit-reversed) position
-  if (s >= a.N) return;
-  const size_t proof = blockIdx.y;
+// L_0(x)(Z(x)-1) for every challenge, then the partial-product checks: terms 0 .. nc*(npp+2), for the point at storage
+// (bit-reversed) position s of `proof`; out[c * N] = the sum for challenge c
+__device__ __forceinline__ void perm_eval(const Args &a, size_t s, size_t proof, uint64_t *out) {
   const uint32_t i = __brev((uint32_t)s) >> (32 - a.log_N);  // natural index
   const size_t N = a.N;
   const uint64_t *cs = a.cs_lde[proof] + s;
@@ -127,22 +130,21 @@ __global__ __launch_bounds__(256) void k_quot_perm(Args a) {
       prev = next;
     }
   }
-  uint64_t *out = a.acc + proof * a.out_stride + s;
 #pragma unroll
   for (int c = 0; c < MAXC; c++)
     if (c < nc) out[(size_t)c * N] = gl::canon(acc[c]);
 }
-
-// grid = (N/256, B). Gate `gi` (of type TYPE): acc[c] += filter * sum_k alpha_c^(t0+k) * constraint_k
-template <int TYPE>
-__global__ __launch_bounds__(256) void k_quot_gate(Args a, int gi, int t0) {
-  // Fourteen of these kernels stream the same wire columns one after the other. Every other launch (odd gi) walks the
-  // batch backwards — last proof first, last rows first — so that it starts on what the previous launch touched last and
-  // finds it in the memory-side cache instead of HBM (CITYPROVER_QUOT_FLIP=0 turns it off for measurements).
-  const bool flip = (gi & 1) && a.flip;
-  const size_t s = (size_t)(flip ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * 256 + threadIdx.x;
+// grid = (N/256, B)
+__global__ __launch_bounds__(256) void k_quot_perm(Args a) {
+  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= a.N) return;
-  const size_t proof = flip ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+  perm_eval(a, s, blockIdx.y, a.acc + (size_t)blockIdx.y * a.out_stride + s);
+}
+
+// Gate `gi` (of type TYPE) at storage position s of `proof`: filter * sum_k alpha_c^(t0+k) * constraint_k, added to out[c * N]
+// (ACCUMULATE) or written there
+template <int TYPE, bool ACCUMULATE>
+__device__ __forceinline__ void gate_eval(const Args &a, int gi, int t0, size_t s, size_t proof, uint64_t *out) {
   const size_t N = a.N;
   const uint64_t *cs = a.cs_lde[proof] + s;
   const uint64_t *w = a.wires_lde + proof * a.wires_stride + s;
@@ -247,10 +249,51 @@ __global__ __launch_bounds__(256) void k_quot_gate(Args a, int gi, int t0) {
   for (int r = g.group_start; r < g.group_end; r++)
     if (r != gi) f = gl::mul(f, gl::sub((uint64_t)r, sv));
   if (a.num_selectors > 1) f = gl::mul(f, gl::sub(UNUSED_SELECTOR, sv));
-  uint64_t *out = a.acc + proof * a.out_stride + s;
 #pragma unroll
   for (int c = 0; c < MAXC; c++)
-    if (c < nc) out[(size_t)c * N] = gl::add(out[(size_t)c * N], gl::mul(f, acc[c]));
+    if (c < nc) out[(size_t)c * N] = ACCUMULATE ? gl::add(out[(size_t)c * N], gl::mul(f, acc[c])) : gl::mul(f, acc[c]);
+}
+
+// grid = (N/256, B): acc[c] += gate `gi`
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_quot_gate(Args a, int gi, int t0) {
+  // Fourteen of these kernels stream the same wire columns one after the other. Every other launch (odd gi) walks the
+  // batch backwards — last proof first, last rows first — so that it starts on what the previous launch touched last and
+  // finds it in the memory-side cache instead of HBM (CITYPROVER_QUOT_FLIP=0 turns it off for measurements).
+  const bool flip = (gi & 1) && a.flip;
+  const size_t s = (size_t)(flip ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * 256 + threadIdx.x;
+  if (s >= a.N) return;
+  const size_t proof = flip ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+  gate_eval<TYPE, true>(a, gi, t0, s, proof, a.acc + proof * a.out_stride + s);
+}
+
+// SMALL BATCHES (one or two proofs): a gate kernel of 2^15 points is 512 waves on 1 024 SIMDs, and fifteen of them in a row are
+// fifteen half-empty launches (0.67 ms of a lone proof's 3.2 ms of kernels). Here every piece of the quotient — each gate and the
+// permutation argument — is a slice of ONE grid (blockIdx.z) and writes its own slice of `parts`; k_quot_finish adds the slices.
+// Field addition is exact and commutative: the same bits as the launch-per-gate form. Register allocation is that of the
+// heaviest gate for everyone, which is why batches that fill the chip anyway keep one launch per gate.
+// grid = (N/256, B, n_gates + 1)
+__global__ __launch_bounds__(256) void k_quot_all(Args a) {
+  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= a.N) return;
+  const size_t proof = blockIdx.y;
+  const int gi = blockIdx.z;
+  uint64_t *out = a.parts + ((size_t)gi * gridDim.y + proof) * a.out_stride + s;
+  if (gi == a.n_gates) {
+    perm_eval(a, s, proof, out);
+    return;
+  }
+  switch (a.gates[gi].type) {
+#define CITY_QUOT_CASE(T) case gates::T: gate_eval<gates::T, false>(a, gi, a.t0_gates, s, proof, out); break;
+    CITY_QUOT_CASE(CONSTANT) CITY_QUOT_CASE(PUBLIC_INPUT) CITY_QUOT_CASE(ARITHMETIC) CITY_QUOT_CASE(POSEIDON) CITY_QUOT_CASE(COMPARISON)
+    CITY_QUOT_CASE(U32_ARITHMETIC) CITY_QUOT_CASE(U32_RANGE_CHECK) CITY_QUOT_CASE(U32_ADD_MANY) CITY_QUOT_CASE(U32_SUBTRACTION)
+    CITY_QUOT_CASE(U32_INTERLEAVE) CITY_QUOT_CASE(UNINTERLEAVE_TO_U32) CITY_QUOT_CASE(UNINTERLEAVE_TO_B32) CITY_QUOT_CASE(ARITHMETIC_EXT)
+    CITY_QUOT_CASE(MUL_EXT) CITY_QUOT_CASE(BASE_SUM) CITY_QUOT_CASE(RANDOM_ACCESS) CITY_QUOT_CASE(REDUCING) CITY_QUOT_CASE(REDUCING_EXT)
+    CITY_QUOT_CASE(POSEIDON_MDS) CITY_QUOT_CASE(COSET_INTERPOLATION) CITY_QUOT_CASE(EXPONENTIATION)
+#undef CITY_QUOT_CASE
+    default:  // Noop: no constraints
+      for (int c = 0; c < a.nc; c++) out[(size_t)c * a.N] = 0;
+  }
 }
 
 // grid = (N/256, B): t_c(x) = acc / Z_H(x), written to the point's natural position
@@ -260,8 +303,16 @@ __global__ __launch_bounds__(256) void k_quot_finish(Args a) {
   const size_t proof = blockIdx.y;
   const uint32_t i = __brev((uint32_t)s) >> (32 - a.log_N);
   const uint64_t zh_inv = a.zh_inv[i & ((1u << a.rb) - 1)];
-  const uint64_t *in = a.acc + proof * a.out_stride + s;
   uint64_t *out = a.out + proof * a.out_stride + i;
+  if (a.n_parts > 0) {  // the slices of k_quot_all
+    for (int c = 0; c < a.nc; c++) {
+      uint64_t v = 0;
+      for (int g = 0; g < a.n_parts; g++) v = gl::add(v, a.parts[((size_t)g * gridDim.y + proof) * a.out_stride + (size_t)c * a.N + s]);
+      out[(size_t)c * a.N] = gl::mul(v, zh_inv);
+    }
+    return;
+  }
+  const uint64_t *in = a.acc + proof * a.out_stride + s;
   for (int c = 0; c < a.nc; c++) out[(size_t)c * a.N] = gl::mul(in[(size_t)c * a.N], zh_inv);
 }
 
