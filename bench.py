@@ -239,7 +239,7 @@ def native_qbench(device, rank, pack):
         many = run(["-i", dump, "-o", out_json, "-n", "256", "--blocks-in-flight", "64", "--contexts", "3", "--batch", "128", "--check-plan"])
         per_job = json.load(open(out_json))
         many32 = run(["-i", dump, "-n", "128", "--blocks-in-flight", "32", "--contexts", "3", "--batch", "128"])
-        one = run(["-i", dump, "-n", "4", "--contexts", "3", "--batch", "128"])   # four blocks one after the other: mean latency
+        one = run(["-i", dump, "-n", "8", "--contexts", "3", "--batch", "128"])   # eight blocks one after the other: mean latency
         serial = run(["-i", dump, "--contexts", "1", "--batch", "1"])
         thr = run(["--mode", "throughput", "--contexts", "3", "--batch", "64", "--iters", "8"])
         # the reference's loops unchanged (one job per pop, one proof per call) as 192 threads sharing one context through cp_batcher
