@@ -96,7 +96,25 @@ __global__ __launch_bounds__(256) void k_combine(BatchRefs refs, const Ext *__re
   for (int r = 0; r < refs.n_ranges; r++) {
     const int o = refs.r_oracle[r];
     const uint64_t *f = (refs.table[o] ? refs.table[o][proof] : refs.base[o] + proof * refs.proof_stride[o]) + (size_t)refs.r_first[r] * refs.n + c;
-    for (int p = 0; p < refs.r_count[r]; p++, idx++) {
+    // eight polynomials per trip: their loads are issued together (a lone proof's launch is 64 waves, each walking ~130
+    // polynomials: one load per step of the running sum was one trip to memory per step)
+    const int cnt = refs.r_count[r];
+    int p = 0;
+    for (; p + 8 <= cnt; p += 8, idx += 8) {
+      uint64_t v[8];
+      Ext a[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        v[u] = f[(size_t)(p + u) * refs.n];
+        a[u] = ap[idx + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        acc.a = gl::add(acc.a, gl::mul(v[u], a[u].a));
+        acc.b = gl::add(acc.b, gl::mul(v[u], a[u].b));
+      }
+    }
+    for (; p < cnt; p++, idx++) {
       uint64_t v = f[(size_t)p * refs.n];
       Ext a = ap[idx];
       acc.a = gl::add(acc.a, gl::mul(v, a.a));
