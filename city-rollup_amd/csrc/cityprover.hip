@@ -293,6 +293,20 @@ int merkle_cols_batch(cp_ctx *ctx, const uint64_t *cols, size_t n_leaves, size_t
     D = (uint64_t *)ctx->scratch;
   }
   const dim3 grid(blocks_for(n_leaves, merkle::THREADS), (unsigned)n_trees), block(merkle::THREADS);
+  // a few thousand leaves: the launch is bound by the latency of one lane's chain of permutations — twelve lanes per leaf then
+  // (poseidon_coop.h; CITYPROVER_COOP_LEAF_MAX = largest number of leaves over all trees that takes this form, 0 = never)
+  static const size_t coop_leaf_max = getenv("CITYPROVER_COOP_LEAF_MAX") ? strtoull(getenv("CITYPROVER_COOP_LEAF_MAX"), nullptr, 10) : 8192;
+  const bool salted = salt && n_salt > 0;
+  if (n_leaves * n_trees <= coop_leaf_max && leaf_len + (salted ? (size_t)n_salt : 0) > 4) {
+    const dim3 cgrid(blocks_for(n_leaves, pcoop::STATES_PER_BLOCK), (unsigned)n_trees);
+    if (salted)
+      LAUNCH(ctx, "leaf_hash_cols_coop", pcoop::k_leaf_hash_cols_coop<true>, cgrid, dim3(256), cols, n_leaves, (int)leaf_len, col_stride, D,
+             tree_cols_stride, per_tree, salt, n_salt, salt_tree_stride);
+    else
+      LAUNCH(ctx, "leaf_hash_cols_coop", pcoop::k_leaf_hash_cols_coop<false>, cgrid, dim3(256), cols, n_leaves, (int)leaf_len, col_stride, D,
+             tree_cols_stride, per_tree, (const uint64_t *)nullptr, 0, (size_t)0);
+    return merkle_levels(ctx, D, per_tree, n_leaves, n_trees, cap_height, caps);
+  }
   if (salt && n_salt > 0)
     LAUNCH(ctx, "leaf_hash_cols", merkle::k_leaf_hash_cols<true>, grid, block, cols, n_leaves, (int)leaf_len, col_stride, D,
            tree_cols_stride, per_tree, salt, n_salt, salt_tree_stride);

@@ -160,4 +160,42 @@ __global__ __launch_bounds__(256) void k_leaf_hash_fri_coop(const uint64_t *__re
   if (active && e < 4) digests[(size_t)blockIdx.y * dig_stride + 4 * j + e] = x;
 }
 
+// Column-major leaves (merkle::k_leaf_hash_cols) for commitments of a few thousand leaves: with one lane per leaf such a launch is
+// a handful of waves, each a chain of ceil(k / 8) permutations at the 38 us a lone wave needs for one (a 912-column leaf of the
+// SHA-256 STARK: 114 of them, 4.3 ms however few rows there are); twelve lanes per leaf run the chain at 13 us a permutation. At
+// fourteen times the instructions this pays while the launch is latency-bound: up to 8 192 leaves (cityprover.hip
+// merkle_cols_batch). Leaf i of tree t = column values cols[t * tree_cols_stride + j * col_stride + i], j < leaf_len, then n_salt
+// salt elements (SALT); leaf_len + n_salt > 4 (shorter leaves are their own digest: the lane-per-leaf kernel does those).
+// grid = (ceil(n_leaves / 20), n_trees), block = 256
+template <bool SALT>
+__global__ __launch_bounds__(256) void k_leaf_hash_cols_coop(const uint64_t *__restrict__ cols, size_t n_leaves, int leaf_len, size_t col_stride,
+                                                             uint64_t *__restrict__ digests, size_t tree_cols_stride, size_t tree_dig_stride,
+                                                             const uint64_t *__restrict__ salt, int n_salt, size_t salt_tree_stride) {
+  __shared__ __attribute__((aligned(16))) uint64_t sh[WAVES][STATES_PER_WAVE * GROUP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / GROUP, e = lane - g * GROUP;
+  const bool lane_used = g < STATES_PER_WAVE;
+  const size_t i = (size_t)blockIdx.x * STATES_PER_BLOCK + wave * STATES_PER_WAVE + (lane_used ? g : 0);
+  const bool active = lane_used && i < n_leaves;
+  cols += (size_t)blockIdx.y * tree_cols_stride;
+  if (SALT) salt += (size_t)blockIdx.y * salt_tree_stride;
+  uint32_t coef[GROUP];
+#pragma unroll
+  for (int k = 0; k < GROUP; k++) coef[k] = mds_coef(lane_used ? e : 0, k);
+  const int len = SALT ? leaf_len + n_salt : leaf_len;
+  auto elem = [&](int j) -> uint64_t {
+    if (SALT && j >= leaf_len) return salt[(size_t)(j - leaf_len) * col_stride + i];
+    return cols[(size_t)j * col_stride + i];
+  };
+  uint64_t x = 0;
+  uint64_t nxt = (active && e < RATE_ && e < len) ? elem(e) : 0;
+  for (int e0 = 0; e0 < len; e0 += RATE_) {
+    if (e < RATE_ && e0 + e < len) x = nxt;  // overwrite the rate part with this chunk (a short last chunk keeps the rest)
+    const int n0 = e0 + RATE_;
+    nxt = (active && e < RATE_ && n0 + e < len) ? elem(n0 + e) : 0;  // fetched under the permutation
+    x = permute(x, lane_used ? g : 0, lane_used ? e : 0, lane_used, sh[wave], coef);
+  }
+  if (active && e < 4) digests[(size_t)blockIdx.y * tree_dig_stride + 4 * i + e] = x;
+}
+
 }  // namespace pcoop

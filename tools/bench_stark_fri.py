@@ -84,5 +84,5 @@ def run(prover, log_rows, reps=3, seed=1):
 
 if __name__ == "__main__":
     p = cp.Prover(0)
-    print(json.dumps({"what": "SHA-256 STARK commitment + FRI through cp_batch_commit_dev / cp_fri_prove", "cases": [run(p, k) for k in (12, 14, 16)]}))
+    print(json.dumps({"what": "SHA-256 STARK commitment + FRI through cp_batch_commit_dev / cp_fri_prove", "cases": [run(p, k) for k in (10, 12, 14, 16)]}))
     p.close()
