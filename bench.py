@@ -575,7 +575,8 @@ def main():
     stark = None
     if rank == 0 and not args.no_qbench:
         import bench_stark_fri
-        stark = {"2^14": bench_stark_fri.run(prover, 14, reps=3), "2^16": bench_stark_fri.run(prover, 16, reps=2)}
+        stark = {"2^10": bench_stark_fri.run(prover, 10, reps=3), "2^14": bench_stark_fri.run(prover, 14, reps=3),
+                 "2^16": bench_stark_fri.run(prover, 16, reps=2)}
 
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
