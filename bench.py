@@ -610,8 +610,12 @@ def main():
             clk = pl.get("clock_GHz_est")
             roof = {"kernel": "leaf_hash_cols", "bound": "valu-issue", "unit": "T lane-ops/s",
                     "achieved": lane_ops / (leaf_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TLOPS,
-                    "peak_note": "1024 SIMD-32 x one wave64 VALU instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md); an all-VOP2 "
-                                 "stream measures 54 T/s, VOP3 forms 33-36 T/s, v_mad_u64_u32 31.5 T/s (profiles/r01_ubench_valu.txt)",
+                    "peak_note": "NOMINAL peak: 1024 SIMD-32 x one full-rate wave64 VALU instruction per 2 cycles at 2.4 GHz "
+                                 "(MI355X_MICROARCH.md). The kernel's mix is quarter-rate (v_mad_u64_u32, v_fma_f64: 4 cycles per wave64 "
+                                 "instruction; measured 31.5-36 T/s for such streams, 54 T/s for all-VOP2, profiles/r01_ubench_valu.txt), "
+                                 "so the ceiling of the MIX is about half this peak: see frac_of_mix_rate",
+                    "frac_is_against": "the nominal full-rate peak (roofline.frac, frac_at_measured_clock); roofline.frac_of_mix_rate is "
+                                       "against the measured issue rate of this instruction mix (4 cycles per instruction)",
                     "valu_instructions_per_launch": pl["SQ_INSTS_VALU"], "valu_instructions_per_permutation": lane_ops / perms,
                     "clock_GHz_under_load": clk,
                     "peak_at_measured_clock": VALU_PEAK_TLOPS * clk / 2.4 if clk else None,
@@ -623,13 +627,16 @@ def main():
             if clk:
                 roof["frac_at_measured_clock"] = roof["achieved"] / roof["peak_at_measured_clock"]
             # what the kernel actually issues: with the shader clock rocm-smi reports while it runs (the clock estimated under
-            # the counter pass is the counter pass's), cycles a SIMD spends per wave64 VALU instruction. A SIMD issues one per
-            # four cycles at full rate; tools/ubench_valu.hip measures 4.3-5.0 for the VOP3 integer forms of this mix.
+            # the counter pass is the counter pass's), cycles a SIMD spends per wave64 VALU instruction. A SIMD-32 issues a
+            # full-rate wave64 instruction in 2 cycles and a quarter-rate one (v_mad_u64_u32, v_fma_f64: this kernel's mix) in 4;
+            # tools/ubench_valu.hip measures 4.3-5.0 for the VOP3 integer forms of this mix.
             sclk = sorted((pw or {}).get("leaf_hash", {}).get("sclk_MHz") or [])
             if sclk:
                 mhz = sclk[len(sclk) // 2]
                 roof["sclk_MHz_while_running"] = mhz
                 roof["cycles_per_valu_instruction_per_simd"] = leaf_ms * 1e-3 * mhz * 1e6 / (pl["SQ_INSTS_VALU"] / 1024.0)
+                # against the rate of the mix: 4 cycles per instruction = 1.0
+                roof["frac_of_mix_rate"] = 4.0 / roof["cycles_per_valu_instruction_per_simd"]
         else:
             roof = {"kernel": "leaf_hash_cols", "bound": "hbm", "unit": "GB/s", "achieved": hbm["achieved_GBs"], "peak": HBM_PEAK_GBS,
                     "frac": hbm["frac"], "traffic": None, "algorithmic_bytes": leaf_bytes,

@@ -1036,6 +1036,11 @@ class FriBatch(ctypes.Structure):
     _fields_ = [("point", ctypes.c_uint64 * 2), ("ranges", ctypes.POINTER(FriPolyRange)), ("n_ranges", ctypes.c_size_t)]
 
 
+class BatchPoolInfo(ctypes.Structure):
+    _fields_ = [("bytes", ctypes.c_size_t), ("buffers", ctypes.c_size_t), ("hits", ctypes.c_size_t), ("misses", ctypes.c_size_t),
+                ("trims", ctypes.c_size_t), ("cap_bytes", ctypes.c_size_t), ("pooled", ctypes.c_int)]
+
+
 class FriOracleInfo(ctypes.Structure):
     _fields_ = [("num_polys", ctypes.c_uint32), ("blinding", ctypes.c_uint32)]
 
@@ -1063,11 +1068,14 @@ ABI.update({
     "cp_batch_commit_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, _vp,
                                            ctypes.POINTER(_vp)]),
     "cp_batch_destroy": (None, [_vp]),
+    "cp_batch_pool_stats": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(BatchPoolInfo)]),
+    "cp_batch_pool_trim": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_size_t)]),
     "cp_batch_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_size_t)] + [ctypes.POINTER(ctypes.c_int)] * 4),
     "cp_batch_cap": (ctypes.c_int, [_vp, _u64p]),
     "cp_batch_eval_ext": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, _u64p, _u64p]),
     "cp_batch_lde_rows": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, _u64p]),
     "cp_batch_leaves": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, _u64p]),
+    "cp_batch_coeffs": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, _u64p]),
     "cp_batch_device_ptrs": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "cp_fri_prove": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_size_t, ctypes.POINTER(FriBatch), ctypes.c_size_t,
                                     ctypes.POINTER(FriParams), ctypes.POINTER(ChallengerState), ctypes.c_int, ctypes.c_uint64,
@@ -1078,6 +1086,21 @@ ABI.update({
     "cp_challenger_observe": (ctypes.c_int, [ctypes.POINTER(ChallengerState), _u64p, ctypes.c_size_t]),
     "cp_challenger_challenges": (ctypes.c_int, [ctypes.POINTER(ChallengerState), _u64p, ctypes.c_size_t]),
 })
+
+
+def batch_pool_stats(device=0):
+    """the batch-handle buffer pool of `device` (include/cityprover.h cp_batch_pool_stats) as a dict"""
+    info = BatchPoolInfo()
+    rc = load_library().cp_batch_pool_stats(device, ctypes.byref(info))
+    if rc != 0:
+        raise CityProverError(rc, load_library().cp_last_error(None).decode())
+    return {f: getattr(info, f) for f, _ in BatchPoolInfo._fields_}
+
+
+def batch_pool_trim(prover):
+    released = ctypes.c_size_t(0)
+    prover._check(prover.lib.cp_batch_pool_trim(prover.ctx, ctypes.byref(released)))
+    return released.value
 
 
 class PolyBatch:
@@ -1122,6 +1145,12 @@ class PolyBatch:
     def leaves(self, first_leaf, count):
         out = np.zeros((count, self.k + (SALT_SIZE if self.blinding else 0)), np.uint64)
         self.prover._check(self.prover.lib.cp_batch_leaves(self.handle, first_leaf, count, _ptr(out)))
+        return out
+
+    def coeffs(self, first=0, count=None):
+        count = self.k - first if count is None else count
+        out = np.zeros((count, 1 << self.degree_bits), np.uint64)
+        self.prover._check(self.prover.lib.cp_batch_coeffs(self.handle, first, count, _ptr(out)))
         return out
 
     def device_ptrs(self):

@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG, "csrc")
 SO = os.path.join(PKG, "libcityprover_hip.so")
 OBJ = os.path.join(PKG, "build")
 # translation unit -> the headers it includes (core.h and its own includes are shared by all)
-COMMON = ["core.h", "gl.h", "host_util.h"]
+COMMON = ["core.h", "gl.h", "host_util.h", "dev_pool.h"]
 UNITS = {
     "cityprover.hip": ["poseidon.h", "poseidon_coop.h", "poseidon_tables.h", "merkle.h", "ntt.h", "ntt16.h", "fri.h", "transcript.h", "zs.h", "quotient.h", "gates.h",
                        "prover_tail.inc", "fri_engine.inc", "fri_prove.inc", "batcher.inc", "verify.inc", "circuit_file.inc"],

@@ -27,7 +27,7 @@ int get_pow_table(cp_ctx *ctx, uint64_t base, const uint64_t **out) {
     b = acc;  // base^(2048^(lvl+1))
   }
   PowTable t;
-  HIP_TRY(ctx, hipMalloc((void **)&t.dev, h.size() * sizeof(uint64_t)));
+  HIP_TRY(ctx, dev_malloc(ctx->device, (void **)&t.dev, h.size() * sizeof(uint64_t)));
   HIP_TRY(ctx, hipMemcpyAsync(t.dev, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice,
                               ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // h goes out of scope
@@ -53,7 +53,7 @@ int get_prescale_table(cp_ctx *ctx, int log_n, int rate_bits, uint64_t shift, co
   CP_TRY(get_pow_table(ctx, root_of_unity(log_n + rate_bits, false), &wtabN));
   size_t N = (size_t)1 << (log_n + rate_bits);
   uint64_t *T = nullptr;
-  HIP_TRY(ctx, hipMalloc((void **)&T, N * sizeof(uint64_t)));
+  HIP_TRY(ctx, dev_malloc(ctx->device, (void **)&T, N * sizeof(uint64_t)));
   LAUNCH(ctx, "lde_fill_prescale", ntt16::k_fill_prescale, dim3((unsigned)((N + 255) / 256)), dim3(256), T,
          log_n, rate_bits, stab, wtabN);
   ctx->prescale_tables[key] = T;
@@ -324,12 +324,14 @@ bool valid_merkle_shape(size_t n_leaves, int cap_height) {
 
 }  // namespace
 
+namespace { void batches_orphan(cp_ctx *ctx); }  // fri_prove.inc
+
 extern "C" {
 
 int cp_abi_version(void) { return CP_ABI_VERSION; }
 
 int cp_fault_inject(int kind, long after) {
-  if (kind != CP_FAULT_THREAD && kind != CP_FAULT_ALLOC && kind != CP_FAULT_SELFTEST) return set_error(nullptr, CP_ERR_INVALID_ARG, "unknown fault kind %d", kind);
+  if (kind != CP_FAULT_THREAD && kind != CP_FAULT_ALLOC && kind != CP_FAULT_SELFTEST && kind != CP_FAULT_DEVMEM) return set_error(nullptr, CP_ERR_INVALID_ARG, "unknown fault kind %d", kind);
   hostu::fault_counter(kind).store(after < 0 ? -1 : after);
   return CP_OK;
 }
@@ -383,6 +385,7 @@ cp_ctx *cp_ctx_create(int device) try {
 
 void cp_ctx_destroy(cp_ctx *ctx) {
   if (!ctx) return;
+  batches_orphan(ctx);  // batch handles may be destroyed after their context (their buffers are not the context's)
   for (cp_ctx *lane : ctx->lanes) cp_ctx_destroy(lane);
   ctx->lanes.clear();
   hipSetDevice(ctx->device);
@@ -433,7 +436,7 @@ int cp_dev_alloc(cp_ctx *ctx, size_t bytes, void **out) try {
   if (!out) return set_error(ctx, CP_ERR_INVALID_ARG, "out is NULL");
   *out = nullptr;
   if (bytes == 0) return CP_OK;
-  HIP_TRY(ctx, hipMalloc(out, bytes));
+  HIP_TRY(ctx, dev_malloc(ctx->device, out, bytes));
   return CP_OK;
 } CP_CATCH(ctx)
 int cp_dev_free(cp_ctx *ctx, void *ptr) try {
@@ -603,7 +606,7 @@ int cp_ntt(cp_ctx *ctx, uint64_t *data_host, int log_n, size_t batch, unsigned f
   if (log_n < 0 || log_n > 32) return set_error(ctx, CP_ERR_INVALID_ARG, "log_n %d out of range [0,32]", log_n);
   size_t n = (size_t)1 << log_n, bytes = batch * n * sizeof(uint64_t);
   uint64_t *d = nullptr;
-  HIP_TRY(ctx, hipMalloc((void **)&d, bytes));
+  HIP_TRY(ctx, dev_malloc(ctx->device, (void **)&d, bytes));
   int rc = cp_h2d(ctx, d, data_host, bytes);
   if (rc == CP_OK) rc = cp_ntt_dev(ctx, d, log_n, batch, n, flags, coset_shift);
   if (rc == CP_OK) rc = cp_d2h(ctx, data_host, d, bytes);
@@ -747,8 +750,8 @@ int cp_merkle_cap(cp_ctx *ctx, const uint64_t *rows_host, size_t n_leaves, size_
   size_t cap_n = (size_t)1 << cap_height;
   size_t rows_bytes = n_leaves * leaf_len * sizeof(uint64_t);
   uint64_t *rows = nullptr, *cap = nullptr;
-  HIP_TRY(ctx, hipMalloc((void **)&rows, rows_bytes));
-  hipError_t e = hipMalloc((void **)&cap, cap_n * 32);
+  HIP_TRY(ctx, dev_malloc(ctx->device, (void **)&rows, rows_bytes));
+  hipError_t e = dev_malloc(ctx->device, (void **)&cap, cap_n * 32);
   if (e != hipSuccess) { hipFree(rows); return set_error(ctx, CP_ERR_OOM, "hipMalloc: %s", hipGetErrorString(e)); }
   int rc = cp_h2d(ctx, rows, rows_host, rows_bytes);
   size_t per_tree = merkle_words_per_tree(n_leaves, cap_height);
@@ -783,7 +786,7 @@ int cp_commit_batch_dev(cp_ctx *ctx, const uint64_t *values, size_t k, size_t n_
   uint64_t *coeffs = coeffs_dev;
   uint64_t *own = nullptr;
   if (!coeffs) {
-    HIP_TRY(ctx, hipMalloc((void **)&own, polys * n * sizeof(uint64_t)));
+    HIP_TRY(ctx, dev_malloc(ctx->device, (void **)&own, polys * n * sizeof(uint64_t)));
     coeffs = own;
   }
   int rc;

@@ -22,6 +22,7 @@
 #include "../../include/cityprover.h"
 #include "gl.h"
 #include "host_util.h"
+#include "dev_pool.h"
 
 inline thread_local std::string g_tls_error = "";
 
@@ -89,7 +90,34 @@ struct cp_ctx {
   // blocked on the stream, reported as "host:<phase>" / "wait:<phase>"
   const char *phase_name = nullptr;
   double phase_t0 = 0, phase_wait = 0;
+  // cp_poly_batch handles made by this context and not yet destroyed: cp_ctx_destroy orphans them (their buffers stay
+  // valid, the handle can then only be destroyed), so that the order of the two destroy calls does not matter
+  std::mutex batches_m;
+  std::vector<struct cp_poly_batch *> live_batches;
 };
+
+// ---- device buffer pool of the batch handles: dev_pool.h on hipMalloc / hipFree; one table for the whole library (inline:
+// shared by the translation units), sized by the number of visible devices
+struct HipRaw {
+  static constexpr int OOM = (int)hipErrorOutOfMemory;
+  static int malloc(void **p, size_t bytes) {
+    if (hostu::fault_fires(3)) return OOM;  // cp_fault_inject(CP_FAULT_DEVMEM): the runtime "has no memory left" once
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return (int)e;
+  }
+  static void free(void *p) { (void)hipFree(p); }
+};
+inline DevPoolT<HipRaw> &dev_pool() {
+  static DevPoolT<HipRaw> pool(
+      [] { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; } return (size_t)(n > 0 ? n : 0); }(),
+      (getenv("CITYPROVER_BATCH_POOL_MB") ? strtoull(getenv("CITYPROVER_BATCH_POOL_MB"), nullptr, 10) : 4096ull) << 20);
+  return pool;
+}
+// hipMalloc for every allocation of the library (the caller has made `device` current)
+inline hipError_t dev_malloc(int device, void **p, size_t bytes) { return (hipError_t)dev_pool().malloc(device, p, bytes); }
+inline hipError_t batch_pool_alloc(int device, void **p, size_t bytes) { return (hipError_t)dev_pool().alloc(device, p, bytes); }
+inline void batch_pool_free(int device, void *p, size_t bytes, bool reusable) { dev_pool().release(device, p, bytes, reusable); }
 
 namespace {
 
@@ -156,7 +184,7 @@ int ensure_scratch(cp_ctx *ctx, size_t bytes) {
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
   }
-  HIP_TRY(ctx, hipMalloc(&ctx->scratch, bytes));
+  HIP_TRY(ctx, dev_malloc(ctx->device, &ctx->scratch, bytes));
   ctx->scratch_bytes = bytes;
   return CP_OK;
 }

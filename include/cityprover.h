@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CP_ABI_VERSION 3
+#define CP_ABI_VERSION 4
 
 typedef enum cp_status {
   CP_OK = 0,
@@ -75,7 +75,8 @@ int cp_ctx_set_lanes(cp_ctx *ctx, int lanes);
 /* Where the Fiat-Shamir transcripts of a proving call are hashed (plonky2's Challenger: a sequential chain of ~115 Poseidon
  * permutations per proof). 1: on the device — a whole batch is enqueued without a host round trip, no host thread hashes;
  * 0: on the host, one synchronisation per phase — faster for a LONE proof (a CPU core out-runs one wave on a sequential chain);
- * -1 (default): by batch size (device from three proofs up). Same proof bytes in every mode. Lanes inherit the setting. */
+ * -1 (default): by batch size (device from EIGHT proofs per batch up). Same proof bytes in every
+ * mode. Lanes inherit the setting. */
 int cp_ctx_set_device_transcript(cp_ctx *ctx, int mode);
 /* last error message of `ctx`, or of the calling thread when ctx == NULL. Never NULL. */
 const char *cp_last_error(cp_ctx *ctx);
@@ -85,9 +86,11 @@ const char *cp_last_error(cp_ctx *ctx);
  * thread: same results); CP_FAULT_ALLOC: a host allocation checkpoint inside a proving / verifying call throws
  * std::bad_alloc (the call must return CP_ERR_OOM and leave the context usable); CP_FAULT_SELFTEST: the power-on self-test
  * of the device arithmetic that cp_ctx_create runs (a dozen field products through every carry path and one Poseidon
- * permutation, against the host's portable code) sees a wrong answer - cp_ctx_create must return NULL with the reason.
+ * permutation, against the host's portable code) sees a wrong answer - cp_ctx_create must return NULL with the reason;
+ * CP_FAULT_DEVMEM: a device allocation of the library is refused by "the runtime" as out of memory (the library must give
+ * the batch-handle pool back and try again: the call succeeds when the pool held anything, else CP_ERR_OOM).
  * after < 0 disarms. */
-enum { CP_FAULT_THREAD = 0, CP_FAULT_ALLOC = 1, CP_FAULT_SELFTEST = 2 };
+enum { CP_FAULT_THREAD = 0, CP_FAULT_ALLOC = 1, CP_FAULT_SELFTEST = 2, CP_FAULT_DEVMEM = 3 };
 int cp_fault_inject(int kind, long after);
 
 /* ---- device memory & stream ---------------------------------------------------------- */
@@ -430,17 +433,37 @@ int cp_fri_fold_dev(cp_ctx *ctx, const uint64_t *coeffs_dev, size_t n_in, int ar
  * cp_poly_batch = plonky2 `PolynomialBatch`: k polynomials of degree < n = 2^degree_bits in coefficient form, their
  * rate-2^rate_bits LDE on the coset 7<omega_N> in bit-reversed order, and the Merkle tree over the LDE rows (leaf i =
  * the k values at bit-reversed position i, followed by the salt when blinding) with its 2^cap_height-entry cap.
- * Owned by the caller (cp_batch_destroy); bound to the context that made it. */
+ * Owned by the caller (cp_batch_destroy); bound to the context that made it.
+ *
+ * Lifetime and streams. Every cp_batch_* / cp_fri_prove call has drained the library's stream when it returns.
+ * cp_batch_destroy does NOT synchronise the device: the buffers of a destroyed handle go to a per-device pool and are
+ * handed to the next commitment of the same shape at once (a hipFree per buffer would stall every other context of the
+ * process). The one way a caller's own kernels can touch these buffers is cp_batch_device_ptrs: a handle whose pointers
+ * were handed out is NOT recycled - its buffers are released with hipFree, which waits for all work on the device - but
+ * the caller must still have finished (or synchronised) every stream that uses the pointers before it calls
+ * cp_batch_destroy, exactly as with hipFree of its own memory. A handle may be destroyed after its context
+ * (cp_ctx_destroy leaves its buffers alone); every other call on such a handle except cp_batch_info returns
+ * CP_ERR_INVALID_ARG.
+ * The pool keeps at most CITYPROVER_BATCH_POOL_MB per device (default 4 096; 0 = off), is emptied whenever any allocation
+ * of the library would otherwise fail with out-of-memory, and can be emptied by hand (cp_batch_pool_trim). */
 typedef struct cp_poly_batch cp_poly_batch;
 #define CP_BATCH_FROM_COEFFS 1u /* polys are coefficients (PolynomialBatch::from_coeffs), not values over <omega_n> */
 /* polys_host: k x n, polynomial-major. salts_host: NULL = blinding off; else CP_SALT_SIZE x N uniformly random canonical
  * elements indexed by leaf (plonky2 draws them inside from_values(.., blinding = true, ..); here the caller's RNG does). */
 int cp_batch_commit(cp_ctx *ctx, const uint64_t *polys_host, size_t k, int degree_bits, int rate_bits, int cap_height,
                     unsigned flags, const uint64_t *salts_host, cp_poly_batch **batch_out);
-/* the same from device memory (polys_dev: k x n; salts_dev: CP_SALT_SIZE x N or NULL); the inputs are not retained */
+/* the same from device memory (polys_dev: k x n; salts_dev: CP_SALT_SIZE x N or NULL); the inputs are not retained.
+ * Device-resident inputs must be canonical (< p): they are the output of the library's own kernels or of the caller's
+ * evaluator and are not re-checked (the host variant checks polynomials and salts). */
 int cp_batch_commit_dev(cp_ctx *ctx, const uint64_t *polys_dev, size_t k, int degree_bits, int rate_bits, int cap_height,
                         unsigned flags, const uint64_t *salts_dev, cp_poly_batch **batch_out);
 void cp_batch_destroy(cp_poly_batch *batch);
+/* the pool of `device`: bytes / buffers parked, hits / misses of commitments, times it was emptied; pooled = 0 when the
+ * device index has no pool (allocations then go straight to the runtime). Needs no context. */
+typedef struct cp_batch_pool_info { size_t bytes, buffers, hits, misses, trims, cap_bytes; int pooled; } cp_batch_pool_info;
+int cp_batch_pool_stats(int device, cp_batch_pool_info *out);
+/* hand everything the pool of ctx's device holds back to the runtime (released_out may be NULL) */
+int cp_batch_pool_trim(cp_ctx *ctx, size_t *released_out);
 /* any out pointer may be NULL; n_salt_out: CP_SALT_SIZE for a blinded batch, else 0 */
 int cp_batch_info(const cp_poly_batch *batch, size_t *k_out, int *degree_bits_out, int *rate_bits_out, int *cap_height_out,
                   int *n_salt_out);
@@ -449,6 +472,9 @@ int cp_batch_cap(cp_poly_batch *batch, uint64_t *cap_out_host);
 /* out[j] = polynomials[first + j].to_extension().eval(point), j < count (what `OpeningSet::new` / starky's
  * `StarkOpeningSet::new` compute from a commitment); point, out: F_p^2 elements as 2 u64 */
 int cp_batch_eval_ext(cp_poly_batch *batch, size_t first, size_t count, const uint64_t point[2], uint64_t *out_host);
+/* `polynomials[first .. first + count)`: the coefficient vectors (count x n, polynomial-major) — what a host-side
+ * `PolynomialBatch::polynomials` holds; a copy, the handle stays in buffer recycling */
+int cp_batch_coeffs(cp_poly_batch *batch, size_t first, size_t count, uint64_t *out_host);
 /* `PolynomialBatch::get_lde_values(index * step, ..)` for `count` consecutive indices: row r of out_host
  * (count x k, row-major) = the k LDE values at NATURAL position (first_index + r) * step of the coset (salt excluded) —
  * what a CPU constraint evaluator reads while it builds the quotient. */
@@ -458,7 +484,8 @@ int cp_batch_lde_rows(cp_poly_batch *batch, size_t first_index, size_t count, si
  * so that plonky2's own `get_lde_values` / `get_lde_values_packed` keep working on a batch committed on the device. */
 int cp_batch_leaves(cp_poly_batch *batch, size_t first_leaf, size_t count, uint64_t *out_host);
 /* device views for callers that evaluate their constraints on the device: coefficient array (k x n) and bit-reversed
- * LDE (k x N), polynomial-major, valid until cp_batch_destroy */
+ * LDE (k x N), polynomial-major, valid until cp_batch_destroy — which the caller may only call once its own streams are
+ * done with them (see "Lifetime and streams" above; the handle is taken out of buffer recycling by this call) */
 int cp_batch_device_ptrs(cp_poly_batch *batch, const uint64_t **coeffs_dev_out, const uint64_t **lde_dev_out);
 
 /* plonky2 `Challenger<F, PoseidonHash>` by value: the duplex sponge state, the elements observed since the last

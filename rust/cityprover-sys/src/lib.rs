@@ -278,6 +278,13 @@ impl PolyBatch {
         Ok(out)
     }
 
+    /// `polynomials`: all k coefficient vectors (k x n, polynomial-major); a copy — the handle's device pointers are not taken
+    pub fn coeffs(&self) -> Result<Vec<u64>> {
+        let mut out = vec![0u64; self.k << self.degree_bits];
+        self.ok(unsafe { ffi::cp_batch_coeffs(self.raw, 0, self.k, out.as_mut_ptr()) })?;
+        Ok(out)
+    }
+
     pub fn raw(&self) -> *mut ffi::CpPolyBatch {
         self.raw
     }

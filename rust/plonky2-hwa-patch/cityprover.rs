@@ -389,24 +389,45 @@ fn min_commit_elements() -> usize {
 /// expects — `polynomials` (coefficients) and `merkle_tree.{leaves, cap}` fetched from the device, so that `get_lde_values`,
 /// `get_lde_values_packed` and `eval` of CPU callers (a STARK's constraint evaluation) keep working — with the device twin
 /// attached. `merkle_tree.digests` stays EMPTY: the only consumer of the inner nodes is `prove_openings`, which runs on the
-/// device when the twin is there (`MerkleTree::prove` on such a tree is a bug; the CPU fallback of `prove_openings` below
-/// rebuilds the tree first). `None`: not worth it / not possible (blinding needs plonky2's RNG: the salts are drawn HERE, on
-/// the Rust side, and handed over).
+/// device when the twin is there; when it cannot (`prove_openings_gpu` -> `None`), the hook rebuilds the host tree first
+/// (`with_host_tree`). `None`: not worth it / not possible (blinding needs plonky2's RNG: the salts are drawn HERE, on the
+/// Rust side, and handed over).
 pub fn batch_from_values_gpu(values: &[PolynomialValues<F>], rate_bits: usize, blinding: bool, cap_height: usize) -> Result<Option<PolynomialBatch<F, C, D>>> {
     let k = values.len();
     if k == 0 {
         return Ok(None);
     }
     let n = values[0].len();
+    let flat: Vec<u64> = values.iter().flat_map(|p| p.values.iter().map(|v| v.to_canonical_u64())).collect();
+    batch_commit_gpu(&flat, k, n, rate_bits, blinding, cap_height, false, None)
+}
+
+/// `PolynomialBatch::from_coeffs` on the GPU (the quotient of a STARK prover goes through this constructor, its traces through
+/// `from_values`: both must have twins for `prove_openings` to run on the device — ADVICE r3). `polynomials` are padded to a
+/// common power-of-two length by the caller (plonky2 asserts it).
+pub fn batch_from_coeffs_gpu(polynomials: &[PolynomialCoeffs<F>], rate_bits: usize, blinding: bool, cap_height: usize) -> Result<Option<PolynomialBatch<F, C, D>>> {
+    let k = polynomials.len();
+    if k == 0 {
+        return Ok(None);
+    }
+    let n = polynomials[0].len();
+    if polynomials.iter().any(|p| p.len() != n) {
+        return Ok(None);
+    }
+    let flat: Vec<u64> = polynomials.iter().flat_map(|p| p.coeffs.iter().map(|v| v.to_canonical_u64())).collect();
+    batch_commit_gpu(&flat, k, n, rate_bits, blinding, cap_height, true, Some(polynomials))
+}
+
+fn batch_commit_gpu(flat: &[u64], k: usize, n: usize, rate_bits: usize, blinding: bool, cap_height: usize, from_coeffs: bool,
+                    host_polys: Option<&[PolynomialCoeffs<F>]>) -> Result<Option<PolynomialBatch<F, C, D>>> {
     if k * n < min_commit_elements() || !n.is_power_of_two() {
         return Ok(None);
     }
     let degree_bits = n.trailing_zeros() as usize;
-    let flat: Vec<u64> = values.iter().flat_map(|p| p.values.iter().map(|v| v.to_canonical_u64())).collect();
     let big_n = n << rate_bits;
     let salts: Option<Vec<u64>> = blinding.then(|| (0..crate::plonk::plonk_common::SALT_SIZE * big_n).map(|_| F::rand().to_canonical_u64()).collect());
     let ctx = context()?.lock().unwrap();
-    let twin = match PolyBatch::commit(&ctx, &flat, k, degree_bits, rate_bits, cap_height, false, salts.as_deref()) {
+    let twin = match PolyBatch::commit(&ctx, flat, k, degree_bits, rate_bits, cap_height, from_coeffs, salts.as_deref()) {
         Ok(t) => t,
         Err(e) if cityprover_sys::is_refusal(&e) => return Ok(None),
         Err(e) => return Err(e),
@@ -421,9 +442,12 @@ pub fn batch_from_values_gpu(values: &[PolynomialValues<F>], rate_bits: usize, b
         let rows = twin.leaves(first, cnt)?;
         leaves.extend(rows.chunks_exact(width).map(|r| r.iter().map(|v| F::from_canonical_u64(*v)).collect::<Vec<_>>()));
     }
-    // coefficients: one more device -> host copy through the evaluation entry point would be k Horner sums; the plain copy is
-    // cp_batch_device_ptrs + cp_d2h (k x n u64)
-    let polynomials = fetch_coeffs(&ctx, &twin, k, n)?;
+    // coefficients: the caller's own for from_coeffs, else one copy (cp_batch_coeffs: k x n u64; the handle's device pointers
+    // are NOT taken, so its buffers stay in the library's recycling pool)
+    let polynomials = match host_polys {
+        Some(p) => p.to_vec(),
+        None => twin.coeffs()?.chunks_exact(n).map(|p| PolynomialCoeffs::new(p.iter().map(|v| F::from_canonical_u64(*v)).collect())).collect(),
+    };
     Ok(Some(PolynomialBatch {
         polynomials,
         merkle_tree: MerkleTree { leaves, digests: Vec::new(), cap },
@@ -434,15 +458,51 @@ pub fn batch_from_values_gpu(values: &[PolynomialValues<F>], rate_bits: usize, b
     }))
 }
 
-fn fetch_coeffs(ctx: &cityprover_sys::Context, twin: &PolyBatch, k: usize, n: usize) -> Result<Vec<PolynomialCoeffs<F>>> {
-    use cityprover_sys::ffi;
-    let (mut c, mut l) = (std::ptr::null(), std::ptr::null());
-    let rc = unsafe { ffi::cp_batch_device_ptrs(twin.raw(), &mut c, &mut l) };
-    ensure!(rc == ffi::CP_OK, "cp_batch_device_ptrs failed");
-    let mut flat = vec![0u64; k * n];
-    let rc = unsafe { ffi::cp_d2h(ctx.raw(), flat.as_mut_ptr().cast(), c.cast(), k * n * 8) };
-    ensure!(rc == ffi::CP_OK, "cp_d2h failed");
-    Ok(flat.chunks_exact(n).map(|p| PolynomialCoeffs::new(p.iter().map(|v| F::from_canonical_u64(*v)).collect())).collect())
+/// A device twin for an oracle that was committed on the CPU (below CITYPROVER_MIN_COMMIT, or by a constructor without a hook),
+/// made on demand so that one small oracle does not send a whole `prove_openings` back to the CPU: its coefficients and — for a
+/// blinded oracle — the salts its host leaves end in. The twin's cap must equal the host tree's. `None`: refused by the backend.
+fn twin_on_demand(ctx: &cityprover_sys::Context, o: &PolynomialBatch<F, C, D>) -> Result<Option<PolyBatch>> {
+    let k = o.polynomials.len();
+    let n = 1usize << o.degree_log;
+    if k == 0 || o.polynomials.iter().any(|p| p.len() != n) {
+        return Ok(None);
+    }
+    let big_n = n << o.rate_bits;
+    let flat: Vec<u64> = o.polynomials.iter().flat_map(|p| p.coeffs.iter().map(|v| v.to_canonical_u64())).collect();
+    let salt_size = crate::plonk::plonk_common::SALT_SIZE;
+    let salts: Option<Vec<u64>> = o.blinding.then(|| {
+        // cp_batch_commit takes salts as SALT_SIZE x N indexed by leaf; host leaf i ends in its SALT_SIZE salt elements
+        let mut s = vec![0u64; salt_size * big_n];
+        for (i, leaf) in o.merkle_tree.leaves.iter().enumerate() {
+            for j in 0..salt_size {
+                s[j * big_n + i] = leaf[k + j].to_canonical_u64();
+            }
+        }
+        s
+    });
+    let twin = match PolyBatch::commit(ctx, &flat, k, o.degree_log, o.rate_bits, o.merkle_tree.cap.height(), true, salts.as_deref()) {
+        Ok(t) => t,
+        Err(e) if cityprover_sys::is_refusal(&e) => return Ok(None),
+        Err(e) => return Err(e),
+    };
+    let cap: Vec<[u64; 4]> = twin.cap()?;
+    let same = cap.len() == o.merkle_tree.cap.0.len()
+        && cap.iter().zip(&o.merkle_tree.cap.0).all(|(a, b)| a.iter().zip(&b.elements).all(|(x, y)| *x == y.to_canonical_u64()));
+    ensure!(same, "cityprover: the device commitment of a CPU-committed oracle has a different cap");
+    Ok(Some(twin))
+}
+
+/// The host Merkle tree of a device-committed oracle, rebuilt from the leaves the mirror holds: what the CPU path of
+/// `prove_openings` needs (`merkle_tree.prove(index)` walks `digests`). Used by the hook when the device path declines.
+pub fn with_host_tree(o: &PolynomialBatch<F, C, D>) -> PolynomialBatch<F, C, D> {
+    PolynomialBatch {
+        polynomials: o.polynomials.clone(),
+        merkle_tree: MerkleTree::new(o.merkle_tree.leaves.clone(), o.merkle_tree.cap.height()),
+        degree_log: o.degree_log,
+        rate_bits: o.rate_bits,
+        blinding: o.blinding,
+        gpu: None,
+    }
 }
 
 fn challenger_to_c(ch: &Challenger<F, PoseidonHash>) -> CpChallengerState {
@@ -478,11 +538,22 @@ pub fn prove_openings_gpu(
     challenger: &mut Challenger<F, PoseidonHash>,
     fri_params: &FriParams,
 ) -> Result<Option<FriProof<F, PoseidonHash, D>>> {
-    let twins: Option<Vec<&PolyBatch>> = oracles.iter().map(|o| o.gpu.as_deref()).collect();
-    let Some(twins) = twins else { return Ok(None) };
-    if twins.len() > 8 || fri_params.reduction_arity_bits.len() > 8 {
-        return Ok(None);
+    if oracles.len() > 8 || fri_params.reduction_arity_bits.len() > 8 || oracles.iter().all(|o| o.gpu.is_none()) {
+        return Ok(None); // nothing lives on the device: the CPU path as it is
     }
+    // oracles without a twin (committed on the CPU: small, or through an unhooked constructor) get one on demand
+    let ctx = context()?.lock().unwrap();
+    let mut made: Vec<Option<PolyBatch>> = Vec::with_capacity(oracles.len());
+    for o in oracles {
+        made.push(match &o.gpu {
+            Some(_) => None,
+            None => match twin_on_demand(&ctx, o)? {
+                Some(t) => Some(t),
+                None => return Ok(None),
+            },
+        });
+    }
+    let twins: Vec<&PolyBatch> = oracles.iter().zip(&made).map(|(o, m)| m.as_ref().unwrap_or_else(|| o.gpu.as_deref().unwrap())).collect();
     let batches: Vec<FriBatch> = instance
         .batches
         .iter()
@@ -512,7 +583,6 @@ pub fn prove_openings_gpu(
         arity_bits,
     };
     let mut state = challenger_to_c(challenger);
-    let ctx = context()?.lock().unwrap();
     let bytes = match cityprover_sys::fri_prove(&ctx, &twins, &batches, &params, &mut state, None) {
         Ok(b) => b,
         Err(e) if cityprover_sys::is_refusal(&e) => return Ok(None),

@@ -23,6 +23,7 @@ kept. Sources (paths relative to /root/reference):
   P5     city_rollup_common/src/config/sighash_wrapper_config.rs:16-1900 (+ the leaf order of
          city_store/src/store/sighash/mod.rs:50-73): the whitelist tree of 1875 circuit fingerprints and its root
   G16    city_rollup_common/src/block_template/data.rs:72-73
+  G16vk  city_rollup_common/src/block_template/verifier_data.rs:1-16
          the two CityGroth16ProofData samples of `test_serde` (4 x 48-byte compressed BLS12-381 elements each)
 """
 import json
@@ -215,6 +216,16 @@ def groth16_samples():
     return out
 
 
+def groth16_verifier_data():
+    """`BLOCK_GROTH16_ENCODED_VERIFIER_DATA` (block_template/verifier_data.rs:1-12): the on-chain Groth16 verifying key as six
+    80-byte script pushes, and the SHA-256 the script checks chunk 0 against (:14-16). Data only."""
+    src = open(f"{REF}/city_rollup_common/src/block_template/verifier_data.rs").read()
+    chunks = re.findall(r'hex!\("([0-9a-f]{160})"\)', src)
+    sha = re.search(r'_0_SHA_256_HASH: \[u8; 32\] =\s*hex_literal::hex!\("([0-9a-f]{64})"\)', src).group(1)
+    assert len(chunks) == 6
+    return {"chunks": chunks, "chunk0_sha256": sha}
+
+
 def example_job_dag():
     """The job DAG `plan_jobs` left in the dump (counter / goal / next-jobs triplets, proof_store.rs:41-87): per job
     group (topic, circuit_type, group_id, sub_group_id) the number of completions it waits for (`goal`) and the jobs it
@@ -258,6 +269,7 @@ def main():
     kept = [{"file": "qbench_example.bin", "offset": off, **k, "len": len(v)} for k, v, off in proofs]
     json.dump(kept, open(f"{OUT}/example_proofs.json", "w"), indent=1)
     json.dump(groth16_samples(), open(f"{OUT}/groth16_proof_samples.json", "w"), indent=1)
+    json.dump(groth16_verifier_data(), open(f"{OUT}/groth16_verifier_data.json", "w"), indent=1)
     json.dump(whitelist_tree(), open(f"{OUT}/sighash_whitelist_tree.json", "w"))
     print("zero hashes 2x128; fingerprints", len(fingerprints()), "; example entries", len(index),
           "; delta witnesses", len(deltas), "; proofs kept", len(kept), "of", len(proofs))

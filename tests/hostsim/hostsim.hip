@@ -199,4 +199,69 @@ int hs_parallel_for_throw(size_t n, size_t max_threads, size_t bad) {
   }
   return 0;
 }
+
+// ---- dev_pool.h (the batch-handle buffer pool) over a counting allocator with a capacity: a script of operations in, the
+// allocator's and the pool's counters out. op: 0 alloc(device, bytes) -> handle index, 1 release(handle, reusable),
+// 2 trim(device), 3 malloc(device, bytes) -> handle index (the path every other allocation of the library takes)
+}  // extern "C"
+#include "../../city-rollup_amd/csrc/dev_pool.h"
+#include <set>
+namespace poolsim {
+struct Fake {
+  static constexpr int OOM = 2;
+  static inline size_t capacity = 0, in_use = 0, n_malloc = 0, n_free = 0, n_oom = 0;
+  static inline std::map<void *, size_t> live;
+  static inline uintptr_t next = 0x1000;
+  static int malloc(void **p, size_t bytes) {
+    if (in_use + bytes > capacity) { n_oom++; return OOM; }
+    *p = (void *)next;
+    next += 0x1000;
+    live[*p] = bytes;
+    in_use += bytes;
+    n_malloc++;
+    return 0;
+  }
+  static void free(void *p) {
+    auto it = live.find(p);
+    if (it == live.end()) { n_free = (size_t)-1; return; }  // double free / foreign pointer: poison the counter
+    in_use -= it->second;
+    live.erase(it);
+    n_free++;
+  }
+};
+}  // namespace poolsim
+extern "C" {
+// ops: n x {op, device, bytes_or_handle, reusable}; results: n x int64 (handle index, -OOM, or bytes trimmed);
+// counters_out: {in_use, n_malloc, n_free, n_oom, live buffers, pooled bytes dev0, pooled bytes dev1, hits0, misses0, trims0}
+int hs_pool_script(size_t n_devices, size_t pool_cap, size_t capacity, const int64_t *ops, size_t n, int64_t *results, uint64_t *counters_out) {
+  using poolsim::Fake;
+  Fake::capacity = capacity; Fake::in_use = 0; Fake::n_malloc = Fake::n_free = Fake::n_oom = 0; Fake::live.clear();
+  DevPoolT<Fake> pool(n_devices, pool_cap);
+  struct H { void *p; size_t bytes; int device; };
+  std::vector<H> handles;
+  std::set<void *> out;  // buffers currently handed out: a pool must never hand one out twice
+  for (size_t i = 0; i < n; i++) {
+    const int64_t op = ops[4 * i], dev = ops[4 * i + 1], arg = ops[4 * i + 2], reusable = ops[4 * i + 3];
+    if (op == 0 || op == 3) {
+      void *p = nullptr;
+      const int e = op == 0 ? pool.alloc((int)dev, &p, (size_t)arg) : pool.malloc((int)dev, &p, (size_t)arg);
+      if (e) { results[i] = -e; continue; }
+      if (!out.insert(p).second) return -1;
+      handles.push_back({p, (size_t)arg, (int)dev});
+      results[i] = (int64_t)handles.size() - 1;
+    } else if (op == 1) {
+      H &h = handles[(size_t)arg];
+      out.erase(h.p);
+      pool.release(h.device, h.p, h.bytes, reusable != 0);
+      results[i] = 0;
+    } else {
+      results[i] = (int64_t)pool.trim((int)dev);
+    }
+  }
+  counters_out[0] = Fake::in_use; counters_out[1] = Fake::n_malloc; counters_out[2] = Fake::n_free; counters_out[3] = Fake::n_oom;
+  counters_out[4] = Fake::live.size();
+  counters_out[5] = pool.stats(0).bytes; counters_out[6] = pool.stats(1).bytes;
+  counters_out[7] = pool.stats(0).hits; counters_out[8] = pool.stats(0).misses; counters_out[9] = pool.stats(0).trims;
+  return 0;
+}
 }

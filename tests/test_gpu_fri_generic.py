@@ -54,6 +54,7 @@ def test_batch_commit_matches_oracle(prover, k, db, rb, ch, coeffs, salt):
         lv = o.lde()
         assert (g.leaves(0, min(N, 50)) == lv[:, :min(N, 50)].T).all()
         assert (g.leaves(N - 1, 1) == lv[:, N - 1:].T).all()
+        assert (g.coeffs() == o.coeffs()).all() and (g.coeffs(k - 1, 1) == o.coeffs()[k - 1:]).all()
         # device views: the coefficient array and the bit-reversed LDE the handle keeps
         cptr, lptr = g.device_ptrs()
         co = np.empty(k * n, np.uint64)
@@ -91,6 +92,97 @@ def test_batch_commit_refuses_bad_arguments(prover):
         cityprover.fri_prove(prover, [b], [((7, 0), [(0, 0, 4)])], cityprover.fri_params(4, 1, 2, 0, 2, ()), st)
     assert st.as_tuple() == cityprover.ChallengerState().as_tuple()   # a refused call leaves the transcript alone
     b.close()
+
+
+def test_batch_pool_two_contexts_exported_handles_oom_flush_and_orphans(prover):
+    """the buffer pool behind cp_batch_destroy (csrc/dev_pool.h; its logic alone: tests/test_hostsim.py): commitments made and
+    destroyed alternately from two contexts of one device keep giving the oracle's caps while they recycle each other's
+    buffers; a handle whose device pointers were handed out is not recycled; an out-of-memory from the runtime
+    (CP_FAULT_DEVMEM) empties the pool and the call succeeds, with nothing parked it is CP_ERR_OOM and the context stays
+    usable; a handle may outlive its context."""
+    import cityprover
+    lib = cityprover.load_library()
+    p2 = cityprover.Prover(0)
+    try:
+        cityprover.batch_pool_trim(prover)
+        s0 = cityprover.batch_pool_stats(0)
+        assert s0["pooled"] == 1 and s0["bytes"] == 0
+        assert cityprover.batch_pool_stats(4096)["pooled"] == 0   # no pool for a device index outside the table
+        shapes = [(9, 7, 1, 3), (5, 6, 2, 2)]
+        want = {}
+        for k, db, rb, ch in shapes:
+            polys = O.splitmix64_felts(1000 + k, k << db).reshape(k, 1 << db)
+            o = O.Batch(polys, rb, ch)
+            want[(k, db, rb, ch)] = (polys, o.cap().copy())
+            o.close()
+        for it in range(8):
+            ctx = prover if it % 2 == 0 else p2
+            k, db, rb, ch = shapes[(it // 2) % 2]
+            polys, cap = want[(k, db, rb, ch)]
+            g = cityprover.PolyBatch(ctx, polys, rb, ch)
+            assert (g.cap() == cap).all(), it
+            pt = np.array([12345, 678], dtype=np.uint64)
+            assert g.eval_ext(pt).shape == (k, 2)
+            g.close()
+        s1 = cityprover.batch_pool_stats(0)
+        assert s1["hits"] - s0["hits"] >= 4 * 5 and s1["bytes"] > 0 and s1["buffers"] == 8   # 4 buffers per shape parked
+        # exported pointers: this handle's buffers leave through hipFree
+        k, db, rb, ch = shapes[0]
+        g = cityprover.PolyBatch(prover, want[shapes[0]][0], rb, ch)
+        g.device_ptrs()
+        g.close()
+        s2 = cityprover.batch_pool_stats(0)
+        assert s2["buffers"] == 4 and s2["bytes"] < s1["bytes"]
+        # the runtime reports out-of-memory once: the pool is given back, the commitment (a shape the pool does not hold) succeeds
+        polys3 = O.splitmix64_felts(5, 3 << 5).reshape(3, 32)
+        o3 = O.Batch(polys3, 1, 1)
+        lib.cp_fault_inject(3, 0)
+        g = cityprover.PolyBatch(p2, polys3, 1, 1)
+        assert (g.cap() == o3.cap()).all()
+        s3 = cityprover.batch_pool_stats(0)
+        assert s3["trims"] == s2["trims"] + 1 and s3["bytes"] == 0
+        g.close()
+        cityprover.batch_pool_trim(prover)
+        # nothing parked: the same fault is an out-of-memory status, and the context carries on
+        lib.cp_fault_inject(3, 0)
+        with pytest.raises(cityprover.CityProverError, match="(?i)memory"):
+            cityprover.PolyBatch(p2, polys3, 1, 1)
+        lib.cp_fault_inject(3, -1)
+        g = cityprover.PolyBatch(p2, polys3, 1, 1)
+        assert (g.cap() == o3.cap()).all()
+        o3.close()
+        # a handle outlives its context: only destroy is left
+        p3 = cityprover.Prover(0)
+        h = cityprover.PolyBatch(p3, polys3, 1, 1)
+        p3.close()
+        with pytest.raises(cityprover.CityProverError, match="destroyed"):
+            h.cap()
+        h.close()
+        g.close()
+    finally:
+        lib.cp_fault_inject(3, -1)
+        p2.close()
+
+
+def test_twin_on_demand_of_a_cpu_committed_oracle(prover):
+    """what rust/plonky2-hwa-patch/cityprover.rs::twin_on_demand does for an oracle that was committed on the CPU (ADVICE r3: a
+    from_values oracle meeting an un-hooked / small from_coeffs one): its coefficients and the salts its host leaves end in,
+    committed with CP_BATCH_FROM_COEFFS, reproduce the same cap — so a mixed set of oracles can be proved on the device."""
+    import cityprover
+    k, db, rb, ch = 6, 7, 2, 3
+    n, N = 1 << db, 1 << (db + rb)
+    vals = O.splitmix64_felts(4711, k * n).reshape(k, n)
+    salts = O.splitmix64_felts(4712, 4 * N).reshape(4, N)
+    host = O.Batch(vals, rb, ch, False, salts)                      # the "CPU-committed" oracle
+    leaves = host.lde()                                              # (k + 4) x N in leaf order: the host mirror's leaves
+    recovered = np.ascontiguousarray(leaves[k:k + 4])                # SALT_SIZE x N, indexed by leaf
+    twin = cityprover.PolyBatch(prover, host.coeffs(), rb, ch, True, recovered)
+    try:
+        assert (twin.cap() == host.cap()).all()
+        assert (twin.leaves(0, N) == leaves.T).all()
+    finally:
+        twin.close()
+        host.close()
 
 
 N_RANDOM = int(os.environ.get("CITY_RANDOM_FRI", "40"))

@@ -139,6 +139,50 @@ def test_reference_samples_pin_the_encoding(samples):
         assert swapped is None                                        # (a1, a0) is not a point: the order is pinned
 
 
+def test_on_chain_verifying_key_is_seven_more_points_the_decoder_is_held_against(golden_dir):
+    """`BLOCK_GROTH16_ENCODED_VERIFIER_DATA` (city_rollup_common/src/block_template/verifier_data.rs:1-16; fixture through
+    tests/golden/make_golden.py): the six 80-byte script pushes are ONE 480-byte string of compressed points in the encoding of
+    the proof samples — found by decoding every offset: four G1 elements at 0, 48, 96, 144, then three G2 elements at 192, 288,
+    384 (a0 then a1, flags on a1), nothing else decodes anywhere. All seven are on the curve / twist and in the r-torsion
+    subgroups (independent Python arithmetic), chunk 0 has the SHA-256 the script checks, and the library's element decoder
+    (`cp_groth16_proof_unpack_city`) and encoder reproduce every one of them. Which G1 element is alpha and which are the
+    public-input points, and the order of beta / gamma / delta, is the chain's OP_CHECKGROTH16VERIFY layout — not in the tree."""
+    import hashlib
+    import cityprover as cp
+    vk = json.load(open(os.path.join(golden_dir, "groth16_verifier_data.json")))
+    chunks = [bytes.fromhex(c) for c in vk["chunks"]]
+    assert [len(c) for c in chunks] == [80] * 6
+    assert hashlib.sha256(chunks[0]).hexdigest() == vk["chunk0_sha256"]
+    blob = b"".join(chunks)
+    g1 = [blob[o:o + 48] for o in (0, 48, 96, 144)]
+    g2 = [blob[o:o + 96] for o in (192, 288, 384)]
+    P, Q = [], []
+    for e in g1:
+        pt, flags = decompress(F1, e)
+        assert pt is not None and not flags & 0x40 and ec_mul(F1, r, pt) is None
+        P.append(pt)
+    for e in g2:
+        assert e[47] & 0xC0 == 0                                     # no flag bits on a0
+        pt, flags = decompress(F2, e)
+        assert pt is not None and not flags & 0x40 and ec_mul(F2, r, pt) is None
+        sw, _ = decompress(F2, e[48:95] + bytes([e[95] & 0x3F]) + e[:48])
+        assert sw is None or ec_mul(F2, r, sw) is not None           # (a1, a0): not on the twist, or a point outside G2
+        Q.append(pt)
+    assert len(set(P)) == 4 and len(set(Q)) == 3
+    # the library's decoder / encoder on all seven: three (G1, G2, G1) triples cover them
+    for a, b, c in ((0, 0, 1), (2, 1, 3), (1, 2, 0)):
+        triple = g1[a] + g2[b] + g1[c]
+        assert cp.groth16_unpack_city(triple) == (P[a], Q[b], P[c])
+        assert cp.groth16_pack_city(P[a], Q[b], P[c]) == triple
+    # and nothing else in the string decodes: the layout above is the only reading at element granularity
+    for off in range(0, 480 - 47, 48):
+        try:
+            ok = decompress(F1, blob[off:off + 48])[0] is not None and ec_mul(F1, r, decompress(F1, blob[off:off + 48])[0]) is None
+        except AssertionError:
+            ok = False
+        assert ok == (off < 192), off
+
+
 def test_library_reproduces_the_reference_bytes(samples):
     import cityprover as cp
     for s in samples:

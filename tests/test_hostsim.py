@@ -436,3 +436,73 @@ def test_parallel_for_survives_thread_creation_failures(hs):
     for bad in (0, 17, 63):
         assert hs.hs_parallel_for_throw(64, 8, bad) == 1
     assert hs.hs_parallel_for_throw(64, 8, 1000) == 0
+
+
+def _pool_script(hs, n_devices, pool_cap, capacity, ops):
+    hs.hs_pool_script.argtypes = [ctypes.c_size_t] * 3 + [ctypes.POINTER(ctypes.c_int64), ctypes.c_size_t, ctypes.POINTER(ctypes.c_int64),
+                                                          ctypes.POINTER(ctypes.c_uint64)]
+    a = np.array(ops, dtype=np.int64).reshape(-1, 4)
+    res = np.zeros(len(a), np.int64)
+    cnt = np.zeros(10, np.uint64)
+    rc = hs.hs_pool_script(n_devices, pool_cap, capacity, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(a),
+                           res.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), cnt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+    assert rc == 0, "the pool handed one buffer out twice"
+    keys = ("in_use", "n_malloc", "n_free", "n_oom", "live", "pooled0", "pooled1", "hits0", "misses0", "trims0")
+    return [int(v) for v in res], dict(zip(keys, (int(v) for v in cnt)))
+
+
+def test_batch_buffer_pool_logic(hs):
+    """city-rollup_amd/csrc/dev_pool.h over a counting allocator: reuse by exact size, the cap, exported (non-reusable)
+    buffers bypass the pool, devices never share buffers, a device index outside the table has no pool, out-of-memory
+    empties the pool and tries again (the OOM-flush path), for pool allocations and for every other allocation alike."""
+    ALLOC, REL, TRIM, MALLOC = 0, 1, 2, 3
+    MB = 1 << 20
+    # reuse: the second commitment of a shape gets the first one's buffers back, nothing is freed in between
+    res, c = _pool_script(hs, 2, 64 * MB, 1 << 40, [(ALLOC, 0, 8 * MB, 0), (ALLOC, 0, MB, 0), (REL, 0, 0, 1), (REL, 0, 1, 1),
+                                                      (ALLOC, 0, 8 * MB, 0), (ALLOC, 0, MB, 0), (ALLOC, 0, 2 * MB, 0)])
+    assert res[4] >= 0 and c["n_malloc"] == 3 and c["n_free"] == 0 and c["hits0"] == 2 and c["misses0"] == 3 and c["pooled0"] == 0
+    # the cap: what does not fit goes back to the runtime
+    res, c = _pool_script(hs, 1, 10 * MB, 1 << 40, [(ALLOC, 0, 8 * MB, 0), (ALLOC, 0, 4 * MB, 0), (REL, 0, 0, 1), (REL, 0, 1, 1)])
+    assert c["pooled0"] == 8 * MB and c["n_free"] == 1 and c["in_use"] == 8 * MB
+    # cap 0 = pool off
+    res, c = _pool_script(hs, 1, 0, 1 << 40, [(ALLOC, 0, MB, 0), (REL, 0, 0, 1), (ALLOC, 0, MB, 0)])
+    assert c["hits0"] == 0 and c["n_free"] == 1 and c["n_malloc"] == 2
+    # a handle whose pointers were exported is freed through the runtime, never re-issued
+    res, c = _pool_script(hs, 1, 64 * MB, 1 << 40, [(ALLOC, 0, MB, 0), (REL, 0, 0, 0), (ALLOC, 0, MB, 0)])
+    assert c["pooled0"] == 0 and c["n_free"] == 1 and c["hits0"] == 0
+    # two devices: a buffer of device 0 is not handed to device 1; a device outside the table (7) bypasses the pool
+    res, c = _pool_script(hs, 2, 64 * MB, 1 << 40, [(ALLOC, 0, MB, 0), (REL, 0, 0, 1), (ALLOC, 1, MB, 0), (ALLOC, 7, MB, 0), (REL, 0, 2, 1),
+                                                      (ALLOC, 7, MB, 0)])
+    assert c["pooled0"] == MB and c["pooled1"] == 0 and c["n_malloc"] == 4 and c["n_free"] == 1
+    # out of memory with buffers parked: the pool is emptied and the allocation succeeds (both entry points); with
+    # nothing parked it fails
+    script = [(ALLOC, 0, 6 * MB, 0), (ALLOC, 0, 3 * MB, 0), (REL, 0, 0, 1), (REL, 0, 1, 1),   # 9 MB parked, 10 MB capacity
+              (ALLOC, 0, 5 * MB, 0),                                                             # miss -> OOM -> trim -> ok
+              (MALLOC, 0, 4 * MB, 0),                                                            # fits
+              (MALLOC, 0, 4 * MB, 0)]                                                            # OOM, nothing to trim
+    res, c = _pool_script(hs, 1, 64 * MB, 10 * MB, script)
+    assert res[4] >= 0 and res[5] >= 0 and res[6] == -2
+    assert c["trims0"] == 1 and c["n_free"] == 2 and c["pooled0"] == 0 and c["in_use"] == 9 * MB and c["n_oom"] == 2
+    res, c = _pool_script(hs, 1, 64 * MB, 10 * MB, [(ALLOC, 0, 6 * MB, 0), (REL, 0, 0, 1), (MALLOC, 0, 8 * MB, 0), (TRIM, 0, 0, 0)])
+    assert res[2] >= 0 and res[3] == 0 and c["trims0"] == 1
+    # random scripts: the allocator's books always balance (no leak, no double free, no buffer out twice)
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        ops, live = [], []
+        n_alloc = 0
+        for _ in range(200):
+            r = rng.random()
+            if r < 0.5 or not live:
+                ops.append((ALLOC if rng.random() < 0.8 else MALLOC, int(rng.integers(0, 3)), int(rng.choice([1, 2, 4, 8])) * MB, 0))
+                live.append(n_alloc)
+                n_alloc += 1
+            elif r < 0.95:
+                h = live.pop(int(rng.integers(0, len(live))))
+                ops.append((REL, 0, h, int(rng.random() < 0.8)))
+            else:
+                ops.append((TRIM, int(rng.integers(0, 2)), 0, 0))
+        res, c = _pool_script(hs, 2, 16 * MB, 1 << 40, ops)   # capacity ample: every allocation succeeds, handle indices line up
+        held = sum(o[2] for o, r_ in zip(ops, res) if o[0] in (ALLOC, MALLOC)) - sum(ops[[i for i, o in enumerate(ops) if o[0] in (ALLOC, MALLOC)][o[2]]][2]
+                                                                                 for o in ops if o[0] == REL)
+        assert c["in_use"] == held + c["pooled0"] + c["pooled1"]
+        assert c["n_free"] != 2**64 - 1

@@ -122,3 +122,23 @@ def test_gate_id_strings_parse_to_the_right_type_and_parameters():
     assert cp_gate_of_py("BaseSumGate { num_limbs: 4 } + Base: 16", t)[1:3] == (4, 16)
     with pytest.raises(KeyError):
         cp_gate_of_py("LookupGate { num_slots: 40 }", t)     # the Rust side bails: the circuit stays on the CPU prover
+
+
+def test_both_polynomial_batch_constructors_are_hooked_and_the_cpu_fallback_never_asserts():
+    """a STARK prover commits traces with `from_values` and its quotient with `from_coeffs`; `prove_openings` runs on
+    the device only when every oracle has a twin, so both constructors carry a hook, an oracle without a twin gets one on
+    demand (`twin_on_demand`: coefficients + the salts of its host leaves — the C-ABI side of that is exercised on the GPU by
+    tests/test_gpu_fri_generic.py::test_twin_on_demand_of_a_cpu_committed_oracle), and when the device path declines the hook
+    rebuilds the host trees of device-committed oracles instead of asserting. Text-level: nothing here can be compiled."""
+    patch = open(os.path.join(ROOT, "rust", "plonky2-hwa-patch", "hooks.patch")).read()
+    rs = open(os.path.join(ROOT, "rust", "plonky2-hwa-patch", "cityprover.rs")).read()
+    assert "batch_from_values_gpu(vals, rate_bits, blinding, cap_height)" in patch
+    assert "batch_from_coeffs_gpu(polys, rate_bits, blinding, cap_height)" in patch
+    body = patch[patch.index("pub fn prove_openings("):]
+    assert "assert!(oracles.iter()" not in body and "with_host_tree" in body
+    for fn in ("pub fn batch_from_coeffs_gpu", "fn twin_on_demand", "pub fn with_host_tree", "fn batch_commit_gpu"):
+        assert fn in rs, fn
+    # the mirror takes coefficients through cp_batch_coeffs: cp_batch_device_ptrs would take the handle out of buffer recycling
+    assert "cp_batch_device_ptrs" not in rs
+    lib_rs = open(os.path.join(ROOT, "rust", "cityprover-sys", "src", "lib.rs")).read()
+    assert "ffi::cp_batch_coeffs" in lib_rs

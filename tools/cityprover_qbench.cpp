@@ -1168,6 +1168,7 @@ int run_redis_worker(const Options &opt) {
   };
   size_t taken = 0;
   const double t0 = now_s();
+  try {
   for (;;) {
     while (open.size() < take && !(opt.max_jobs > 0 && taken >= (size_t)opt.max_jobs)) {
       std::string body;
@@ -1217,10 +1218,23 @@ int run_redis_worker(const Options &opt) {
     }
     std::vector<Open> still;
     for (size_t i = 0; i < open.size(); i++) {
-      if (open[i].stage + 1 == qb::proofs_per_job(open[i].job.circuit_type)) complete(open[i].job, std::move(stage_out[i]));
-      else still.push_back({open[i].job, open[i].stage + 1});
+      if (open[i].stage + 1 == qb::proofs_per_job(open[i].job.circuit_type)) {
+        const JobId job = open[i].job;
+        open[i].stage = -1;  // from here on this job is never re-queued: its bookkeeping runs once, whatever happens in it
+        complete(job, std::move(stage_out[i]));
+      } else still.push_back({open[i].job, open[i].stage + 1});
     }
     open.swap(still);
+  }
+  } catch (...) {
+    // With --redis-batch N up to N jobs have been popped (destructively) when something fails. The reference's loop loses the ONE
+    // job it was working on (actors/simple.rs:32-56: pop, process, error out); so does this one: the jobs that are merely open go
+    // back to the queue before the worker exits, best effort (the failure may be the connection itself).
+    for (const Open &o : open) {
+      if (o.stage < 0) continue;  // completed (or failed while completing) in this round
+      try { queue.send("JOB", qb::job_to_json(o.job)); } catch (...) { break; }
+    }
+    throw;
   }
   const double wall = now_s() - t0;
   printf("{\"harness\": \"cityprover-qbench\", \"mode\": \"redis-worker\", \"dry_run\": %s, \"redis\": \"%s\", \"jobs\": %zu, \"proving_jobs\": %zu, "

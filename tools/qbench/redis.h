@@ -176,7 +176,8 @@ class RedisStore {
     uint64_t n = 0;
     if (b.size() < 8) throw StoreError("next-jobs record of " + job.hex() + " is truncated");
     memcpy(&n, b.data(), 8);
-    if (b.size() != 8 + 24 * n) throw StoreError("next-jobs record of " + job.hex() + " has the wrong length");
+    // bound n by the record before multiplying: a huge count must not wrap 8 + 24 n round to the record's size
+    if (n > (b.size() - 8) / 24 || b.size() != 8 + 24 * (size_t)n) throw StoreError("next-jobs record of " + job.hex() + " has the wrong length");
     std::vector<JobId> out(n);
     for (uint64_t i = 0; i < n; i++) out[i] = JobId::from_bytes(b.data() + 8 + 24 * i);
     return out;
@@ -273,7 +274,12 @@ class RsmqQueue {
     c.command({"ZADD", key, std::to_string(t.first + delay_ms), id});
     c.command({"HSET", key + ":Q", id, body});
     c.command({"HINCRBY", key + ":Q", "totalsent", "1"});
-    c.command({"EXEC"});
+    // EXEC answers with one reply per queued command (or Nil when the transaction was discarded): a command that failed inside
+    // it would otherwise leave a half-sent message unnoticed
+    const Reply ex = c.command({"EXEC"});
+    if (ex.kind != Reply::Array || ex.items.size() != 3) throw RedisError("rsmq: sending to " + q + ": the transaction was not executed");
+    for (const Reply &it : ex.items)
+      if (it.kind == Reply::Error) throw RedisError("rsmq: sending to " + q + ": " + it.str);
   }
   // is_empty (redis/mod.rs:144-149): the number of messages of the queue
   long long size(const std::string &q) {
