@@ -1193,3 +1193,192 @@ def fri_verify(params, oracle_infos, caps, batches, opened_values, challenger, p
                            proof_bytes, len(proof_bytes))
     if rc != 0:
         raise CityProverError(f"[{rc}] " + lib.cp_last_error(None).decode())
+
+
+# ---- generic AIR machinery (include/cityprover.h "the STARK's own two steps as GENERIC device machinery") -----------------
+(AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_GLOBAL, AIR_CHALLENGE, AIR_CONST, AIR_ADD, AIR_SUB, AIR_MUL, AIR_NEG, AIR_INV, AIR_ASSERT_ZERO,
+ AIR_ASSERT_ZERO_TRANSITION, AIR_ASSERT_ZERO_FIRST_ROW, AIR_ASSERT_ZERO_LAST_ROW, AIR_STORE) = range(16)
+AIR_CONSTRAINTS, AIR_MAP = 0, 1
+STARK_STEP_MAP, STARK_STEP_CUBIC_INVERSE, STARK_STEP_PREFIX_SUM = 0, 1, 2
+
+
+class AirProgramDesc(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("ops", _vp), ("n_ops", ctypes.c_size_t), ("consts", _u64p), ("n_consts", ctypes.c_size_t),
+                ("n_columns", ctypes.c_uint32), ("n_public", ctypes.c_uint32), ("n_global", ctypes.c_uint32), ("n_challenge", ctypes.c_uint32),
+                ("n_out_columns", ctypes.c_uint32)]
+
+
+class AirProgramInfo(ctypes.Structure):
+    _fields_ = [("n_ops", ctypes.c_size_t), ("n_live_ops", ctypes.c_size_t), ("n_constraints", ctypes.c_size_t),
+                ("max_constraint_degree", ctypes.c_uint32), ("n_segments_max", ctypes.c_uint32), ("n_slots", ctypes.c_uint32),
+                ("n_instructions", ctypes.c_size_t)]
+
+
+class StarkStep(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("program", _vp), ("first", ctypes.c_uint32), ("count", ctypes.c_uint32), ("flags", ctypes.c_uint32),
+                ("modulus", ctypes.c_uint64 * 2)]
+
+
+class StarkDesc(ctypes.Structure):
+    _fields_ = [("degree_bits", ctypes.c_int), ("quotient_degree_bits", ctypes.c_int), ("num_challenges", ctypes.c_uint32), ("fri", FriParams),
+                ("n_trace_columns", ctypes.c_uint32), ("n_extended_columns", ctypes.c_uint32), ("n_round_challenges", ctypes.c_uint32),
+                ("n_public", ctypes.c_uint32), ("n_global", ctypes.c_uint32), ("steps", ctypes.POINTER(StarkStep)), ("n_steps", ctypes.c_size_t),
+                ("constraints", _vp)]
+
+
+ABI.update({
+    "cp_air_program_create": (_vp, [_vp, ctypes.POINTER(AirProgramDesc)]),
+    "cp_air_program_destroy": (None, [_vp]),
+    "cp_air_program_get_info": (ctypes.c_int, [_vp, ctypes.POINTER(AirProgramInfo)]),
+    "cp_air_program_eval_ext": (ctypes.c_int, [_vp, _u64p, _u64p, _u64p, _u64p, _u64p, _u64p, ctypes.POINTER(ctypes.c_uint32)]),
+    "cp_air_quotient_commit": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), ctypes.c_size_t, ctypes.c_int, _u64p, _u64p, _u64p, _u64p,
+                                              ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "cp_air_map_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _u64p, _u64p, _u64p]),
+    "cp_cubic_batch_inverse_dev": (ctypes.c_int, [_vp, _u64p, _vp, ctypes.c_size_t, ctypes.c_size_t]),
+    "cp_column_prefix_sum_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]),
+    "cp_stark_prove": (ctypes.c_int, [_vp, ctypes.POINTER(StarkDesc), _vp, ctypes.c_int, _u64p, _u64p, ctypes.POINTER(ChallengerState), ctypes.c_int,
+                                      ctypes.c_uint64, _u8pp, ctypes.POINTER(ctypes.c_size_t)]),
+    "cp_stark_verify": (ctypes.c_int, [ctypes.POINTER(StarkDesc), _u64p, _u64p, ctypes.POINTER(ChallengerState), ctypes.c_char_p, ctypes.c_size_t]),
+})
+
+
+def _opt_u64(x):
+    """None / empty -> (NULL, keep-alive None); else a contiguous u64 array and its pointer"""
+    if x is None:
+        return None, None
+    a = _as_u64(x)
+    return (_ptr(a) if a.size else None), a
+
+
+class AirProgram:
+    """cp_air_program: a straight-line program over F_p. ops: (n, 4) uint32 rows (op, a, b, 0) with the AIR_* codes."""
+
+    def __init__(self, prover, kind, ops, consts=(), n_columns=0, n_public=0, n_global=0, n_challenge=0, n_out_columns=0):
+        self.prover = prover
+        o = np.ascontiguousarray(np.asarray(ops, dtype=np.uint32).reshape(-1, 4))
+        c = _as_u64(np.asarray(list(consts) if not isinstance(consts, np.ndarray) else consts, dtype=np.uint64))
+        d = AirProgramDesc(kind, o.ctypes.data if o.size else None, len(o), _ptr(c) if c.size else None, c.size, n_columns, n_public, n_global,
+                           n_challenge, n_out_columns)
+        self.handle = prover.lib.cp_air_program_create(prover.ctx, ctypes.byref(d))
+        if not self.handle:
+            raise CityProverError(prover.lib.cp_last_error(prover.ctx).decode())
+        self.kind, self.n_columns, self.n_public, self.n_global, self.n_challenge, self.n_out_columns = kind, n_columns, n_public, n_global, n_challenge, n_out_columns
+
+    def info(self):
+        i = AirProgramInfo()
+        self.prover._check(self.prover.lib.cp_air_program_get_info(self.handle, ctypes.byref(i)))
+        return {f: getattr(i, f) for f, _ in AirProgramInfo._fields_}
+
+    def eval_ext(self, local, nxt, publics=None, globals_=None, challenges=None):
+        """constraint values on one row over F_p^2: ((n_constraints, 2) array, kinds)"""
+        n = self.info()["n_constraints"]
+        out = np.zeros((n, 2), np.uint64)
+        kinds = np.zeros(max(n, 1), np.uint32)
+        ptrs, keep = zip(*[_opt_u64(x) for x in (local, nxt, publics, globals_, challenges)])
+        self.prover._check(self.prover.lib.cp_air_program_eval_ext(self.handle, *ptrs, _ptr(out), kinds.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+        return out, kinds[:n]
+
+    def close(self):
+        if self.handle:
+            self.prover.lib.cp_air_program_destroy(self.handle)
+            self.handle = None
+
+
+def _wrap_batch(prover, handle):
+    b = PolyBatch.__new__(PolyBatch)
+    b.prover, b.handle = prover, handle
+    k, db, rb, ch, ns = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    prover._check(prover.lib.cp_batch_info(handle, ctypes.byref(k), ctypes.byref(db), ctypes.byref(rb), ctypes.byref(ch), ctypes.byref(ns)))
+    b.k, b.degree_bits, b.rate_bits, b.cap_height, b.blinding = k.value, db.value, rb.value, ch.value, ns.value != 0
+    return b
+
+
+def air_quotient_commit(prover, program, oracles, quotient_degree_bits, alphas, publics=None, globals_=None, challenges=None):
+    """cp_air_quotient_commit -> PolyBatch of len(alphas) * 2^q quotient chunk polynomials"""
+    hs = (_vp * len(oracles))(*[o.handle for o in oracles])
+    al = _as_u64(alphas)
+    (pp, gp, cp_), keep = zip(*[_opt_u64(x) for x in (publics, globals_, challenges)])
+    out = _vp()
+    prover._check(prover.lib.cp_air_quotient_commit(prover.ctx, program.handle, hs, len(oracles), quotient_degree_bits, pp, gp, cp_, _ptr(al), al.size,
+                                                    ctypes.byref(out)))
+    return _wrap_batch(prover, out.value)
+
+
+def air_map(prover, program, in_cols, publics=None, globals_=None, challenges=None):
+    """cp_air_map_dev on host arrays: in_cols (n_columns, n) -> (n_out_columns, n) (columns never stored stay 0)"""
+    v = _as_u64(in_cols)
+    n = v.shape[1]
+    din = prover.to_device(v)
+    dout = prover.alloc(max(program.n_out_columns, 1) * n)
+    try:
+        dout.upload(np.zeros(max(program.n_out_columns, 1) * n, np.uint64))
+        (pp, gp, cp_), keep = zip(*[_opt_u64(x) for x in (publics, globals_, challenges)])
+        prover._check(prover.lib.cp_air_map_dev(prover.ctx, program.handle, din.ptr, dout.ptr, n, pp, gp, cp_))
+        return dout.download(program.n_out_columns * n).reshape(program.n_out_columns, n)
+    finally:
+        din.free()
+        dout.free()
+
+
+def cubic_batch_inverse(prover, modulus, cols):
+    """cp_cubic_batch_inverse_dev on a host array: cols (3 * count, n) -> the inverses, same layout"""
+    v = _as_u64(cols)
+    d = prover.to_device(v)
+    try:
+        m = _as_u64(modulus)
+        prover._check(prover.lib.cp_cubic_batch_inverse_dev(prover.ctx, _ptr(m), d.ptr, v.shape[0] // 3, v.shape[1]))
+        return d.download(v.size).reshape(v.shape)
+    finally:
+        d.free()
+
+
+def column_prefix_sum(prover, cols, exclusive=False):
+    v = _as_u64(cols)
+    d = prover.to_device(v)
+    try:
+        prover._check(prover.lib.cp_column_prefix_sum_dev(prover.ctx, d.ptr, v.shape[0], v.shape[1], int(exclusive)))
+        return d.download(v.size).reshape(v.shape)
+    finally:
+        d.free()
+
+
+def stark_desc(degree_bits, quotient_degree_bits, num_challenges, fri, n_trace_columns, constraints, n_extended_columns=0, n_round_challenges=0,
+               n_public=0, n_global=0, steps=()):
+    """cp_stark_desc. steps: [("map", AirProgram) | ("cubic_inverse", first, count, (m0, m1)) | ("prefix_sum", first, count, exclusive)].
+    Returns (desc, keep-alive) — hold on to both."""
+    arr = (StarkStep * max(1, len(steps)))()
+    for i, st in enumerate(steps):
+        if st[0] == "map":
+            arr[i].kind, arr[i].program = STARK_STEP_MAP, st[1].handle
+        elif st[0] == "cubic_inverse":
+            arr[i].kind, arr[i].first, arr[i].count = STARK_STEP_CUBIC_INVERSE, st[1], st[2]
+            arr[i].modulus[0], arr[i].modulus[1] = int(st[3][0]), int(st[3][1])
+        elif st[0] == "prefix_sum":
+            arr[i].kind, arr[i].first, arr[i].count, arr[i].flags = STARK_STEP_PREFIX_SUM, st[1], st[2], int(bool(st[3]))
+        else:
+            raise ValueError(st[0])
+    d = StarkDesc(degree_bits, quotient_degree_bits, num_challenges, fri, n_trace_columns, n_extended_columns, n_round_challenges, n_public, n_global,
+                  ctypes.cast(arr, ctypes.POINTER(StarkStep)), len(steps), constraints.handle)
+    return d, (arr, steps, constraints)
+
+
+def stark_prove(prover, desc, trace, challenger, publics=None, globals_=None, pow_override=None):
+    """cp_stark_prove: trace (n_trace_columns, n) host array -> proof bytes; advances `challenger`"""
+    t = _as_u64(trace)
+    (pp, gp), keep = zip(*[_opt_u64(x) for x in (publics, globals_)])
+    out, ln = ctypes.POINTER(ctypes.c_uint8)(), ctypes.c_size_t(0)
+    prover._check(prover.lib.cp_stark_prove(prover.ctx, ctypes.byref(desc), t.ctypes.data, 0, pp, gp, ctypes.byref(challenger),
+                                            0 if pow_override is None else 1, 0 if pow_override is None else int(pow_override),
+                                            ctypes.byref(out), ctypes.byref(ln)))
+    try:
+        return ctypes.string_at(out, ln.value)
+    finally:
+        prover.lib.cp_free(out)
+
+
+def stark_verify(desc, challenger, proof, publics=None, globals_=None):
+    lib = load_library()
+    (pp, gp), keep = zip(*[_opt_u64(x) for x in (publics, globals_)])
+    rc = lib.cp_stark_verify(ctypes.byref(desc), pp, gp, ctypes.byref(challenger), proof, len(proof))
+    if rc != 0:
+        raise CityProverError(f"[{rc}] " + lib.cp_last_error(None).decode())

@@ -13,7 +13,7 @@ OBJ = os.path.join(PKG, "build")
 COMMON = ["core.h", "gl.h", "host_util.h", "dev_pool.h"]
 UNITS = {
     "cityprover.hip": ["poseidon.h", "poseidon_coop.h", "poseidon_tables.h", "merkle.h", "ntt.h", "ntt16.h", "fri.h", "transcript.h", "zs.h", "quotient.h", "gates.h",
-                       "prover_tail.inc", "fri_engine.inc", "fri_prove.inc", "batcher.inc", "verify.inc", "circuit_file.inc"],
+                       "prover_tail.inc", "fri_engine.inc", "fri_prove.inc", "batcher.inc", "verify.inc", "circuit_file.inc", "air.h", "ext3.h", "stark.inc"],
     "bls.hip": ["bls12_381.h", "bls12_381_tables.h", "msm.h", "msm.inc", "bls12_381_fr.h", "fr_ntt.h", "fr_ntt.inc", "groth16.inc",
                 "groth16_pack.inc"],
 }

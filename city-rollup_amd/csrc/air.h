@@ -1,0 +1,416 @@
+// Generic AIR machinery (include/cityprover.h "the STARK's own two steps as GENERIC device machinery"; SURVEY.md §8(a) A13 /
+// §8(f) N3). The SHA-256 STARK of the sighash circuit (city_common_circuit/src/hash/accelerator/sha256/smartgadget.rs:518-524,
+// 418 + 912 columns :55-79) evaluates its constraints through starkyx's generic parser trait; a fork records them as a flat
+// straight-line program (rust/starkyx-patch/recording_parser.rs) and this file runs such a program:
+//   * host: validation, the constraint degree, and a small COMPILER from the recorded SSA ops to a compact bytecode — dead
+//     values dropped, loads and uniform values (constants, publics, globals, challenges) folded into operands, the constraints
+//     cut into independent segments (a segment = a run of consecutive sinks + the backward slice of ops they need; its
+//     contribution to the alpha-fold is its own Horner sum times alpha^(sinks after it), so segments are summed afterwards —
+//     field addition is exact, the bits do not depend on the cut), temporaries assigned by liveness to per-lane slots, a value
+//     consumed only by the next instruction kept in a register (the accumulator) and never stored;
+//   * device: an interpreter — one lane per point of the quotient coset (storage order: all column loads of a wave are
+//     coalesced), one wave per workgroup, grid = (point blocks, segments); the bytecode, the uniform table and the column
+//     pointer table are read through the scalar unit (uniform addresses), slots live in LDS ([slot][lane]: conflict-free
+//     ds_read_b64 / ds_write_b64), slots beyond the LDS budget in a global scratch array.
+// A trace of 2^10 rows is 32 waves of points; cut into ~128 segments it is 4 096 waves. Nothing of any particular AIR is here.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <queue>
+#include <string>
+#include <vector>
+
+#include "gl.h"
+
+namespace air {
+
+// raw op codes = CP_AIR_* (include/cityprover.h)
+enum : uint32_t { R_LOCAL = 0, R_NEXT, R_PUBLIC, R_GLOBAL, R_CHALLENGE, R_CONST, R_ADD, R_SUB, R_MUL, R_NEG, R_INV,
+                  R_ASSERT, R_ASSERT_TRANSITION, R_ASSERT_FIRST, R_ASSERT_LAST, R_STORE };
+struct RawOp { uint32_t op, a, b, c; };
+inline bool defines_value(uint32_t op) { return op <= R_INV; }
+inline bool is_sink(uint32_t op) { return op >= R_ASSERT && op <= R_ASSERT_LAST; }
+inline bool is_uniform(uint32_t op) { return op >= R_PUBLIC && op <= R_CONST; }
+inline bool is_load(uint32_t op) { return op == R_LOCAL || op == R_NEXT; }
+inline bool is_arith(uint32_t op) { return op >= R_ADD && op <= R_INV; }
+
+// bytecode: one 64-bit word per instruction
+//   bits 0-3 op | 4-6 kind of a | 7-9 kind of b | 10-23 dst slot (DST_NONE: result only in the accumulator; SINK: the
+//   selector 0..3; STORE: unused) | 24-43 index of a | 44-63 index of b (STORE: the output column)
+enum : uint32_t { I_ADD = 0, I_SUB = 1, I_MUL = 2, I_INV = 3, I_SINK = 4, I_STORE = 5 };
+enum : uint32_t { K_ACC = 0, K_SLOT = 1, K_UNI = 2, K_LOCAL = 3, K_NEXT = 4 };
+constexpr uint32_t DST_NONE = 0x3FFF;
+constexpr uint32_t MAX_INDEX = 1u << 20;
+GL_HD uint64_t encode(uint32_t op, uint32_t ka, uint32_t kb, uint32_t dst, uint32_t ia, uint32_t ib) {
+  return (uint64_t)op | ((uint64_t)ka << 4) | ((uint64_t)kb << 7) | ((uint64_t)dst << 10) | ((uint64_t)ia << 24) | ((uint64_t)ib << 44);
+}
+
+struct Program {
+  int kind = 0;  // CP_AIR_CONSTRAINTS / CP_AIR_MAP
+  std::vector<RawOp> ops;
+  std::vector<uint64_t> consts;
+  uint32_t n_columns = 0, n_public = 0, n_global = 0, n_challenge = 0, n_out_columns = 0;
+  // derived
+  std::vector<uint32_t> roots;  // sinks (constraint programs) or stores (map programs), program order
+  std::vector<uint8_t> live;    // reaches a root
+  size_t n_live = 0;
+  uint32_t max_degree = 0;
+  // uniform table layout: consts | publics | globals | challenges | 0
+  uint32_t uni_public() const { return (uint32_t)consts.size(); }
+  uint32_t uni_global() const { return uni_public() + n_public; }
+  uint32_t uni_challenge() const { return uni_global() + n_global; }
+  uint32_t uni_zero() const { return uni_challenge() + n_challenge; }
+  uint32_t uni_size() const { return uni_zero() + 1; }
+};
+
+// "" = well-formed (and p.roots / live / max_degree filled); else what is wrong
+inline std::string analyse(Program &p) {
+  const size_t n = p.ops.size();
+  auto bad = [&](size_t i, const char *why) { return "op " + std::to_string(i) + ": " + why; };
+  if (n > ((size_t)1 << 24)) return "more than 2^24 ops";
+  if (p.kind != 0 && p.kind != 1) return "kind must be CP_AIR_CONSTRAINTS or CP_AIR_MAP";
+  if (p.n_columns >= MAX_INDEX || p.n_out_columns >= MAX_INDEX) return "more than 2^20 - 1 columns";
+  if ((uint64_t)p.consts.size() + p.n_public + p.n_global + p.n_challenge + 1 >= MAX_INDEX) return "more than 2^20 - 2 uniform values (constants + publics + globals + challenges)";
+  if (p.kind == 0 && p.n_out_columns) return "n_out_columns of a constraint program must be 0";
+  for (uint64_t c : p.consts)
+    if (c >= gl::P) return "a constant is not canonical";
+  std::vector<uint32_t> deg(n, 0);
+  std::vector<uint8_t> stored(p.n_out_columns, 0);
+  p.roots.clear();
+  p.max_degree = 0;
+  for (size_t i = 0; i < n; i++) {
+    const RawOp &o = p.ops[i];
+    if (o.c != 0) return bad(i, "reserved field c is not 0");
+    auto val = [&](uint32_t x) { return x < i && defines_value(p.ops[x].op); };
+    auto sat = [](uint64_t d) { return (uint32_t)std::min<uint64_t>(d, 1u << 30); };
+    switch (o.op) {
+      case R_LOCAL: case R_NEXT:
+        if (o.a >= p.n_columns) return bad(i, "column out of range");
+        deg[i] = 1;
+        break;
+      case R_PUBLIC: if (o.a >= p.n_public) return bad(i, "public input out of range"); break;
+      case R_GLOBAL: if (o.a >= p.n_global) return bad(i, "global value out of range"); break;
+      case R_CHALLENGE: if (o.a >= p.n_challenge) return bad(i, "challenge out of range"); break;
+      case R_CONST: if (o.a >= p.consts.size()) return bad(i, "constant out of range"); break;
+      case R_ADD: case R_SUB:
+        if (!val(o.a) || !val(o.b)) return bad(i, "operand is not an earlier value");
+        deg[i] = std::max(deg[o.a], deg[o.b]);
+        break;
+      case R_MUL:
+        if (!val(o.a) || !val(o.b)) return bad(i, "operand is not an earlier value");
+        deg[i] = sat((uint64_t)deg[o.a] + deg[o.b]);
+        break;
+      case R_NEG:
+        if (!val(o.a)) return bad(i, "operand is not an earlier value");
+        deg[i] = deg[o.a];
+        break;
+      case R_INV:
+        if (p.kind != 1) return bad(i, "INV is for map programs only");
+        if (!val(o.a)) return bad(i, "operand is not an earlier value");
+        break;
+      case R_ASSERT: case R_ASSERT_TRANSITION: case R_ASSERT_FIRST: case R_ASSERT_LAST:
+        if (p.kind != 0) return bad(i, "a map program has no constraints");
+        if (!val(o.a)) return bad(i, "operand is not an earlier value");
+        // degree in units of n: a first / last row constraint is multiplied by a Lagrange basis polynomial (degree n - 1: one
+        // more unit); the transition factor (x - g^(n-1)) is one more in DEGREE, which the bound d <= 2^q + 1 already leaves room for
+        p.max_degree = std::max(p.max_degree, sat((uint64_t)deg[o.a] + (o.op == R_ASSERT_FIRST || o.op == R_ASSERT_LAST ? 1 : 0)));
+        p.roots.push_back((uint32_t)i);
+        break;
+      case R_STORE:
+        if (p.kind != 1) return bad(i, "STORE is for map programs only");
+        if (o.a >= p.n_out_columns) return bad(i, "output column out of range");
+        if (!val(o.b)) return bad(i, "operand is not an earlier value");
+        if (stored[o.a]) return bad(i, "output column stored twice");
+        stored[o.a] = 1;
+        p.roots.push_back((uint32_t)i);
+        break;
+      default: return bad(i, "unknown op code");
+    }
+  }
+  // liveness from the roots
+  p.live.assign(n, 0);
+  for (size_t i = n; i-- > 0;) {
+    const RawOp &o = p.ops[i];
+    if (is_sink(o.op)) { p.live[i] = 1; p.live[o.a] = 1; }
+    else if (o.op == R_STORE) { p.live[i] = 1; p.live[o.b] = 1; }
+    else if (p.live[i]) {
+      if (o.op == R_ADD || o.op == R_SUB || o.op == R_MUL) p.live[o.a] = p.live[o.b] = 1;
+      else if (o.op == R_NEG || o.op == R_INV) p.live[o.a] = 1;
+    }
+  }
+  p.n_live = 0;
+  for (uint8_t l : p.live) p.n_live += l;
+  return "";
+}
+
+struct Compiled {
+  std::vector<uint64_t> code;
+  std::vector<uint32_t> seg_off;      // [S + 1] into code
+  std::vector<uint32_t> sinks_after;  // [S]: constraints in later segments (the exponent of this segment's alpha weight)
+  uint32_t n_slots = 0;               // per-lane temporaries (max over segments)
+  uint32_t n_segments() const { return (uint32_t)sinks_after.size(); }
+};
+
+// Cut the roots into at most `want_segments` runs of about equal work and emit each run's backward slice.
+inline Compiled compile(const Program &p, uint32_t want_segments) {
+  Compiled C;
+  const size_t n = p.ops.size();
+  const size_t n_roots = p.roots.size();
+  if (want_segments < 1) want_segments = 1;
+  // work by position: live arithmetic ops up to each root
+  std::vector<uint32_t> arith_before(n + 1, 0);
+  for (size_t i = 0; i < n; i++) arith_before[i + 1] = arith_before[i] + (p.live[i] && (is_arith(p.ops[i].op) || is_sink(p.ops[i].op) || p.ops[i].op == R_STORE));
+  const uint32_t total = arith_before[n];
+  const uint32_t target = std::max<uint32_t>(1, (total + want_segments - 1) / want_segments);
+  std::vector<std::pair<size_t, size_t>> runs;  // [first root, last root] index ranges
+  {
+    size_t first = 0;
+    uint32_t start_work = 0;
+    for (size_t r = 0; r < n_roots; r++) {
+      const uint32_t w = arith_before[p.roots[r] + 1];
+      if (w - start_work >= target || r + 1 == n_roots) {
+        runs.push_back({first, r});
+        first = r + 1;
+        start_work = w;
+      }
+    }
+    if (runs.empty()) runs.push_back({0, 0});  // a program without roots: one empty segment
+  }
+  std::vector<uint32_t> stamp(n, 0xFFFFFFFFu), uses(n, 0), slot(n, DST_NONE);
+  std::vector<uint32_t> need;
+  C.seg_off.push_back(0);
+  for (size_t s = 0; s < runs.size(); s++) {
+    need.clear();
+    // backward slice of this run's roots
+    std::vector<uint32_t> stack;
+    if (n_roots)
+      for (size_t r = runs[s].first; r <= runs[s].second; r++) stack.push_back(p.roots[r]);
+    while (!stack.empty()) {
+      const uint32_t i = stack.back();
+      stack.pop_back();
+      if (stamp[i] == (uint32_t)s) continue;
+      stamp[i] = (uint32_t)s;
+      uses[i] = 0;
+      slot[i] = DST_NONE;
+      const RawOp &o = p.ops[i];
+      if (is_load(o.op) || is_uniform(o.op)) continue;  // folded into operands: nothing to emit, nothing to visit
+      need.push_back(i);
+      if (o.op == R_STORE) stack.push_back(o.b);
+      else {
+        stack.push_back(o.a);
+        if (o.op == R_ADD || o.op == R_SUB || o.op == R_MUL) stack.push_back(o.b);
+      }
+    }
+    std::sort(need.begin(), need.end());
+    auto each_operand = [&](const RawOp &o, auto f) {
+      if (o.op == R_STORE) f(o.b);
+      else {
+        f(o.a);
+        if (o.op == R_ADD || o.op == R_SUB || o.op == R_MUL) f(o.b);
+      }
+    };
+    for (uint32_t i : need) each_operand(p.ops[i], [&](uint32_t x) { uses[x]++; });
+    std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> free_slots;
+    uint32_t next_slot = 0;
+    for (size_t t = 0; t < need.size(); t++) {
+      const uint32_t i = need[t];
+      const RawOp &o = p.ops[i];
+      const uint32_t prev = t ? need[t - 1] : 0xFFFFFFFFu;  // the value the accumulator holds (when it defines one)
+      auto operand = [&](uint32_t x, uint32_t &k, uint32_t &ix) {
+        const RawOp &src = p.ops[x];
+        if (src.op == R_LOCAL) { k = K_LOCAL; ix = src.a; }
+        else if (src.op == R_NEXT) { k = K_NEXT; ix = src.a; }
+        else if (src.op == R_CONST) { k = K_UNI; ix = src.a; }
+        else if (src.op == R_PUBLIC) { k = K_UNI; ix = p.uni_public() + src.a; }
+        else if (src.op == R_GLOBAL) { k = K_UNI; ix = p.uni_global() + src.a; }
+        else if (src.op == R_CHALLENGE) { k = K_UNI; ix = p.uni_challenge() + src.a; }
+        else if (x == prev) { k = K_ACC; ix = 0; }
+        else { k = K_SLOT; ix = slot[x]; }
+      };
+      uint32_t ka = K_UNI, ia = p.uni_zero(), kb = K_UNI, ib = p.uni_zero(), op = I_ADD, dst = DST_NONE;
+      switch (o.op) {
+        case R_ADD: op = I_ADD; operand(o.a, ka, ia); operand(o.b, kb, ib); break;
+        case R_SUB: op = I_SUB; operand(o.a, ka, ia); operand(o.b, kb, ib); break;
+        case R_MUL: op = I_MUL; operand(o.a, ka, ia); operand(o.b, kb, ib); break;
+        case R_NEG: op = I_SUB; operand(o.a, kb, ib); break;  // 0 - a
+        case R_INV: op = I_INV; operand(o.a, ka, ia); break;
+        case R_STORE: op = I_STORE; operand(o.b, ka, ia); ib = o.a; kb = K_UNI; break;
+        default: op = I_SINK; operand(o.a, ka, ia); dst = o.op - R_ASSERT; break;
+      }
+      // operands consumed: slots whose last use this was go back to the pool BEFORE the result takes one (the interpreter
+      // reads both operands before it writes)
+      each_operand(o, [&](uint32_t x) {
+        if (--uses[x] == 0 && slot[x] != DST_NONE) { free_slots.push(slot[x]); slot[x] = DST_NONE; }
+      });
+      if (defines_value(o.op)) {
+        // a slot unless every use is an operand of the very next instruction
+        uint32_t next_uses = 0;
+        if (t + 1 < need.size()) each_operand(p.ops[need[t + 1]], [&](uint32_t x) { next_uses += x == i; });
+        if (uses[i] > next_uses) {
+          if (free_slots.empty()) slot[i] = next_slot++;
+          else { slot[i] = free_slots.top(); free_slots.pop(); }
+          dst = slot[i];
+        }
+      }
+      C.code.push_back(encode(op, ka, kb, dst, ia, ib));
+    }
+    C.n_slots = std::max(C.n_slots, next_slot);
+    C.seg_off.push_back((uint32_t)C.code.size());
+    C.sinks_after.push_back(p.kind == 0 && n_roots ? (uint32_t)(n_roots - 1 - runs[s].second) : 0);
+  }
+  return C;
+}
+
+// per-point selector values of the quotient (starky's ConstraintConsumer): z_last = x - g^(n-1), L_0(x), L_(n-1)(x)
+struct Selectors { uint64_t z_last, l_first, l_last; };
+
+constexpr int MAX_ALPHAS = 4;
+
+// ---- the instruction semantics, shared by the host executor (tests/hostsim, cp_air_program_eval_ext has its own F_p^2 form)
+// and the device interpreter ----
+template <class Mem>  // Mem: slot_read(i), slot_write(i, v), uni(i), local(i), next(i), store(col, v)
+GL_HD void run_segment(const uint64_t *code, uint32_t first, uint32_t last, Mem &m, const uint64_t *alphas, int n_alphas, const Selectors &sel,
+                       uint64_t *acc_out /* [MAX_ALPHAS], Horner sums of this segment */) {
+  uint64_t acc = 0;
+#pragma unroll
+  for (int c = 0; c < MAX_ALPHAS; c++) acc_out[c] = 0;
+  for (uint32_t pc = first; pc < last; pc++) {
+    const uint64_t w = code[pc];
+    const uint32_t op = (uint32_t)w & 15, ka = (uint32_t)(w >> 4) & 7, kb = (uint32_t)(w >> 7) & 7, dst = (uint32_t)(w >> 10) & 0x3FFF,
+                   ia = (uint32_t)(w >> 24) & 0xFFFFF, ib = (uint32_t)(w >> 44);
+    auto fetch = [&](uint32_t k, uint32_t i) -> uint64_t {
+      switch (k) {
+        case K_ACC: return acc;
+        case K_SLOT: return m.slot_read(i);
+        case K_UNI: return m.uni(i);
+        case K_LOCAL: return m.local(i);
+        default: return m.next(i);
+      }
+    };
+    const uint64_t a = fetch(ka, ia);
+    if (op == I_SINK) {
+      const uint64_t v = dst == 0 ? a : gl::mul(a, dst == 1 ? sel.z_last : dst == 2 ? sel.l_first : sel.l_last);
+#pragma unroll
+      for (int c = 0; c < MAX_ALPHAS; c++)
+        if (c < n_alphas) acc_out[c] = gl::add(gl::mul(acc_out[c], alphas[c]), v);
+      continue;
+    }
+    if (op == I_STORE) { m.store(ib, a); continue; }
+    uint64_t r;
+    if (op == I_INV) r = a ? gl::inv(a) : 0;
+    else {
+      const uint64_t b = fetch(kb, ib);
+      r = op == I_ADD ? gl::add(a, b) : op == I_SUB ? gl::sub(a, b) : gl::mul(a, b);
+    }
+    if (dst != DST_NONE) m.slot_write(dst, r);
+    acc = r;
+  }
+}
+
+// ---- device side ----
+constexpr int WAVE = 64;
+constexpr uint32_t MAX_LDS_SLOTS = 64;  // 32 KB per one-wave workgroup; slots beyond live in global scratch
+
+struct KArgs {
+  const uint64_t *code;
+  const uint32_t *seg_off;
+  const uint64_t *uni;
+  const uint64_t *const *cols;   // n_columns column base pointers
+  const uint64_t *sel;           // quotient: [3][M] z_last, l_first, l_last in storage order
+  const uint64_t *alphas;        // [n_alphas]
+  const uint64_t *weights;       // [S][n_alphas]: alpha^(sinks after the segment)
+  uint64_t *parts;               // quotient: [S][n_alphas][M]
+  uint64_t *spill;               // [n_slots - n_lds][S * M_padded]
+  uint64_t *const *out_cols;     // map: n_out_columns column base pointers
+  size_t M;                      // points (quotient: n << q; map: n rows)
+  size_t spill_stride;           // S * M rounded up to whole waves
+  int degree_bits, n_alphas, n_lds;
+};
+
+struct DevMem {
+  uint64_t *lds;  // this wave's slots, [slot][lane]
+  const KArgs &a;
+  size_t pos, npos, gid;
+  int lane;
+  __device__ __forceinline__ uint64_t slot_read(uint32_t i) const {
+    return (int)i < a.n_lds ? lds[i * WAVE + lane] : a.spill[(size_t)(i - a.n_lds) * a.spill_stride + gid];
+  }
+  __device__ __forceinline__ void slot_write(uint32_t i, uint64_t v) const {
+    if ((int)i < a.n_lds) lds[i * WAVE + lane] = v;
+    else a.spill[(size_t)(i - a.n_lds) * a.spill_stride + gid] = v;
+  }
+  __device__ __forceinline__ uint64_t uni(uint32_t i) const { return a.uni[i]; }
+  __device__ __forceinline__ uint64_t local(uint32_t i) const { return a.cols[i][pos]; }
+  __device__ __forceinline__ uint64_t next(uint32_t i) const { return a.cols[i][npos]; }
+  __device__ __forceinline__ void store(uint32_t col, uint64_t v) const {
+    if (pos < a.M) a.out_cols[col][pos] = v;
+  }
+};
+
+// MODE 0: quotient (points in storage order: pos = [coset block][bit-reversed row]); MODE 1: map (pos = row, natural order)
+template <int MODE>
+__global__ __launch_bounds__(WAVE) void k_run(KArgs a) {
+  extern __shared__ uint64_t lds[];
+  const int lane = threadIdx.x;
+  const size_t p0 = (size_t)blockIdx.x * WAVE + lane;
+  const bool active = p0 < a.M;
+  const size_t pos = active ? p0 : a.M - 1;  // idle lanes of a short grid shadow the last point (loads stay in bounds)
+  const uint32_t seg = blockIdx.y;
+  size_t npos;
+  if (MODE == 0) {
+    const size_t n = (size_t)1 << a.degree_bits;
+    const uint32_t q = (uint32_t)(pos & (n - 1));
+    const uint32_t r = a.degree_bits ? __brev(q) >> (32 - a.degree_bits) : 0;
+    const uint32_t r1 = (r + 1) & (uint32_t)(n - 1);
+    npos = (pos & ~(n - 1)) | (a.degree_bits ? __brev(r1) >> (32 - a.degree_bits) : 0);
+  } else {
+    npos = pos + 1 == a.M ? 0 : pos + 1;
+  }
+  DevMem m{lds, a, pos, npos, (size_t)seg * gridDim.x * WAVE + p0, lane};
+  Selectors sel{0, 0, 0};
+  if (MODE == 0) sel = Selectors{a.sel[pos], a.sel[a.M + pos], a.sel[2 * a.M + pos]};
+  uint64_t acc[MAX_ALPHAS];
+  run_segment(a.code, a.seg_off[seg], a.seg_off[seg + 1], m, a.alphas, MODE == 0 ? a.n_alphas : 0, sel, acc);
+  if (MODE == 0 && active) {
+#pragma unroll
+    for (int c = 0; c < MAX_ALPHAS; c++)
+      if (c < a.n_alphas) a.parts[((size_t)seg * a.n_alphas + c) * a.M + pos] = gl::mul(acc[c], a.weights[seg * a.n_alphas + c]);
+  }
+}
+
+// z_last, l_first, l_last at every point of the quotient coset 7<omega_M>, storage order. omega_tab: power table of omega_M
+// (3 x 2048, see get_pow_table). One-off per (degree_bits, q) and context.
+__global__ __launch_bounds__(256) void k_selectors(uint64_t *out, size_t M, int log_M, int degree_bits, const uint64_t *omega_tab, uint64_t g_last,
+                                                   uint64_t n_inv) {
+  const size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (pos >= M) return;
+  // storage position -> natural index of the coset: [coset block c'][bit-reversed row q] <-> nat = r * 2^q_bits + c
+  const uint32_t nat = log_M ? __brev((uint32_t)pos) >> (32 - log_M) : 0;
+  const uint32_t e0 = nat & 2047, e1 = (nat >> 11) & 2047, e2 = nat >> 22;
+  uint64_t w = omega_tab[e0];
+  if (e1) w = gl::mul(w, omega_tab[2048 + e1]);
+  if (e2) w = gl::mul(w, omega_tab[4096 + e2]);
+  const uint64_t x = gl::mul(7, w);
+  uint64_t xn = x;
+  for (int i = 0; i < degree_bits; i++) xn = gl::sqr(xn);
+  const uint64_t zh = gl::sub(xn, 1), zl = gl::sub(x, g_last), zhn = gl::mul(zh, n_inv);
+  out[pos] = zl;
+  out[M + pos] = gl::mul(zhn, gl::inv(gl::sub(x, 1)));
+  out[2 * M + pos] = gl::mul(gl::mul(zhn, g_last), gl::inv(zl));
+}
+
+// sum of the segments' parts, / Z_H (2^q distinct values: zh_inv[nat mod 2^q]), scattered to the NATURAL order the coset iNTT reads
+__global__ __launch_bounds__(256) void k_finish(const uint64_t *parts, uint32_t n_segments, int n_alphas, size_t M, int log_M, int q_bits,
+                                                const uint64_t *zh_inv, uint64_t *out) {
+  const size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (pos >= M) return;
+  const uint32_t nat = log_M ? __brev((uint32_t)pos) >> (32 - log_M) : 0;
+  const uint64_t zi = zh_inv[nat & ((1u << q_bits) - 1)];
+  for (int c = 0; c < n_alphas; c++) {
+    uint64_t s = 0;
+    for (uint32_t g = 0; g < n_segments; g++) s = gl::add(s, parts[((size_t)g * n_alphas + c) * M + pos]);
+    out[(size_t)c * M + nat] = gl::mul(s, zi);
+  }
+}
+
+}  // namespace air

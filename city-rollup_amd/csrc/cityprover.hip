@@ -395,6 +395,7 @@ void cp_ctx_destroy(cp_ctx *ctx) {
   for (auto &kv : ctx->pow_tables) hipFree(kv.second.dev);
   for (auto &kv : ctx->prescale_tables) hipFree(kv.second);
   for (auto &kv : ctx->l0_tables) hipFree(kv.second);
+  for (auto &kv : ctx->air_sel_tables) hipFree(kv.second);
   for (auto &ch : ctx->arena.chunks) hipFree(ch.first);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->wires_stage) hipFree(ctx->wires_stage);
@@ -831,4 +832,7 @@ int cp_commit_dev(cp_ctx *ctx, const uint64_t *values, size_t k, int log_n, int 
 #include "verify.inc"
 #include "fri_prove.inc"
 #include "circuit_file.inc"
+#include "air.h"
+#include "ext3.h"
+#include "stark.inc"
 // (the BLS12-381 / Groth16 side is its own translation unit: bls.hip)

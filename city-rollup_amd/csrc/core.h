@@ -12,6 +12,7 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -49,6 +50,7 @@ struct cp_ctx {
     return std::tie(log_n, rate_bits, shift) < std::tie(o.log_n, o.rate_bits, o.shift); } };
   std::map<PreKey, uint64_t *> prescale_tables;  // LDE pre-scale tables [2^rate_bits][n]
   std::map<std::pair<int, int>, uint64_t *> l0_tables;  // (degree_bits, rate_bits) -> L_0 on the LDE coset [N], storage order
+  std::map<std::pair<int, int>, uint64_t *> air_sel_tables;  // (degree_bits, q) -> z_last, L_0, L_(n-1) on the quotient coset [3][M] (stark.inc)
   // scratch buffer reused by natural-order NTT epilogues / merkle host paths
   void *scratch = nullptr;
   size_t scratch_bytes = 0;

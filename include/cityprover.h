@@ -539,6 +539,145 @@ int cp_fri_verify(const cp_fri_params *params, const cp_fri_oracle_info *oracles
 int cp_challenger_observe(cp_challenger_state *challenger, const uint64_t *elements, size_t count);
 int cp_challenger_challenges(cp_challenger_state *challenger, uint64_t *out, size_t count);
 
+/* ---- the STARK's own two steps as GENERIC device machinery (second slice) ------
+ * starkyx `ByteStark::prove` (city_common_circuit/src/hash/accelerator/sha256/smartgadget.rs:518-524; 418 free + 912
+ * extended columns, :55-79; row count :310-312; called from city_rollup_circuit/src/sighash_circuits/sighash.rs:132-146)
+ * does two things between its commitments that are the AIR itself: it fills the extended (lookup-argument) columns and it
+ * evaluates every constraint on the quotient coset. The AIR lives in the un-vendored crate starkyx 0.1.0 and cannot be
+ * restated - but it does not have to be: starkyx evaluates its constraints through a generic parser trait, and the crate is
+ * already a [patch] target of the workspace (/root/reference/Cargo.toml:131-132), so a fork can RECORD the constraints as a
+ * flat straight-line program (rust/starkyx-patch/recording_parser.rs, uncompiled) and hand it over. What is built here is
+ * the machinery such a program runs on, with nothing of any particular AIR in it:
+ *   cp_air_program            a straight-line program over F_p: loads (local row / next row / public / global / challenge
+ *                             slots / constants), add, sub, mul, neg (+ inv and column stores in "map" programs), and
+ *                             constraint sinks (all rows / transition / first row / last row)
+ *   cp_air_quotient_commit    plonky2-starky's `compute_quotient_polys` + `PolynomialBatch::from_coeffs`: the program at every
+ *                             point of the quotient coset straight from cp_poly_batch LDEs, alpha-combined per challenge,
+ *                             / Z_H, coset iNTT, split into degree-n chunks, committed - nothing leaves the device
+ *   cp_air_map_dev            a map program over the n rows of value columns, writing new columns (the row-local part of
+ *                             filling extended columns: denominators, products, row sums)
+ *   cp_cubic_batch_inverse_dev, cp_column_prefix_sum_dev   the two non-row-local primitives of a logUp argument over a cubic
+ *                             extension F_p[X]/(X^3 - m1 X - m0) whose modulus is a parameter: batched inversion and the running
+ *                             sum of columns down the trace
+ *   cp_stark_prove / cp_stark_verify   the whole prover strung from these and the two seams above (commit -> challenges ->
+ *                             extended columns -> commit -> quotient -> commit -> openings -> FRI) and its verifier
+ * Protocol restated from plonky2's starky (UPSTREAM-MEMORY, as SURVEY.md Appendix B): transition constraints are multiplied
+ * by (x - g^(n-1)), first / last row constraints by the Lagrange basis polynomials L_0 / L_(n-1); per challenge alpha the
+ * constraints are folded as acc = acc * alpha + c in program order; quotient = acc / Z_H on the coset 7<omega_(n 2^q)>,
+ * q = quotient_degree_bits <= rate_bits, split into 2^q chunks per challenge. PARITY OF A13 STAYS UNPINNED: the reference holds
+ * no STARK vector (smartgadget.rs:505-513 asserts digests only), and starkyx's own transcript order is not in the tree. */
+typedef struct cp_air_op { uint32_t op, a, b, c; } cp_air_op; /* c: reserved, 0 */
+enum {
+  CP_AIR_LOCAL = 0,     /* value = column a of the current row (columns of all trace oracles concatenated, in oracle order) */
+  CP_AIR_NEXT = 1,      /* value = column a of the next row (cyclically) */
+  CP_AIR_PUBLIC = 2,    /* value = public input a */
+  CP_AIR_GLOBAL = 3,    /* value = global value a */
+  CP_AIR_CHALLENGE = 4, /* value = challenge a (the challenges drawn between trace rounds) */
+  CP_AIR_CONST = 5,     /* value = consts[a] */
+  CP_AIR_ADD = 6,       /* value = value[a] + value[b]; a, b: indices of EARLIER ops that define a value */
+  CP_AIR_SUB = 7,
+  CP_AIR_MUL = 8,
+  CP_AIR_NEG = 9,       /* value = -value[a] */
+  CP_AIR_INV = 10,      /* map programs only: value = value[a]^-1 (0 -> 0) */
+  CP_AIR_ASSERT_ZERO = 11,            /* constraint value[a] = 0 on every row (defines no value) */
+  CP_AIR_ASSERT_ZERO_TRANSITION = 12, /* on every row but the last */
+  CP_AIR_ASSERT_ZERO_FIRST_ROW = 13,
+  CP_AIR_ASSERT_ZERO_LAST_ROW = 14,
+  CP_AIR_STORE = 15     /* map programs only: output column a <- value[b] (defines no value) */
+};
+enum { CP_AIR_CONSTRAINTS = 0, CP_AIR_MAP = 1 };
+typedef struct cp_air_program_desc {
+  int kind;                /* CP_AIR_CONSTRAINTS (sinks, no INV / STORE) or CP_AIR_MAP (INV / STORE, no sinks) */
+  const cp_air_op *ops;
+  size_t n_ops;            /* <= 2^24 */
+  const uint64_t *consts;  /* canonical */
+  size_t n_consts;
+  uint32_t n_columns;      /* width of a row (local / next) */
+  uint32_t n_public, n_global, n_challenge;
+  uint32_t n_out_columns;  /* map programs: the columns STORE may write (each at most once); else 0 */
+} cp_air_program_desc;
+typedef struct cp_air_program cp_air_program;
+/* Validates (operand order, index ranges, canonical constants, kind) and compiles the program for the device: dead values
+ * dropped, the constraints cut into independent segments so that a small trace still fills the chip, temporaries assigned by
+ * liveness to a few per-lane slots. NULL on failure (cp_last_error(ctx)). Immutable afterwards; bound to ctx's device. */
+cp_air_program *cp_air_program_create(cp_ctx *ctx, const cp_air_program_desc *desc);
+void cp_air_program_destroy(cp_air_program *program);
+typedef struct cp_air_program_info {
+  size_t n_ops, n_live_ops;      /* as given / after dead-value elimination */
+  size_t n_constraints;          /* sinks */
+  uint32_t max_constraint_degree; /* in the row variables, selectors included (transition / first / last add one) */
+  uint32_t n_segments_max;       /* how many independent segments the constraints can be cut into */
+  uint32_t n_slots;              /* per-lane temporaries the compiled single-segment form needs */
+  size_t n_instructions;         /* device instructions of the single-segment form */
+} cp_air_program_info;
+int cp_air_program_get_info(const cp_air_program *program, cp_air_program_info *out);
+/* The program on ONE row over F_p^2 (host arithmetic, no GPU): what a verifier does at zeta. local / next / publics / globals /
+ * challenges: extension elements (2 u64 each). CP_AIR_CONSTRAINTS programs: out = one extension value per constraint, in program
+ * order, NOT multiplied by any selector; sink_kinds_out (optional) = the CP_AIR_ASSERT_* code of each. */
+int cp_air_program_eval_ext(const cp_air_program *program, const uint64_t *local, const uint64_t *next, const uint64_t *publics,
+                            const uint64_t *globals, const uint64_t *challenges, uint64_t *out, uint32_t *sink_kinds_out);
+/* starky `compute_quotient_polys` + `from_coeffs`: oracles = the trace commitments (one degree, rate and cap height; their
+ * columns concatenated are the program's row), quotient_degree_bits <= rate_bits with max constraint degree <= 2^q + 1;
+ * publics / globals / challenges / alphas: host arrays of canonical elements (n_alphas = starky's num_challenges, <= 4).
+ * quotient_out: a cp_poly_batch of n_alphas * 2^q polynomials (challenge-major, chunk-minor), same rate and cap height. */
+int cp_air_quotient_commit(cp_ctx *ctx, const cp_air_program *program, cp_poly_batch *const *oracles, size_t n_oracles,
+                           int quotient_degree_bits, const uint64_t *publics, const uint64_t *globals,
+                           const uint64_t *challenges, const uint64_t *alphas, size_t n_alphas, cp_poly_batch **quotient_out);
+/* A map program over n rows. in_cols_dev: n_columns x n values (column-major, natural row order; the next row of the last
+ * row is row 0); out_cols_dev: n_out_columns x n, only the stored columns are written. publics / globals / challenges: host. */
+int cp_air_map_dev(cp_ctx *ctx, const cp_air_program *program, const uint64_t *in_cols_dev, uint64_t *out_cols_dev, size_t n,
+                   const uint64_t *publics, const uint64_t *globals, const uint64_t *challenges);
+/* count x n cubic-extension elements, element e of row i = (cols[3e][i], cols[3e+1][i], cols[3e+2][i]) with columns n apart,
+ * replaced by their inverses in F_p[X]/(X^3 - modulus[1] X - modulus[0]) (0 -> 0). One field inversion per lane and 8
+ * elements (Montgomery's trick on the norms). */
+int cp_cubic_batch_inverse_dev(cp_ctx *ctx, const uint64_t modulus[2], uint64_t *cols_dev, size_t count, size_t n);
+/* k columns of n rows (columns n apart), each replaced by its running sum down the rows: inclusive (out[i] = sum_{j<=i} in[j])
+ * or exclusive (out[i] = sum_{j<i} in[j], out[0] = 0). Addition in a cubic (or any) extension is componentwise, so the running
+ * sum of an extension column is this on its component columns. */
+int cp_column_prefix_sum_dev(cp_ctx *ctx, uint64_t *cols_dev, size_t k, size_t n, int exclusive);
+
+/* One step of filling the extended columns (all on the device, in order): */
+enum { CP_STARK_STEP_MAP = 0, CP_STARK_STEP_CUBIC_INVERSE = 1, CP_STARK_STEP_PREFIX_SUM = 2 };
+typedef struct cp_stark_step {
+  int kind;
+  /* MAP: `program` (n_columns = n_trace_columns + n_extended_columns: a row is the execution trace followed by the extended
+   *   columns as filled so far; n_out_columns = n_extended_columns; n_challenge = n_round_challenges)
+   * CUBIC_INVERSE: extended columns [first, first + 3 * count) as `count` cubic elements, inverted, modulus as above
+   * PREFIX_SUM: extended columns [first, first + count), flags bit 0 = exclusive */
+  const cp_air_program *program;
+  uint32_t first, count, flags;
+  uint64_t modulus[2];
+} cp_stark_step;
+typedef struct cp_stark_desc {
+  int degree_bits;           /* n = 2^degree_bits rows */
+  int quotient_degree_bits;  /* q */
+  uint32_t num_challenges;   /* alphas (starky: config.num_challenges), 1..4 */
+  cp_fri_params fri;         /* fri.degree_bits must equal degree_bits */
+  uint32_t n_trace_columns;     /* the execution trace the caller hands in */
+  uint32_t n_extended_columns;  /* second trace round, filled by `steps` after the round challenges; 0 = none */
+  uint32_t n_round_challenges;  /* drawn after the first trace cap is observed */
+  uint32_t n_public, n_global;
+  const cp_stark_step *steps;
+  size_t n_steps;
+  const cp_air_program *constraints; /* n_columns = n_trace_columns + n_extended_columns */
+} cp_stark_desc;
+/* The prover. trace_values: n_trace_columns x n, column-major, natural row order (host, or device with trace_on_device).
+ * `challenger` comes in with whatever the caller's protocol observes first (public inputs, a configuration digest) and goes
+ * back as the verifier's will be. Order: observe trace cap; [draw round challenges; fill and commit the extended columns;
+ * observe cap]; draw alphas; quotient, commit, observe cap; draw zeta (F_p^2); open every trace column at zeta and g zeta,
+ * the quotient chunks at zeta; observe the openings (zeta batch: trace, extended, quotient; then the g zeta batch);
+ * `prove_openings`. proof_out (malloc'd; cp_free) in bincode conventions:
+ *   trace_caps: Vec<Vec<[u64;4]>> (1 or 2) | quotient_cap: Vec<[u64;4]> | local_values, next_values, quotient_polys: Vec<[u64;2]> |
+ *   FriProof (as cp_fri_prove) */
+int cp_stark_prove(cp_ctx *ctx, const cp_stark_desc *desc, const uint64_t *trace_values, int trace_on_device,
+                   const uint64_t *publics, const uint64_t *globals, cp_challenger_state *challenger, int use_pow_override,
+                   uint64_t pow_override, uint8_t **proof_out, size_t *proof_len);
+/* The verifier (host arithmetic only; desc->steps is not read, and the program handle is used for its host form only):
+ * transcript, constraints at zeta from the openings against Z_H(zeta) * sum_i zeta^(n i) t_i(zeta), then `verify_fri_proof`.
+ * 0 = accepted; CP_ERR_VERIFY with cp_last_error(NULL) naming the first failing check. */
+int cp_stark_verify(const cp_stark_desc *desc, const uint64_t *publics, const uint64_t *globals, cp_challenger_state *challenger,
+                    const uint8_t *proof, size_t proof_len);
+
 /* ---- BLS12-381 G1 multi-scalar multiplication ---------------------------------
  * The G1 MSMs of the Groth16 wrap proof: replaces the CPU MSM inside `gnark_plonky2_wrapper::wrap_plonky2_proof`
  * (reference call sites: city_rollup_circuit/src/worker/toolbox/root.rs:296-304,

@@ -161,6 +161,59 @@ int or_fri_verify(const or_fri_params *params, const uint32_t *num_polys, const 
                   const uint64_t *const *caps, const or_fri_batch *batches, size_t n_batches, const uint64_t *const *opened,
                   or_challenger *c, const uint8_t *proof, size_t len, or_tail_debug *dbg);
 
+void or_batch_shape(const or_batch *b, size_t *k, int *log_n, int *rate_bits, int *cap_height);
+
+/* ---- generic AIR machinery (stark_air.c): checker of cp_air_* / cp_cubic_batch_inverse_dev / cp_column_prefix_sum_dev /
+ * cp_stark_prove / cp_stark_verify. An AIR is DATA here - a straight-line program over F_p with the op codes of
+ * include/cityprover.h (CP_AIR_*) - because the SHA-256 STARK's own AIR lives in an absent crate (starkyx 0.1.0,
+ * /root/reference/Cargo.toml:112); the protocol around it follows plonky2's starky (UPSTREAM-MEMORY). Parity unpinned. ---- */
+typedef struct { uint32_t op, a, b, c; } or_air_op;
+typedef struct {
+  int map; /* 0: constraint program (sinks), 1: map program (INV / STORE) */
+  const or_air_op *ops;
+  size_t n_ops;
+  const uint64_t *consts;
+  size_t n_consts;
+  uint32_t n_columns, n_public, n_global, n_challenge, n_out_columns;
+} or_air_program;
+size_t or_air_check(const or_air_program *p); /* 0 = well-formed, else 1 + index of the first bad op */
+size_t or_air_num_constraints(const or_air_program *p);
+void or_air_eval_row(const or_air_program *p, const uint64_t *local, const uint64_t *next, const uint64_t *publics,
+                     const uint64_t *globals, const uint64_t *challenges, uint64_t *vals);
+/* unfiltered constraint values on one row over F_p^2 (inputs: extension elements), program order */
+void or_air_eval_ext(const or_air_program *p, const uint64_t *local, const uint64_t *next, const uint64_t *publics,
+                     const uint64_t *globals, const uint64_t *challenges, uint64_t *out, uint32_t *kinds_out);
+void or_air_map(const or_air_program *p, const uint64_t *in_cols, uint64_t *out_cols, size_t n, const uint64_t *publics,
+                const uint64_t *globals, const uint64_t *challenges);
+/* F_p[X]/(X^3 - m[1] X - m[0]) */
+void or_cubic_mul(const uint64_t m[2], const uint64_t a[3], const uint64_t b[3], uint64_t out[3]);
+void or_cubic_inverse(const uint64_t m[2], const uint64_t a[3], uint64_t out[3]);
+void or_cubic_batch_inverse(const uint64_t m[2], uint64_t *cols, size_t count, size_t n);
+void or_column_prefix_sum(uint64_t *cols, size_t k, size_t n, int exclusive);
+/* starky compute_quotient_polys: n_alphas * 2^qdb coefficient vectors of length n, challenge-major */
+int or_air_quotient(const or_air_program *p, const or_batch *const *oracles, size_t n_oracles, int qdb, const uint64_t *publics,
+                    const uint64_t *globals, const uint64_t *challenges, const uint64_t *alphas, size_t n_alphas, uint64_t *out);
+typedef struct {
+  int kind; /* 0 map, 1 cubic inverse, 2 prefix sum */
+  const or_air_program *program;
+  uint32_t first, count, flags;
+  uint64_t modulus[2];
+} or_stark_step;
+typedef struct {
+  int degree_bits, quotient_degree_bits;
+  uint32_t num_challenges;
+  or_fri_params fri;
+  uint32_t n_trace_columns, n_extended_columns, n_round_challenges, n_public, n_global;
+  const or_stark_step *steps;
+  size_t n_steps;
+  const or_air_program *constraints;
+} or_stark_desc;
+int or_stark_prove(const or_stark_desc *d, const uint64_t *trace_values, const uint64_t *publics, const uint64_t *globals,
+                   or_challenger *c, int use_pow_override, uint64_t pow_override, uint8_t **proof_out, size_t *proof_len);
+/* 0 accepted; 1 malformed; 2 constraints fail at zeta; negative: or_fri_verify's code */
+int or_stark_verify(const or_stark_desc *d, const uint64_t *publics, const uint64_t *globals, or_challenger *c, const uint8_t *proof,
+                    size_t len);
+
 /* ---- gates / quotient (plonky2_quotient.c) ---- */
 enum { OR_GATE_NOOP = 0, OR_GATE_CONSTANT = 1, OR_GATE_PUBLIC_INPUT = 2, OR_GATE_ARITHMETIC = 3, OR_GATE_POSEIDON = 4,
        OR_GATE_COMPARISON = 5, OR_GATE_U32_ARITHMETIC = 6, OR_GATE_U32_RANGE_CHECK = 7,

@@ -470,6 +470,9 @@ void or_batch_free(or_batch *b) { if (b) { batch_free(b); free(b); } }
 const uint64_t *or_batch_cap(const or_batch *b) { return b->cap; }
 const uint64_t *or_batch_coeffs(const or_batch *b) { return b->coeffs; }
 const uint64_t *or_batch_lde(const or_batch *b) { return b->lde; }
+void or_batch_shape(const or_batch *b, size_t *k, int *log_n, int *rate_bits, int *cap_height) {
+  *k = b->k; *log_n = b->log_n; *rate_bits = b->rate_bits; *cap_height = b->cap_height;
+}
 void or_batch_eval_ext(const or_batch *b, size_t first, size_t count, const uint64_t point[2], uint64_t *out) {
   size_t n = (size_t)1 << b->log_n;
   gl2_t z = gl2_make(point[0], point[1]);

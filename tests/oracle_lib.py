@@ -643,3 +643,145 @@ def fri_verify(params, oracle_infos, caps, batches, opened_values, challenger, p
     rc = L.or_fri_verify(ctypes.byref(params), nps, bl, ctypes.c_size_t(len(oracle_infos)), capp, a, ctypes.c_size_t(len(batches)), ovp,
                          ctypes.byref(challenger), buf, ctypes.c_size_t(len(proof_bytes)), ctypes.byref(dbg))
     return rc, dbg
+
+
+# ---- generic AIR machinery (oracle/stark_air.c): checker of cp_air_* / cp_stark_* ----------------------------------------
+class AirProgramC(ctypes.Structure):
+    _fields_ = [("map", ctypes.c_int), ("ops", ctypes.c_void_p), ("n_ops", ctypes.c_size_t), ("consts", _u64p), ("n_consts", ctypes.c_size_t),
+                ("n_columns", ctypes.c_uint32), ("n_public", ctypes.c_uint32), ("n_global", ctypes.c_uint32), ("n_challenge", ctypes.c_uint32),
+                ("n_out_columns", ctypes.c_uint32)]
+
+
+class StarkStepC(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("program", ctypes.POINTER(AirProgramC)), ("first", ctypes.c_uint32), ("count", ctypes.c_uint32),
+                ("flags", ctypes.c_uint32), ("modulus", ctypes.c_uint64 * 2)]
+
+
+class StarkDescC(ctypes.Structure):
+    _fields_ = [("degree_bits", ctypes.c_int), ("quotient_degree_bits", ctypes.c_int), ("num_challenges", ctypes.c_uint32), ("fri", FriParams),
+                ("n_trace_columns", ctypes.c_uint32), ("n_extended_columns", ctypes.c_uint32), ("n_round_challenges", ctypes.c_uint32),
+                ("n_public", ctypes.c_uint32), ("n_global", ctypes.c_uint32), ("steps", ctypes.POINTER(StarkStepC)), ("n_steps", ctypes.c_size_t),
+                ("constraints", ctypes.POINTER(AirProgramC))]
+
+
+class AirProgram:
+    """or_air_program over numpy arrays it keeps alive. ops: (n, 4) uint32 rows (op, a, b, 0)."""
+
+    def __init__(self, kind, ops, consts=(), n_columns=0, n_public=0, n_global=0, n_challenge=0, n_out_columns=0):
+        self.ops = np.ascontiguousarray(np.asarray(ops, dtype=np.uint32).reshape(-1, 4))
+        self.consts = arr(list(consts) if not isinstance(consts, np.ndarray) else consts)
+        self.c = AirProgramC(kind, self.ops.ctypes.data if self.ops.size else None, len(self.ops), ptr(self.consts) if self.consts.size else None,
+                             self.consts.size, n_columns, n_public, n_global, n_challenge, n_out_columns)
+        self.kind, self.n_columns, self.n_out_columns = kind, n_columns, n_out_columns
+
+    def check(self):
+        L = lib()
+        L.or_air_check.restype = ctypes.c_size_t
+        return L.or_air_check(ctypes.byref(self.c))
+
+    def num_constraints(self):
+        L = lib()
+        L.or_air_num_constraints.restype = ctypes.c_size_t
+        return L.or_air_num_constraints(ctypes.byref(self.c))
+
+    def eval_row(self, local, nxt, publics=(), globals_=(), challenges=()):
+        vals = np.zeros(max(len(self.ops), 1), np.uint64)
+        a = [arr(x) for x in (local, nxt, publics, globals_, challenges)]
+        L = lib()
+        L.or_air_eval_row.restype = None
+        L.or_air_eval_row(ctypes.byref(self.c), *[ptr(x) for x in a], ptr(vals))
+        return vals[:len(self.ops)]
+
+    def eval_ext(self, local, nxt, publics=(), globals_=(), challenges=()):
+        n = self.num_constraints()
+        out = np.zeros((max(n, 1), 2), np.uint64)
+        kinds = np.zeros(max(n, 1), np.uint32)
+        a = [arr(x) for x in (local, nxt, publics, globals_, challenges)]
+        L = lib()
+        L.or_air_eval_ext.restype = None
+        L.or_air_eval_ext(ctypes.byref(self.c), *[ptr(x) for x in a], ptr(out), kinds.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+        return out[:n], kinds[:n]
+
+    def map(self, in_cols, publics=(), globals_=(), challenges=()):
+        v = arr(in_cols)
+        n = v.shape[1]
+        out = np.zeros((max(self.n_out_columns, 1), n), np.uint64)
+        a = [arr(x) for x in (publics, globals_, challenges)]
+        L = lib()
+        L.or_air_map.restype = None
+        L.or_air_map(ctypes.byref(self.c), ptr(v), ptr(out), ctypes.c_size_t(n), *[ptr(x) for x in a])
+        return out[:self.n_out_columns]
+
+
+def air_quotient(program, oracles, qdb, alphas, publics=(), globals_=(), challenges=()):
+    """or_air_quotient -> (len(alphas) * 2^qdb, n) coefficient vectors"""
+    L = lib()
+    L.or_air_quotient.restype = ctypes.c_int
+    hs = (ctypes.c_void_p * len(oracles))(*[o.h for o in oracles])
+    n = 1 << oracles[0].log_n
+    al = arr(alphas)
+    out = np.zeros((al.size << qdb, n), np.uint64)
+    a = [arr(x) for x in (publics, globals_, challenges)]
+    rc = L.or_air_quotient(ctypes.byref(program.c), hs, ctypes.c_size_t(len(oracles)), ctypes.c_int(qdb), *[ptr(x) for x in a], ptr(al),
+                           ctypes.c_size_t(al.size), ptr(out))
+    assert rc == 0, rc
+    return out
+
+
+def cubic_mul(m, a, b):
+    out = np.zeros(3, np.uint64)
+    lib().or_cubic_mul(ptr(arr(m)), ptr(arr(a)), ptr(arr(b)), ptr(out))
+    return out
+
+
+def cubic_batch_inverse(m, cols):
+    v = arr(cols).copy()
+    L = lib()
+    L.or_cubic_batch_inverse.restype = None
+    L.or_cubic_batch_inverse(ptr(arr(m)), ptr(v), ctypes.c_size_t(v.shape[0] // 3), ctypes.c_size_t(v.shape[1]))
+    return v
+
+
+def column_prefix_sum(cols, exclusive=False):
+    v = arr(cols).copy()
+    L = lib()
+    L.or_column_prefix_sum.restype = None
+    L.or_column_prefix_sum(ptr(v), ctypes.c_size_t(v.shape[0]), ctypes.c_size_t(v.shape[1]), ctypes.c_int(int(exclusive)))
+    return v
+
+
+def stark_desc(degree_bits, quotient_degree_bits, num_challenges, fri, n_trace_columns, constraints, n_extended_columns=0, n_round_challenges=0,
+               n_public=0, n_global=0, steps=()):
+    """or_stark_desc; steps as cityprover.stark_desc takes them (with oracle_lib.AirProgram objects). Returns (desc, keep-alive)."""
+    sa = (StarkStepC * max(1, len(steps)))()
+    for i, st in enumerate(steps):
+        if st[0] == "map":
+            sa[i].kind, sa[i].program = 0, ctypes.pointer(st[1].c)
+        elif st[0] == "cubic_inverse":
+            sa[i].kind, sa[i].first, sa[i].count = 1, st[1], st[2]
+            sa[i].modulus[0], sa[i].modulus[1] = int(st[3][0]), int(st[3][1])
+        else:
+            sa[i].kind, sa[i].first, sa[i].count, sa[i].flags = 2, st[1], st[2], int(bool(st[3]))
+    d = StarkDescC(degree_bits, quotient_degree_bits, num_challenges, fri, n_trace_columns, n_extended_columns, n_round_challenges, n_public, n_global,
+                   ctypes.cast(sa, ctypes.POINTER(StarkStepC)), len(steps), ctypes.pointer(constraints.c))
+    return d, (sa, steps, constraints)
+
+
+def stark_prove(desc, trace, challenger, publics=(), globals_=(), pow_override=None):
+    L = lib()
+    L.or_stark_prove.restype = ctypes.c_int
+    t = arr(trace)
+    out, ln = ctypes.POINTER(ctypes.c_uint8)(), ctypes.c_size_t(0)
+    rc = L.or_stark_prove(ctypes.byref(desc), ptr(t), ptr(arr(publics)), ptr(arr(globals_)), ctypes.byref(challenger),
+                          ctypes.c_int(0 if pow_override is None else 1), ctypes.c_uint64(pow_override or 0), ctypes.byref(out), ctypes.byref(ln))
+    assert rc == 0, rc
+    data = ctypes.string_at(out, ln.value)
+    L.or_free(out)
+    return data
+
+
+def stark_verify(desc, challenger, proof, publics=(), globals_=()):
+    L = lib()
+    L.or_stark_verify.restype = ctypes.c_int
+    buf = (ctypes.c_uint8 * len(proof)).from_buffer_copy(proof)
+    return L.or_stark_verify(ctypes.byref(desc), ptr(arr(publics)), ptr(arr(globals_)), ctypes.byref(challenger), buf, ctypes.c_size_t(len(proof)))
