@@ -16,6 +16,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <map>
 #include <queue>
 #include <string>
 #include <vector>
@@ -37,7 +38,7 @@ inline bool is_arith(uint32_t op) { return op >= R_ADD && op <= R_INV; }
 // bytecode: one 64-bit word per instruction
 //   bits 0-3 op | 4-6 kind of a | 7-9 kind of b | 10-23 dst slot (DST_NONE: result only in the accumulator; SINK: the
 //   selector 0..3; STORE: unused) | 24-43 index of a | 44-63 index of b (STORE: the output column)
-enum : uint32_t { I_ADD = 0, I_SUB = 1, I_MUL = 2, I_INV = 3, I_SINK = 4, I_STORE = 5 };
+enum : uint32_t { I_ADD = 0, I_SUB = 1, I_MUL = 2, I_INV = 3, I_SINK = 4, I_STORE = 5, I_LOAD = 6 };  // I_LOAD: slot dst <- column a (kind LOCAL / NEXT)
 enum : uint32_t { K_ACC = 0, K_SLOT = 1, K_UNI = 2, K_LOCAL = 3, K_NEXT = 4 };
 constexpr uint32_t DST_NONE = 0x3FFF;
 constexpr uint32_t MAX_INDEX = 1u << 20;
@@ -152,7 +153,10 @@ struct Compiled {
 };
 
 // Cut the roots into at most `want_segments` runs of about equal work and emit each run's backward slice.
-inline Compiled compile(const Program &p, uint32_t want_segments) {
+// prefetch: column operands are loaded into slots in batches of up to PREFETCH_BATCH, ahead of the instructions that use them (one
+// memory latency per batch instead of one per operand); false: every column operand is a load at its use.
+constexpr size_t PREFETCH_BATCH = 8, PREFETCH_WINDOW = 32;
+inline Compiled compile(const Program &p, uint32_t want_segments, bool prefetch = true) {
   Compiled C;
   const size_t n = p.ops.size();
   const size_t n_roots = p.roots.size();
@@ -178,6 +182,11 @@ inline Compiled compile(const Program &p, uint32_t want_segments) {
   }
   std::vector<uint32_t> stamp(n, 0xFFFFFFFFu), uses(n, 0), slot(n, DST_NONE);
   std::vector<uint32_t> need;
+  // one abstract instruction per emitted op: operands are uniform-table entries, columns (to be prefetched) or earlier values
+  enum : uint8_t { O_UNI = 0, O_COL = 1, O_VAL = 2 };
+  struct Operand { uint8_t kind; uint32_t ix; };  // O_COL: (next << 20) | column; O_VAL: the raw op index of the value
+  struct AInstr { uint32_t op; Operand a, b; uint32_t aux; uint32_t def; };  // aux: sink selector / store column; def: raw op index or ~0
+  std::vector<AInstr> ai;
   C.seg_off.push_back(0);
   for (size_t s = 0; s < runs.size(); s++) {
     need.clear();
@@ -202,57 +211,101 @@ inline Compiled compile(const Program &p, uint32_t want_segments) {
       }
     }
     std::sort(need.begin(), need.end());
-    auto each_operand = [&](const RawOp &o, auto f) {
-      if (o.op == R_STORE) f(o.b);
-      else {
-        f(o.a);
-        if (o.op == R_ADD || o.op == R_SUB || o.op == R_MUL) f(o.b);
-      }
+    // ---- abstract instructions ----
+    auto operand = [&](uint32_t x) -> Operand {
+      const RawOp &src = p.ops[x];
+      if (src.op == R_LOCAL) return {O_COL, src.a};
+      if (src.op == R_NEXT) return {O_COL, (1u << 20) | src.a};
+      if (src.op == R_CONST) return {O_UNI, src.a};
+      if (src.op == R_PUBLIC) return {O_UNI, p.uni_public() + src.a};
+      if (src.op == R_GLOBAL) return {O_UNI, p.uni_global() + src.a};
+      if (src.op == R_CHALLENGE) return {O_UNI, p.uni_challenge() + src.a};
+      return {O_VAL, x};
     };
-    for (uint32_t i : need) each_operand(p.ops[i], [&](uint32_t x) { uses[x]++; });
+    ai.clear();
+    const Operand zero{O_UNI, p.uni_zero()};
+    for (uint32_t i : need) {
+      const RawOp &o = p.ops[i];
+      switch (o.op) {
+        case R_ADD: ai.push_back({I_ADD, operand(o.a), operand(o.b), 0, i}); break;
+        case R_SUB: ai.push_back({I_SUB, operand(o.a), operand(o.b), 0, i}); break;
+        case R_MUL: ai.push_back({I_MUL, operand(o.a), operand(o.b), 0, i}); break;
+        case R_NEG: ai.push_back({I_SUB, zero, operand(o.a), 0, i}); break;  // 0 - a
+        case R_INV: ai.push_back({I_INV, operand(o.a), zero, 0, i}); break;
+        case R_STORE: ai.push_back({I_STORE, operand(o.b), zero, o.a, 0xFFFFFFFFu}); break;
+        default: ai.push_back({I_SINK, operand(o.a), zero, o.op - R_ASSERT, 0xFFFFFFFFu}); break;
+      }
+    }
+    for (const AInstr &x : ai) {
+      if (x.a.kind == O_VAL) uses[x.a.ix]++;
+      if (x.b.kind == O_VAL) uses[x.b.ix]++;
+    }
+    // ---- emission: slots by liveness, column operands prefetched in batches ----
     std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> free_slots;
     uint32_t next_slot = 0;
-    for (size_t t = 0; t < need.size(); t++) {
-      const uint32_t i = need[t];
-      const RawOp &o = p.ops[i];
-      const uint32_t prev = t ? need[t - 1] : 0xFFFFFFFFu;  // the value the accumulator holds (when it defines one)
-      auto operand = [&](uint32_t x, uint32_t &k, uint32_t &ix) {
-        const RawOp &src = p.ops[x];
-        if (src.op == R_LOCAL) { k = K_LOCAL; ix = src.a; }
-        else if (src.op == R_NEXT) { k = K_NEXT; ix = src.a; }
-        else if (src.op == R_CONST) { k = K_UNI; ix = src.a; }
-        else if (src.op == R_PUBLIC) { k = K_UNI; ix = p.uni_public() + src.a; }
-        else if (src.op == R_GLOBAL) { k = K_UNI; ix = p.uni_global() + src.a; }
-        else if (src.op == R_CHALLENGE) { k = K_UNI; ix = p.uni_challenge() + src.a; }
-        else if (x == prev) { k = K_ACC; ix = 0; }
-        else { k = K_SLOT; ix = slot[x]; }
-      };
-      uint32_t ka = K_UNI, ia = p.uni_zero(), kb = K_UNI, ib = p.uni_zero(), op = I_ADD, dst = DST_NONE;
-      switch (o.op) {
-        case R_ADD: op = I_ADD; operand(o.a, ka, ia); operand(o.b, kb, ib); break;
-        case R_SUB: op = I_SUB; operand(o.a, ka, ia); operand(o.b, kb, ib); break;
-        case R_MUL: op = I_MUL; operand(o.a, ka, ia); operand(o.b, kb, ib); break;
-        case R_NEG: op = I_SUB; operand(o.a, kb, ib); break;  // 0 - a
-        case R_INV: op = I_INV; operand(o.a, ka, ia); break;
-        case R_STORE: op = I_STORE; operand(o.b, ka, ia); ib = o.a; kb = K_UNI; break;
-        default: op = I_SINK; operand(o.a, ka, ia); dst = o.op - R_ASSERT; break;
-      }
-      // operands consumed: slots whose last use this was go back to the pool BEFORE the result takes one (the interpreter
-      // reads both operands before it writes)
-      each_operand(o, [&](uint32_t x) {
-        if (--uses[x] == 0 && slot[x] != DST_NONE) { free_slots.push(slot[x]); slot[x] = DST_NONE; }
-      });
-      if (defines_value(o.op)) {
-        // a slot unless every use is an operand of the very next instruction
-        uint32_t next_uses = 0;
-        if (t + 1 < need.size()) each_operand(p.ops[need[t + 1]], [&](uint32_t x) { next_uses += x == i; });
-        if (uses[i] > next_uses) {
-          if (free_slots.empty()) slot[i] = next_slot++;
-          else { slot[i] = free_slots.top(); free_slots.pop(); }
-          dst = slot[i];
+    auto take_slot = [&]() {
+      if (free_slots.empty()) return next_slot++;
+      const uint32_t v = free_slots.top();
+      free_slots.pop();
+      return v;
+    };
+    struct Loaded { uint32_t slot, uses_left; };
+    std::map<uint32_t, Loaded> loaded;  // column key -> where it sits and how many operand occurrences it still serves
+    for (size_t t = 0; t < ai.size(); t++) {
+      const AInstr &x = ai[t];
+      if (prefetch) {
+        // a column operand that is not in a slot: load it together with the next columns the instructions ahead will need
+        const bool miss = (x.a.kind == O_COL && !loaded.count(x.a.ix)) || (x.b.kind == O_COL && !loaded.count(x.b.ix));
+        if (miss) {
+          std::vector<uint32_t> keys;
+          size_t u = t;
+          for (; u < ai.size() && u < t + PREFETCH_WINDOW && keys.size() < PREFETCH_BATCH; u++)
+            for (const Operand *o : {&ai[u].a, &ai[u].b})
+              if (o->kind == O_COL && !loaded.count(o->ix) && std::find(keys.begin(), keys.end(), o->ix) == keys.end() && keys.size() < PREFETCH_BATCH)
+                keys.push_back(o->ix);
+          // the batch serves the occurrences of its keys in [t, u): count them (the last scanned instruction may be cut short when
+          // the batch filled up on its first operand: count only what was taken)
+          for (uint32_t k : keys) loaded[k] = Loaded{take_slot(), 0};
+          for (size_t v = t; v < u; v++)
+            for (const Operand *o : {&ai[v].a, &ai[v].b})
+              if (o->kind == O_COL) {
+                auto it = loaded.find(o->ix);
+                if (it != loaded.end() && std::find(keys.begin(), keys.end(), o->ix) != keys.end()) it->second.uses_left++;
+              }
+          for (uint32_t k : keys) C.code.push_back(encode(I_LOAD, (k >> 20) ? K_NEXT : K_LOCAL, K_UNI, loaded[k].slot, k & 0xFFFFF, 0));
         }
       }
-      C.code.push_back(encode(op, ka, kb, dst, ia, ib));
+      const uint32_t prev = t ? ai[t - 1].def : 0xFFFFFFFFu;  // the value the accumulator holds (when the last instruction defined one)
+      auto place = [&](const Operand &o, uint32_t &k, uint32_t &ix) {
+        if (o.kind == O_UNI) { k = K_UNI; ix = o.ix; }
+        else if (o.kind == O_COL) {
+          if (prefetch) { k = K_SLOT; ix = loaded[o.ix].slot; }
+          else { k = (o.ix >> 20) ? K_NEXT : K_LOCAL; ix = o.ix & 0xFFFFF; }
+        } else if (o.ix == prev) { k = K_ACC; ix = 0; }
+        else { k = K_SLOT; ix = slot[o.ix]; }
+      };
+      uint32_t ka, ia, kb, ib, dst = DST_NONE;
+      place(x.a, ka, ia);
+      place(x.b, kb, ib);
+      if (x.op == I_SINK) dst = x.aux;
+      if (x.op == I_STORE) ib = x.aux;
+      // operands consumed: slots whose last use this was go back to the pool BEFORE the result takes one (the interpreter reads both
+      // operands before it writes)
+      for (const Operand *o : {&x.a, &x.b}) {
+        if (o->kind == O_VAL) {
+          if (--uses[o->ix] == 0 && slot[o->ix] != DST_NONE) { free_slots.push(slot[o->ix]); slot[o->ix] = DST_NONE; }
+        } else if (o->kind == O_COL && prefetch) {
+          auto it = loaded.find(o->ix);
+          if (--it->second.uses_left == 0) { free_slots.push(it->second.slot); loaded.erase(it); }
+        }
+      }
+      if (x.def != 0xFFFFFFFFu) {
+        // a slot unless every use is an operand of the very next instruction
+        uint32_t next_uses = 0;
+        if (t + 1 < ai.size()) next_uses = (ai[t + 1].a.kind == O_VAL && ai[t + 1].a.ix == x.def) + (ai[t + 1].b.kind == O_VAL && ai[t + 1].b.ix == x.def);
+        if (uses[x.def] > next_uses) dst = slot[x.def] = take_slot();
+      }
+      C.code.push_back(encode(x.op, ka, kb, dst, ia, ib));
     }
     C.n_slots = std::max(C.n_slots, next_slot);
     C.seg_off.push_back((uint32_t)C.code.size());
@@ -268,14 +321,14 @@ constexpr int MAX_ALPHAS = 4;
 
 // ---- the instruction semantics, shared by the host executor (tests/hostsim, cp_air_program_eval_ext has its own F_p^2 form)
 // and the device interpreter ----
-template <class Mem>  // Mem: slot_read(i), slot_write(i, v), uni(i), local(i), next(i), store(col, v)
-GL_HD void run_segment(const uint64_t *code, uint32_t first, uint32_t last, Mem &m, const uint64_t *alphas, int n_alphas, const Selectors &sel,
+template <class Mem>  // Mem: code(pc), alpha(c), slot_read(i), slot_write(i, v), uni(i), local(i), next(i), store(col, v)
+GL_HD void run_segment(uint32_t first, uint32_t last, Mem &m, int n_alphas, const Selectors &sel,
                        uint64_t *acc_out /* [MAX_ALPHAS], Horner sums of this segment */) {
   uint64_t acc = 0;
 #pragma unroll
   for (int c = 0; c < MAX_ALPHAS; c++) acc_out[c] = 0;
   for (uint32_t pc = first; pc < last; pc++) {
-    const uint64_t w = code[pc];
+    const uint64_t w = m.code(pc);
     const uint32_t op = (uint32_t)w & 15, ka = (uint32_t)(w >> 4) & 7, kb = (uint32_t)(w >> 7) & 7, dst = (uint32_t)(w >> 10) & 0x3FFF,
                    ia = (uint32_t)(w >> 24) & 0xFFFFF, ib = (uint32_t)(w >> 44);
     auto fetch = [&](uint32_t k, uint32_t i) -> uint64_t {
@@ -287,12 +340,35 @@ GL_HD void run_segment(const uint64_t *code, uint32_t first, uint32_t last, Mem 
         default: return m.next(i);
       }
     };
+    if (op == I_LOAD) {
+      // a run of up to PREFETCH_BATCH loads: every load is issued before the first value is needed, then the slots are written
+      uint64_t v[PREFETCH_BATCH];
+      uint32_t d[PREFETCH_BATCH];
+      uint32_t r = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < PREFETCH_BATCH; j++) {
+        if (j == r && pc + j < last) {
+          const uint64_t wj = m.code(pc + j);
+          if (((uint32_t)wj & 15) == I_LOAD) {
+            const uint32_t col = (uint32_t)(wj >> 24) & 0xFFFFF;
+            v[j] = (((uint32_t)(wj >> 4) & 7) == K_NEXT) ? m.next(col) : m.local(col);
+            d[j] = (uint32_t)(wj >> 10) & 0x3FFF;
+            r = j + 1;
+          }
+        }
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < PREFETCH_BATCH; j++)
+        if (j < r) m.slot_write(d[j], v[j]);
+      pc += r - 1;
+      continue;
+    }
     const uint64_t a = fetch(ka, ia);
     if (op == I_SINK) {
       const uint64_t v = dst == 0 ? a : gl::mul(a, dst == 1 ? sel.z_last : dst == 2 ? sel.l_first : sel.l_last);
 #pragma unroll
       for (int c = 0; c < MAX_ALPHAS; c++)
-        if (c < n_alphas) acc_out[c] = gl::add(gl::mul(acc_out[c], alphas[c]), v);
+        if (c < n_alphas) acc_out[c] = gl::add(gl::mul(acc_out[c], m.alpha(c)), v);
       continue;
     }
     if (op == I_STORE) { m.store(ib, a); continue; }
@@ -327,11 +403,28 @@ struct KArgs {
   int degree_bits, n_alphas, n_lds;
 };
 
+// The bytecode, the uniform table, the column pointer table, the alphas and the weights are read at wave-uniform addresses. Read
+// through ordinary global pointers they are VECTOR loads (the kernel also stores to global memory, so the compiler may not treat
+// them as invariant): one memory round trip per interpreted instruction for the instruction word alone, another for a pointer
+// before the column load that needs it. Through the constant address space they are scalar loads (s_load: the scalar cache,
+// invariant by definition) - the kernel never writes what it reads this way.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AIR_CONSTANT_AS __attribute__((address_space(4)))
+#else
+#define AIR_CONSTANT_AS
+#endif
+template <class T>
+__device__ __forceinline__ const AIR_CONSTANT_AS T *constant_as(const T *p) {
+  return (const AIR_CONSTANT_AS T *)p;
+}
+
 struct DevMem {
   uint64_t *lds;  // this wave's slots, [slot][lane]
   const KArgs &a;
   size_t pos, npos, gid;
   int lane;
+  __device__ __forceinline__ uint64_t code(uint32_t pc) const { return constant_as(a.code)[pc]; }
+  __device__ __forceinline__ uint64_t alpha(int c) const { return constant_as(a.alphas)[c]; }
   __device__ __forceinline__ uint64_t slot_read(uint32_t i) const {
     return (int)i < a.n_lds ? lds[i * WAVE + lane] : a.spill[(size_t)(i - a.n_lds) * a.spill_stride + gid];
   }
@@ -339,11 +432,11 @@ struct DevMem {
     if ((int)i < a.n_lds) lds[i * WAVE + lane] = v;
     else a.spill[(size_t)(i - a.n_lds) * a.spill_stride + gid] = v;
   }
-  __device__ __forceinline__ uint64_t uni(uint32_t i) const { return a.uni[i]; }
-  __device__ __forceinline__ uint64_t local(uint32_t i) const { return a.cols[i][pos]; }
-  __device__ __forceinline__ uint64_t next(uint32_t i) const { return a.cols[i][npos]; }
+  __device__ __forceinline__ uint64_t uni(uint32_t i) const { return constant_as(a.uni)[i]; }
+  __device__ __forceinline__ uint64_t local(uint32_t i) const { return ((const uint64_t *)constant_as(a.cols)[i])[pos]; }
+  __device__ __forceinline__ uint64_t next(uint32_t i) const { return ((const uint64_t *)constant_as(a.cols)[i])[npos]; }
   __device__ __forceinline__ void store(uint32_t col, uint64_t v) const {
-    if (pos < a.M) a.out_cols[col][pos] = v;
+    if (pos < a.M) ((uint64_t *)constant_as(a.out_cols)[col])[pos] = v;
   }
 };
 
@@ -370,11 +463,11 @@ __global__ __launch_bounds__(WAVE) void k_run(KArgs a) {
   Selectors sel{0, 0, 0};
   if (MODE == 0) sel = Selectors{a.sel[pos], a.sel[a.M + pos], a.sel[2 * a.M + pos]};
   uint64_t acc[MAX_ALPHAS];
-  run_segment(a.code, a.seg_off[seg], a.seg_off[seg + 1], m, a.alphas, MODE == 0 ? a.n_alphas : 0, sel, acc);
+  run_segment(constant_as(a.seg_off)[seg], constant_as(a.seg_off)[seg + 1], m, MODE == 0 ? a.n_alphas : 0, sel, acc);
   if (MODE == 0 && active) {
 #pragma unroll
     for (int c = 0; c < MAX_ALPHAS; c++)
-      if (c < a.n_alphas) a.parts[((size_t)seg * a.n_alphas + c) * a.M + pos] = gl::mul(acc[c], a.weights[seg * a.n_alphas + c]);
+      if (c < a.n_alphas) a.parts[((size_t)seg * a.n_alphas + c) * a.M + pos] = gl::mul(acc[c], constant_as(a.weights)[seg * a.n_alphas + c]);
   }
 }
 
@@ -399,18 +492,33 @@ __global__ __launch_bounds__(256) void k_selectors(uint64_t *out, size_t M, int 
   out[2 * M + pos] = gl::mul(gl::mul(zhn, g_last), gl::inv(zl));
 }
 
-// sum of the segments' parts, / Z_H (2^q distinct values: zh_inv[nat mod 2^q]), scattered to the NATURAL order the coset iNTT reads
+// sum of the segments' parts, / Z_H (2^q distinct values: zh_inv[nat mod 2^q]), scattered to the NATURAL order the coset iNTT reads.
+// A workgroup = 64 points x 4 groups of segments (a small trace is cut into hundreds of segments: one thread per point would walk
+// them all in sequence); the four partial sums meet in LDS.
 __global__ __launch_bounds__(256) void k_finish(const uint64_t *parts, uint32_t n_segments, int n_alphas, size_t M, int log_M, int q_bits,
                                                 const uint64_t *zh_inv, uint64_t *out) {
-  const size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (pos >= M) return;
+  __shared__ uint64_t part[MAX_ALPHAS][4][WAVE];
+  const int lane = threadIdx.x & (WAVE - 1), grp = threadIdx.x / WAVE;
+  const size_t pos = (size_t)blockIdx.x * WAVE + lane;
+  const bool active = pos < M;
+#pragma unroll
+  for (int c = 0; c < MAX_ALPHAS; c++)
+    if (c < n_alphas) {
+      uint64_t s = 0;
+      if (active)
+        for (uint32_t g = grp; g < n_segments; g += 4) s = gl::add(s, parts[((size_t)g * n_alphas + c) * M + pos]);
+      part[c][grp][lane] = s;
+    }
+  __syncthreads();
+  if (grp != 0 || !active) return;
   const uint32_t nat = log_M ? __brev((uint32_t)pos) >> (32 - log_M) : 0;
   const uint64_t zi = zh_inv[nat & ((1u << q_bits) - 1)];
-  for (int c = 0; c < n_alphas; c++) {
-    uint64_t s = 0;
-    for (uint32_t g = 0; g < n_segments; g++) s = gl::add(s, parts[((size_t)g * n_alphas + c) * M + pos]);
-    out[(size_t)c * M + nat] = gl::mul(s, zi);
-  }
+#pragma unroll
+  for (int c = 0; c < MAX_ALPHAS; c++)
+    if (c < n_alphas) {
+      const uint64_t s = gl::add(gl::add(part[c][0][lane], part[c][1][lane]), gl::add(part[c][2][lane], part[c][3][lane]));
+      out[(size_t)c * M + nat] = gl::mul(s, zi);
+    }
 }
 
 }  // namespace air

@@ -63,16 +63,18 @@ class Builder:
 
 
 def random_program(seed, n_columns, n_ops, n_public=3, n_global=2, n_challenge=3, max_degree=3, far=0.1):
-    """a seeded constraint program of ~n_ops ops over n_columns columns: chains of arithmetic on recent values (short-lived
-    temporaries), operands from far back with probability `far` (long-lived ones), every column read, sinks of all four kinds
-    within the degree bound (first / last row constraints one lower)."""
+    """a seeded constraint program of ~n_ops ops over n_columns columns, nearly all of it LIVE: chains of arithmetic on recent
+    values (short-lived temporaries), operands from far back with probability `far` (long-lived ones), every column read, values
+    nobody has consumed yet preferred as operands and as constraints, sinks of all four kinds within the degree bound (first /
+    last row constraints one lower)."""
     rng = np.random.default_rng(seed)
     b = Builder(CONSTRAINTS, n_columns, n_public, n_global, n_challenge)
-    deg, vals = {}, []
+    deg, vals, unused = {}, [], []
 
     def push(i, d):
         deg[i] = d
         vals.append(i)
+        unused.append(i)
         return i
 
     def load():
@@ -80,18 +82,23 @@ def random_program(seed, n_columns, n_ops, n_public=3, n_global=2, n_challenge=3
         return push(b.local(c) if rng.random() < 0.6 else b.next(c), 1)
 
     def pick():
+        if unused and rng.random() < 0.7:
+            return unused.pop(max(0, len(unused) - 1 - int(rng.exponential(2))))
         if rng.random() < far:
             return vals[int(rng.integers(0, len(vals)))]
-        return vals[max(0, len(vals) - 1 - int(rng.exponential(6)))]
+        x = vals[max(0, len(vals) - 1 - int(rng.exponential(6)))]
+        if x in unused[-8:]:
+            unused.remove(x)
+        return x
 
     for _ in range(4):
         load()
     n_sinks = 0
     while len(b.ops) < n_ops:
         r = rng.random()
-        if r < 0.30:
+        if r < 0.27 or len(vals) < 4:
             load()
-        elif r < 0.38:
+        elif r < 0.33:
             k = int(rng.integers(0, 4))
             if k == 0:
                 push(b.const(int(rng.integers(0, P, dtype=np.uint64))), 0)
@@ -101,7 +108,7 @@ def random_program(seed, n_columns, n_ops, n_public=3, n_global=2, n_challenge=3
                 push(b.glob(int(rng.integers(0, n_global))), 0)
             elif n_challenge:
                 push(b.challenge(int(rng.integers(0, n_challenge))), 0)
-        elif r < 0.88:
+        elif r < 0.88 and len(unused) < 24:
             x, y = pick(), pick()
             k = rng.random()
             if k < 0.45 and deg[x] + deg[y] <= max_degree:
@@ -111,6 +118,7 @@ def random_program(seed, n_columns, n_ops, n_public=3, n_global=2, n_challenge=3
             elif k < 0.95:
                 push(b.sub(x, y), max(deg[x], deg[y]))
             else:
+                unused.append(y)
                 push(b.neg(x), deg[x])
         else:
             x = pick()
@@ -119,8 +127,73 @@ def random_program(seed, n_columns, n_ops, n_public=3, n_global=2, n_challenge=3
                 when = "all"
             b.assert_zero(x, when)
             n_sinks += 1
+    for x in unused[-64:]:               # what is still unconsumed ends in constraints as well
+        b.assert_zero(x, "all")
+        n_sinks += 1
     if not n_sinks:
         b.assert_zero(vals[-1], "all")
+    return b
+
+
+def gadget_program(seed, n_columns, n_ops, n_public=3, n_global=2, n_challenge=3, max_degree=3, share=0.03):
+    """a seeded constraint program shaped like an AIR that is a list of instructions (byte operations, limb arithmetic, lookup
+    accumulations): GADGETS of 4-12 columns, 10-40 arithmetic ops on their own values and a few uniform ones, 3-8 constraints
+    each; with probability `share` an operand comes from an earlier gadget (a shared subexpression). Expression depth stays
+    bounded, every column is read, all four kinds of constraint occur."""
+    rng = np.random.default_rng(seed)
+    b = Builder(CONSTRAINTS, n_columns, n_public, n_global, n_challenge)
+    deg, old = {}, []
+    col = 0
+    while len(b.ops) < n_ops:
+        vals = []
+        for _ in range(int(rng.integers(4, 13))):
+            c = col % n_columns if rng.random() < 0.7 else int(rng.integers(0, n_columns))
+            col += 1
+            v = b.local(c) if rng.random() < 0.65 else b.next(c)
+            deg[v] = 1
+            vals.append(v)
+        for _ in range(int(rng.integers(0, 3))):
+            k = int(rng.integers(0, 4))
+            if k == 0:
+                v = b.const(int(rng.integers(0, 1 << 16)) if rng.random() < 0.7 else int(rng.integers(0, P, dtype=np.uint64)))
+            elif k == 1 and n_public:
+                v = b.public(int(rng.integers(0, n_public)))
+            elif k == 2 and n_global:
+                v = b.glob(int(rng.integers(0, n_global)))
+            elif n_challenge:
+                v = b.challenge(int(rng.integers(0, n_challenge)))
+            else:
+                continue
+            deg[v] = 0
+            vals.append(v)
+        unused = []
+        for _ in range(int(rng.integers(10, 41))):
+            def pick():
+                if old and rng.random() < share:
+                    return old[int(rng.integers(max(0, len(old) - 400), len(old)))]
+                if unused and rng.random() < 0.6:
+                    return unused.pop(int(rng.integers(0, len(unused))))
+                return vals[int(rng.integers(0, len(vals)))]
+            x, y = pick(), pick()
+            k = rng.random()
+            if k < 0.4 and deg[x] + deg[y] <= max_degree:
+                v, d = b.mul(x, y), deg[x] + deg[y]
+            elif k < 0.7:
+                v, d = b.add(x, y), max(deg[x], deg[y])
+            elif k < 0.95:
+                v, d = b.sub(x, y), max(deg[x], deg[y])
+            else:
+                v, d = b.neg(x), deg[x]
+            deg[v] = d
+            vals.append(v)
+            unused.append(v)
+        n_c = int(rng.integers(3, 9))
+        for x in (unused[-n_c:] if len(unused) >= n_c else unused):
+            when = ("all", "all", "transition", "transition", "first", "last")[int(rng.integers(0, 6))]
+            if when in ("first", "last") and deg[x] + 1 > max_degree:
+                when = "all"
+            b.assert_zero(x, when)
+        old.extend(v for v in vals if deg[v] > 0)
     return b
 
 

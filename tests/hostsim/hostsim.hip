@@ -277,6 +277,9 @@ struct HostMem {
   std::vector<uint64_t> slots;
   const uint64_t *u, *loc, *nxt;
   uint64_t *out;
+  const uint64_t *prog, *al;
+  uint64_t code(uint32_t pc) const { return prog[pc]; }
+  uint64_t alpha(int c) const { return al[c]; }
   uint64_t slot_read(uint32_t i) const { return slots[i]; }
   void slot_write(uint32_t i, uint64_t v) { slots[i] = v; }
   uint64_t uni(uint32_t i) const { return u[i]; }
@@ -289,7 +292,7 @@ extern "C" {
 // dims: n_columns, n_public, n_global, n_challenge, n_out_columns. Returns 0, or -1 with the analyser's message in err (256 bytes).
 // acc_out[c] = sum over segments of (the segment's Horner sum) * alpha_c^(sinks after it) - what k_run + k_finish add up before the
 // division by Z_H; stores_out: the stored columns of a map program; info_out: segments, slots, instructions, live ops, max degree
-int hs_air_point(int kind, const uint32_t *ops, size_t n_ops, const uint64_t *consts, size_t n_consts, const uint32_t *dims, uint32_t want_segments,
+int hs_air_point(int kind, const uint32_t *ops, size_t n_ops, const uint64_t *consts, size_t n_consts, const uint32_t *dims, uint32_t want_segments, int prefetch,
                  const uint64_t *local, const uint64_t *next, const uint64_t *publics, const uint64_t *globals, const uint64_t *challenges,
                  const uint64_t *alphas, int n_alphas, const uint64_t *sel, uint64_t *acc_out, uint64_t *stores_out, uint32_t *info_out, char *err) {
   air::Program P;
@@ -300,19 +303,19 @@ int hs_air_point(int kind, const uint32_t *ops, size_t n_ops, const uint64_t *co
   P.n_columns = dims[0]; P.n_public = dims[1]; P.n_global = dims[2]; P.n_challenge = dims[3]; P.n_out_columns = dims[4];
   const std::string why = air::analyse(P);
   if (!why.empty()) { snprintf(err, 256, "%s", why.c_str()); return -1; }
-  const air::Compiled C = air::compile(P, want_segments);
+  const air::Compiled C = air::compile(P, want_segments, prefetch != 0);
   std::vector<uint64_t> uni(P.consts);
   uni.insert(uni.end(), publics, publics + P.n_public);
   uni.insert(uni.end(), globals, globals + P.n_global);
   uni.insert(uni.end(), challenges, challenges + P.n_challenge);
   uni.push_back(0);
-  airsim::HostMem m{std::vector<uint64_t>(C.n_slots ? C.n_slots : 1, 0xDEADBEEFull), uni.data(), local, next, stores_out};
+  airsim::HostMem m{std::vector<uint64_t>(C.n_slots ? C.n_slots : 1, 0xDEADBEEFull), uni.data(), local, next, stores_out, C.code.data(), alphas};
   const air::Selectors S{sel[0], sel[1], sel[2]};
   for (int c = 0; c < n_alphas; c++) acc_out[c] = 0;
   for (uint32_t s = 0; s < C.n_segments(); s++) {
     uint64_t acc[air::MAX_ALPHAS];
     std::fill(m.slots.begin(), m.slots.end(), 0xDEADBEEFull);  // a segment must not read what another one left
-    air::run_segment(C.code.data(), C.seg_off[s], C.seg_off[s + 1], m, alphas, kind == 0 ? n_alphas : 0, S, acc);
+    air::run_segment(C.seg_off[s], C.seg_off[s + 1], m, kind == 0 ? n_alphas : 0, S, acc);
     for (int c = 0; c < n_alphas; c++) acc_out[c] = gl::add(acc_out[c], gl::mul(acc[c], gl::pow(alphas[c], C.sinks_after[s])));
   }
   info_out[0] = C.n_segments(); info_out[1] = C.n_slots; info_out[2] = (uint32_t)C.code.size(); info_out[3] = (uint32_t)P.n_live; info_out[4] = P.max_degree;

@@ -28,13 +28,13 @@ def hs():
     import build as hb
     lib = ctypes.CDLL(hb.build())
     u64p, u32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)
-    lib.hs_air_point.argtypes = [ctypes.c_int, u32p, ctypes.c_size_t, u64p, ctypes.c_size_t, u32p, ctypes.c_uint32] + [u64p] * 6 + [ctypes.c_int, u64p, u64p,
-                                                                                                                            u64p, u32p, ctypes.c_char_p]
+    lib.hs_air_point.argtypes = [ctypes.c_int, u32p, ctypes.c_size_t, u64p, ctypes.c_size_t, u32p, ctypes.c_uint32, ctypes.c_int] + [u64p] * 6 + [
+        ctypes.c_int, u64p, u64p, u64p, u32p, ctypes.c_char_p]
     lib.hs_cubic.argtypes = [ctypes.c_int] + [u64p] * 4
     return lib
 
 
-def hs_point(hs, b, want_segments, local, nxt, publics=(), globals_=(), challenges=(), alphas=(), sel=(0, 0, 0)):
+def hs_point(hs, b, want_segments, local, nxt, publics=(), globals_=(), challenges=(), alphas=(), sel=(0, 0, 0), prefetch=1):
     ops, consts = b.arrays()
     u64p, u32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)
     dims = np.array([b.n_columns, b.n_public, b.n_global, b.n_challenge, b.n_out_columns], dtype=np.uint32)
@@ -43,7 +43,7 @@ def hs_point(hs, b, want_segments, local, nxt, publics=(), globals_=(), challeng
     stores = np.zeros(max(b.n_out_columns, 1), np.uint64)
     info = np.zeros(5, np.uint32)
     err = ctypes.create_string_buffer(256)
-    rc = hs.hs_air_point(b.kind, ops.ctypes.data_as(u32p), len(ops), consts.ctypes.data_as(u64p), len(consts), dims.ctypes.data_as(u32p), want_segments,
+    rc = hs.hs_air_point(b.kind, ops.ctypes.data_as(u32p), len(ops), consts.ctypes.data_as(u64p), len(consts), dims.ctypes.data_as(u32p), want_segments, prefetch,
                          *[a.ctypes.data_as(u64p) for a in arrs[:6]], len(alphas), arrs[6].ctypes.data_as(u64p), acc.ctypes.data_as(u64p),
                          stores.ctypes.data_as(u64p), info.ctypes.data_as(u32p), err)
     if rc != 0:
@@ -173,9 +173,13 @@ def test_cubic_and_prefix_sum_primitives(hs):
 
 
 # ---- the product's compiler + instruction semantics on the host, against the oracle ----------------------------------------
-@pytest.mark.parametrize("seed,n_columns,n_ops", [(0, 12, 300), (1, 40, 2000), (2, 418 + 912, 10000), (3, 418 + 912, 12000), (4, 5, 60)])
+@pytest.mark.parametrize("seed,n_columns,n_ops", [(0, 12, 300), (1, 40, 2000), (2, 418 + 912, 10000), (3, 418 + 912, 12000), (4, 5, 60), (5, 418 + 912, 10500),
+                                                  (6, 30, 3000)])
 def test_compiled_program_equals_the_direct_interpreter(hs, seed, n_columns, n_ops):
-    b = A.random_program(seed, n_columns, n_ops, far=0.02 if seed == 3 else 0.1)
+    if seed >= 5:
+        b = A.gadget_program(seed, n_columns, n_ops)       # the shape of an instruction-list AIR
+    else:
+        b = A.random_program(seed, n_columns, n_ops, far=0.02 if seed == 3 else 0.1)   # one connected web of values
     op = b.oracle()
     assert op.check() == 0
     rng = np.random.default_rng(100 + seed)
@@ -189,13 +193,17 @@ def test_compiled_program_equals_the_direct_interpreter(hs, seed, n_columns, n_o
     for segs in (1, 2, 7, 32, 256):
         got, _, info = hs_point(hs, b, segs, loc, nxt, pub, glo, cha, alphas, sel)
         assert got == want, (segs, info)
+        got0, _, info0 = hs_point(hs, b, segs, loc, nxt, pub, glo, cha, alphas, sel, prefetch=0)   # column operands loaded at their use
+        assert got0 == want and info0["instructions"] <= info["instructions"], (segs, info0)
         assert info["segments"] <= max(1, min(segs, op.num_constraints()))
         seen.add(info["segments"])
         if segs == 1:
             one = info
     assert len(seen) > 1 or op.num_constraints() < 2
     # dead values are dropped, loads and uniform values cost no instruction, temporaries are few
-    assert one["instructions"] <= one["live"] <= len(b.ops)
+    # dead values are dropped; uniform values cost no instruction; a column costs one per prefetch (again when it is needed after its
+    # window): never more than the live ops plus a reload here and there
+    assert one["live"] <= len(b.ops) and one["instructions"] <= 1.25 * one["live"]
     assert one["slots"] < 0x3FFF and one["max_degree"] <= 3
     if n_ops >= 10000:
         print("program %d: %d ops, %d live, %d instructions, %d slots in one segment" % (seed, len(b.ops), one["live"], one["instructions"], one["slots"]))

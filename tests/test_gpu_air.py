@@ -115,11 +115,16 @@ def test_quotient_commit_matches_oracle_on_small_random_programs(prover, seed):
     assert info["max_constraint_degree"] <= max_degree
 
 
-@pytest.mark.parametrize("log_rows,seed,far", [(10, 21, 0.1), (14, 22, 0.1), (10, 23, 0.0), (12, 24, 0.5)])
-def test_quotient_commit_at_the_sha256_stark_width(prover, log_rows, seed, far):
+@pytest.mark.parametrize("log_rows,seed,kind", [(10, 21, "gadgets"), (14, 22, "gadgets"), (10, 23, "tangle"), (14, 25, "tangle"), (12, 24, "tangle-far")])
+def test_quotient_commit_at_the_sha256_stark_width(prover, log_rows, seed, kind):
     """>= 10^4 ops over 418 + 912 columns in two oracles, rate_bits 1 (starky's fast configuration: UPSTREAM-MEMORY), degree-3
-    constraints, 2 challenges. `far`: how often an operand comes from far back (long-lived temporaries -> more slots)."""
-    b = A.random_program(seed, 418 + 912, 10500, max_degree=3, far=far)
+    constraints, 2 challenges. "gadgets": the shape of an instruction-list AIR (shallow expressions, little sharing); "tangle": one
+    connected web of values where every constraint reaches far back (the compiler then cuts coarser instead of recomputing the web
+    in every segment), "tangle-far" with half of all operands from anywhere in the program (long-lived temporaries: slots spill)."""
+    if kind == "gadgets":
+        b = A.gadget_program(seed, 418 + 912, 10500, max_degree=3)
+    else:
+        b = A.random_program(seed, 418 + 912, 10500, max_degree=3, far=0.5 if kind == "tangle-far" else 0.1)
     info = quotient_case(prover, b, [418, 912], log_rows, 1, 1, 2, 4, seed)
     assert info["n_ops"] >= 10000 and info["n_constraints"] > 100
     print("rows 2^%d: %s" % (log_rows, info))
@@ -236,7 +241,7 @@ def test_stark_prove_bytes_at_the_sha256_stark_width(prover):
     produces is the byte the oracle produces."""
     import cityprover
     db, k0, k1 = 10, 418, 912
-    cons = A.random_program(77, k0 + k1, 10500, n_public=4, n_global=0, n_challenge=6, max_degree=3)
+    cons = A.gadget_program(77, k0 + k1, 10500, n_public=4, n_global=0, n_challenge=6, max_degree=3)
     m = A.Builder(A.MAP, k0 + k1, n_public=4, n_challenge=6, n_out_columns=k1)
     ch = [m.challenge(i) for i in range(6)]
     for j in range(k1):                                   # every extended column from a couple of trace columns and a challenge
