@@ -578,6 +578,15 @@ def main():
         stark = {"2^10": bench_stark_fri.run(prover, 10, reps=3), "2^14": bench_stark_fri.run(prover, 14, reps=3),
                  "2^16": bench_stark_fri.run(prover, 16, reps=2)}
 
+    # A13's own two steps on the generic device machinery (cp_air_quotient_commit / cp_stark_prove: a recorded constraint program
+    # of >= 10^4 ops at the SHA-256 STARK's width evaluated on the quotient coset straight from the committed traces; the whole
+    # prover with its extended columns filled on the device) - tools/bench_stark_air.py; tests/test_gpu_air.py holds the bytes
+    stark_air = None
+    if rank == 0 and not args.no_qbench:
+        import bench_stark_air
+        stark_air = {"2^10": bench_stark_air.run(prover, 10, reps=3), "2^14": bench_stark_air.run(prover, 14, reps=3),
+                     "2^16": bench_stark_air.run(prover, 16, reps=2)}
+
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
         ntts = k * world
@@ -590,7 +599,7 @@ def main():
         leaf_ms, _ = kern("leaf_hash_cols")
         cols_ms, cols_l = kern("ntt16_cols")
         rows_ms, rows_l = kern("ntt16_rows")
-        lvl_ms = sum(prof.get(nm, {"total_ms": 0.0})["total_ms"] for nm in ("merkle_level", "merkle_level_coop", "merkle_levels_coop"))
+        lvl_ms = sum(prof.get(nm, {"total_ms": 0.0})["total_ms"] for nm in ("merkle_level", "merkle_level_fused", "merkle_level_coop", "merkle_levels_coop"))
         # Dominant kernel by time: the Poseidon leaf hash (75 % of the step). It moves exactly its algorithmic bytes
         # (8*R*k read + 32*R written) but is bound by integer-VALU issue, not by HBM: ~15 K VALU
         # instructions per permutation. `roofline` is therefore priced in lane-operations against the VALU issue peak;
@@ -599,8 +608,16 @@ def main():
         # was collected with the kernel sources as they are now; the durations are this run's HIP events.
         default_shape = (k, log_n) == (COLS, LOG_N)
         pmc, pmc_refused = stored_pmc() if default_shape else ({}, "not the default workload shape")
-        leaf_bytes = 8.0 * n * k + 32.0 * n
-        perms = n * ((k + 7) // 8)
+        # round 4: the leaf-hash workgroups also compute the first levels of their 256-leaf subtrees (csrc/merkle.h fused_levels;
+        # CITYPROVER_MERKLE_FUSE, default 3, as long as the level is at least as wide as the cooperative kernels' switch): those node
+        # permutations and digests are work of the SAME launch and are counted with it
+        fuse = max(0, min(3, int(os.environ.get("CITYPROVER_MERKLE_FUSE", "3"))))
+        coop_max = int(os.environ.get("CITYPROVER_COOP_MAX", "16384"))
+        while fuse > 0 and ((n >> fuse) < coop_max or (n >> (fuse + 0)) <= (1 << CAP_H) or n % 256):
+            fuse -= 1
+        fused_nodes = sum(n >> l for l in range(1, fuse + 1))
+        leaf_bytes = 8.0 * n * k + 32.0 * (n + fused_nodes)
+        perms = n * ((k + 7) // 8) + fused_nodes
         pl = pmc.get("leaf_hash_cols", {})
         hbm = {"achieved_GBs": leaf_bytes / (leaf_ms * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
                "frac": leaf_bytes / (leaf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": leaf_bytes,
@@ -672,10 +689,17 @@ def main():
             "kernels_ms_per_step": {name: d["total_ms"] / args.steps for name, d in prof.items()},
             "poseidon_perms_per_s": (perms / (leaf_ms * 1e-3)) if leaf_ms else None,
             "merkle_levels_ms": lvl_ms / args.steps,
+            "merkle_levels_fused_into_leaf_hash": {"levels": fuse, "node_permutations": fused_nodes,
+                                                   "ms_at_this_run's_leaf_rate": (fused_nodes / (perms / (leaf_ms * 1e-3)) * 1e3) if leaf_ms else None,
+                                                   "note": "merkle_levels_ms counts the separate level launches only; the levels the leaf-hash workgroups compute "
+                                                           "themselves are inside leaf_hash_cols (their permutations are counted in poseidon_perms_per_s)"},
             "cpu_baseline": base,
             "qbench": dict(qb, roofline=qbench_roofline(qb, (perms / (leaf_ms * 1e-3)) if leaf_ms else None)) if qb else None,
             "groth16_kernels": g16,
             "stark_commit_fri": stark,
+            "stark_quotient_ms": {k: v["stark_quotient_ms"] for k, v in stark_air.items()} if stark_air else None,
+            "stark_prove_ms": {k: v["stark_prove_ms"] for k, v in stark_air.items()} if stark_air else None,
+            "stark_air": stark_air,
             "power_and_clock": pw,
         }
         emit(out)

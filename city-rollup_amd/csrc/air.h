@@ -154,9 +154,10 @@ struct Compiled {
 
 // Cut the roots into at most `want_segments` runs of about equal work and emit each run's backward slice.
 // prefetch: column operands are loaded into slots in batches of up to PREFETCH_BATCH, ahead of the instructions that use them (one
-// memory latency per batch instead of one per operand); false: every column operand is a load at its use.
+// memory latency per batch instead of one per operand); false (the default of the library: stark.inc air_prefetch): every column
+// operand is a load at its use, hidden by the other waves of the CU.
 constexpr size_t PREFETCH_BATCH = 8, PREFETCH_WINDOW = 32;
-inline Compiled compile(const Program &p, uint32_t want_segments, bool prefetch = true) {
+inline Compiled compile(const Program &p, uint32_t want_segments, bool prefetch = false) {
   Compiled C;
   const size_t n = p.ops.size();
   const size_t n_roots = p.roots.size();
@@ -385,7 +386,8 @@ GL_HD void run_segment(uint32_t first, uint32_t last, Mem &m, int n_alphas, cons
 
 // ---- device side ----
 constexpr int WAVE = 64;
-constexpr uint32_t MAX_LDS_SLOTS = 64;  // 32 KB per one-wave workgroup; slots beyond live in global scratch
+constexpr uint32_t MAX_LDS_SLOTS = 24;  // 12 KB per one-wave workgroup (13 waves per CU); slots beyond live in global scratch (the
+                                        // allocator hands out the lowest free number first, so the high numbers are the long-lived, rarely touched ones)
 
 struct KArgs {
   const uint64_t *code;

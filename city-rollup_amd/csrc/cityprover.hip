@@ -237,11 +237,27 @@ size_t merkle_words_per_tree(size_t n_leaves, int cap_height) {
   return nodes * 4;
 }
 
-// Levels above the leaf digests for `n_trees` trees laid out per tree at D + t*per_tree (level 0 first).
+// How many levels the leaf-hash workgroups (and the fused level kernel) compute themselves: CITYPROVER_MERKLE_FUSE = 0 (none: one
+// launch per level, the round-3 form) .. 3 (default, merkle.h fused_levels).
+int merkle_fuse_levels() {
+  static const int v = getenv("CITYPROVER_MERKLE_FUSE") ? atoi(getenv("CITYPROVER_MERKLE_FUSE")) : 3;
+  return v < 0 ? 0 : v > 3 ? 3 : v;
+}
+// levels a 256-node workgroup may add on top of a level of `nodes` nodes: below the cap, and only whole workgroups
+int fusable_levels(size_t nodes, size_t cap_n, int want) {
+  if (nodes % merkle::THREADS) return 0;
+  int f = 0;
+  while (f < want && (nodes >> (f + 1)) > cap_n) f++;
+  return f;
+}
+
+// Levels above the leaf digests for `n_trees` trees laid out per tree at D + t*per_tree (level 0 first). `done`: levels the
+// leaf-hash launch has computed already (fused_levels).
 int merkle_levels(cp_ctx *ctx, uint64_t *D, size_t per_tree, size_t n_leaves, size_t n_trees,
-                  int cap_height, uint64_t *caps) {
+                  int cap_height, uint64_t *caps, int done = 0) {
   size_t cap_n = (size_t)1 << cap_height;
   size_t n = n_leaves, off = 0;
+  for (int l = 0; l < done; l++, n >>= 1) off += n * 4;
   while (n > cap_n) {
     size_t np = n / 2;
     const uint64_t *child = D + off;
@@ -264,6 +280,18 @@ int merkle_levels(cp_ctx *ctx, uint64_t *D, size_t per_tree, size_t n_leaves, si
         for (int l = 0; l < levels; l++, n >>= 1) off += n * 4;
       }
       break;
+    }
+    // a level that fills the chip, lane per parent: with up to three more levels by the same workgroups when they are whole and
+    // stay below the cap (and those levels would not rather go to the cooperative kernels: they are at least as wide as its switch)
+    int fuse = np == cap_n ? 0 : fusable_levels(np, cap_n, merkle_fuse_levels());
+    while (fuse > 0 && (np >> fuse) * n_trees < coop_max) fuse--;
+    if (fuse > 0) {
+      const dim3 g((unsigned)(np / merkle::THREADS), (unsigned)n_trees), b(merkle::THREADS);
+      if (fuse == 1) LAUNCH(ctx, "merkle_level_fused", merkle::k_level_fused<1>, g, b, D, off, np, per_tree);
+      else if (fuse == 2) LAUNCH(ctx, "merkle_level_fused", merkle::k_level_fused<2>, g, b, D, off, np, per_tree);
+      else LAUNCH(ctx, "merkle_level_fused", merkle::k_level_fused<3>, g, b, D, off, np, per_tree);
+      for (int l = 0; l <= fuse; l++, n >>= 1) off += n * 4;
+      continue;
     }
     if (np * n_trees <= coop_max)
       LAUNCH(ctx, "merkle_level_coop", pcoop::k_level_coop, dim3(blocks_for(np, pcoop::STATES_PER_BLOCK), (unsigned)n_trees), dim3(256), child,
@@ -307,13 +335,27 @@ int merkle_cols_batch(cp_ctx *ctx, const uint64_t *cols, size_t n_leaves, size_t
              tree_cols_stride, per_tree, (const uint64_t *)nullptr, 0, (size_t)0);
     return merkle_levels(ctx, D, per_tree, n_leaves, n_trees, cap_height, caps);
   }
-  if (salt && n_salt > 0)
-    LAUNCH(ctx, "leaf_hash_cols", merkle::k_leaf_hash_cols<true>, grid, block, cols, n_leaves, (int)leaf_len, col_stride, D,
-           tree_cols_stride, per_tree, salt, n_salt, salt_tree_stride);
-  else
-    LAUNCH(ctx, "leaf_hash_cols", merkle::k_leaf_hash_cols<false>, grid, block, cols, n_leaves, (int)leaf_len, col_stride, D,
-           tree_cols_stride, per_tree, (const uint64_t *)nullptr, 0, (size_t)0);
-  return merkle_levels(ctx, D, per_tree, n_leaves, n_trees, cap_height, caps);
+  // the first levels by the leaf-hash workgroups themselves (merkle.h fused_levels) when the levels they would write are wide
+  // enough to belong to the lane-per-parent kernel anyway
+  static const size_t coop_max = getenv("CITYPROVER_COOP_MAX") ? strtoull(getenv("CITYPROVER_COOP_MAX"), nullptr, 10) : 16384;
+  int fuse = fusable_levels(n_leaves, (size_t)1 << cap_height, merkle_fuse_levels());
+  while (fuse > 0 && (n_leaves >> fuse) * n_trees < coop_max) fuse--;
+#define CP_LEAF_LAUNCH(SALTED, F, SP, NS, SS)                                                                                          \
+  LAUNCH(ctx, "leaf_hash_cols", (merkle::k_leaf_hash_cols<SALTED, F>), grid, block, cols, n_leaves, (int)leaf_len, col_stride, D, \
+         tree_cols_stride, per_tree, SP, NS, SS)
+  if (salted) {
+    if (fuse == 3) CP_LEAF_LAUNCH(true, 3, salt, n_salt, salt_tree_stride);
+    else if (fuse == 2) CP_LEAF_LAUNCH(true, 2, salt, n_salt, salt_tree_stride);
+    else if (fuse == 1) CP_LEAF_LAUNCH(true, 1, salt, n_salt, salt_tree_stride);
+    else CP_LEAF_LAUNCH(true, 0, salt, n_salt, salt_tree_stride);
+  } else {
+    if (fuse == 3) CP_LEAF_LAUNCH(false, 3, (const uint64_t *)nullptr, 0, (size_t)0);
+    else if (fuse == 2) CP_LEAF_LAUNCH(false, 2, (const uint64_t *)nullptr, 0, (size_t)0);
+    else if (fuse == 1) CP_LEAF_LAUNCH(false, 1, (const uint64_t *)nullptr, 0, (size_t)0);
+    else CP_LEAF_LAUNCH(false, 0, (const uint64_t *)nullptr, 0, (size_t)0);
+  }
+#undef CP_LEAF_LAUNCH
+  return merkle_levels(ctx, D, per_tree, n_leaves, n_trees, cap_height, caps, fuse);
 }
 
 bool valid_merkle_shape(size_t n_leaves, int cap_height) {

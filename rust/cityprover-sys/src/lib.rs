@@ -394,3 +394,50 @@ pub fn groth16_pack_city(a_xy: &[u64; 12], b_xy: &[u64; 24], c_xy: &[u64; 12]) -
     }
     Ok(out)
 }
+
+/// A straight-line AIR program compiled for the device (`cp_air_program`, include/cityprover.h "the STARK's own two steps as
+/// GENERIC device machinery"): what rust/starkyx-patch/recording_parser.rs produces by running an AIR once against a recorder.
+pub struct AirProgram {
+    raw: *mut ffi::CpAirProgram,
+}
+unsafe impl Send for AirProgram {}
+unsafe impl Sync for AirProgram {}
+
+impl AirProgram {
+    pub fn create(ctx: &Context, desc: &ffi::CpAirProgramDesc) -> Result<Self> {
+        let raw = unsafe { ffi::cp_air_program_create(ctx.raw, desc) };
+        if raw.is_null() {
+            bail!("cityprover[{}]: {}", ffi::CP_ERR_INVALID_ARG, last_error(ctx.raw));
+        }
+        Ok(Self { raw })
+    }
+
+    pub fn info(&self) -> ffi::CpAirProgramInfo {
+        let mut i: ffi::CpAirProgramInfo = unsafe { std::mem::zeroed() };
+        unsafe { ffi::cp_air_program_get_info(self.raw, &mut i) };
+        i
+    }
+
+    pub fn raw(&self) -> *mut ffi::CpAirProgram {
+        self.raw
+    }
+}
+
+impl Drop for AirProgram {
+    fn drop(&mut self) {
+        unsafe { ffi::cp_air_program_destroy(self.raw) }
+    }
+}
+
+/// starky `compute_quotient_polys` + `PolynomialBatch::from_coeffs` on the device: the program at every point of the quotient
+/// coset straight from the trace commitments, alpha-folded, / Z_H, coset iNTT, committed. Returns the quotient chunks
+/// (`alphas.len() << quotient_degree_bits` polynomials, challenge-major) as a batch for `fri_prove`.
+pub fn air_quotient_commit(ctx: &Context, program: &AirProgram, oracles: &[&PolyBatch], quotient_degree_bits: usize, publics: &[u64], globals: &[u64], challenges: &[u64], alphas: &[u64]) -> Result<PolyBatch> {
+    let os: Vec<*mut ffi::CpPolyBatch> = oracles.iter().map(|o| o.raw).collect();
+    let mut raw = ptr::null_mut();
+    check(ctx.raw, unsafe {
+        ffi::cp_air_quotient_commit(ctx.raw, program.raw, os.as_ptr(), os.len(), quotient_degree_bits as c_int, publics.as_ptr(), globals.as_ptr(), challenges.as_ptr(), alphas.as_ptr(), alphas.len(), &mut raw)
+    })?;
+    let first = oracles[0];
+    Ok(PolyBatch { raw, k: alphas.len() << quotient_degree_bits, degree_bits: first.degree_bits, rate_bits: first.rate_bits, cap_height: first.cap_height, blinding: false })
+}

@@ -142,3 +142,30 @@ def test_both_polynomial_batch_constructors_are_hooked_and_the_cpu_fallback_neve
     assert "cp_batch_device_ptrs" not in rs
     lib_rs = open(os.path.join(ROOT, "rust", "cityprover-sys", "src", "lib.rs")).read()
     assert "ffi::cp_batch_coeffs" in lib_rs
+
+
+def test_recording_parser_speaks_the_header_op_codes():
+    """rust/starkyx-patch/recording_parser.rs (uncompiled): every parser call it records maps to a CP_AIR_* code of the header, the
+    op / descriptor layouts it fills are the generated ones, and the safe wrapper it calls exists in cityprover-sys."""
+    rs = open(os.path.join(ROOT, "rust", "starkyx-patch", "recording_parser.rs")).read()
+    ffi = open(os.path.join(ROOT, "rust", "cityprover-sys", "src", "ffi.rs")).read()
+    lib_rs = open(os.path.join(ROOT, "rust", "cityprover-sys", "src", "lib.rs")).read()
+    used = set(re.findall(r"ffi::(CP_AIR_\w+)", rs))
+    assert used >= {"CP_AIR_LOCAL", "CP_AIR_NEXT", "CP_AIR_PUBLIC", "CP_AIR_GLOBAL", "CP_AIR_CHALLENGE", "CP_AIR_CONST", "CP_AIR_ADD", "CP_AIR_SUB",
+                    "CP_AIR_MUL", "CP_AIR_NEG", "CP_AIR_ASSERT_ZERO", "CP_AIR_ASSERT_ZERO_TRANSITION", "CP_AIR_ASSERT_ZERO_FIRST_ROW",
+                    "CP_AIR_ASSERT_ZERO_LAST_ROW", "CP_AIR_CONSTRAINTS"}
+    for name in used:
+        assert re.search(r"pub const %s: c_int = \d+;" % name, ffi), name
+    # the values are the header's (the Python recorder of tests/air_programs.py uses the same numbers and is run on the device)
+    hdr = open(os.path.join(ROOT, "include", "cityprover.h")).read()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import air_programs as A
+    for name, val in (("CP_AIR_LOCAL", A.LOCAL), ("CP_AIR_MUL", A.MUL), ("CP_AIR_NEG", A.NEG), ("CP_AIR_INV", A.INV), ("CP_AIR_ASSERT_ZERO_LAST_ROW", A.ASSERT_ZERO_LAST_ROW),
+                      ("CP_AIR_STORE", A.STORE)):
+        assert re.search(r"%s = %d\b" % (name, val), hdr), name
+        assert re.search(r"pub const %s: c_int = %d;" % (name, val), ffi), name
+    for field in ("kind", "ops", "n_ops", "consts", "n_consts", "n_columns", "n_public", "n_global", "n_challenge", "n_out_columns"):
+        assert re.search(r"\b%s:" % field, rs) and re.search(r"pub %s:" % field, ffi), field
+    assert "CpAirOp { op: op as u32, a, b, c: 0 }" in rs and "pub struct CpAirOp" in ffi
+    for fn in ("pub fn air_quotient_commit", "impl AirProgram", "ffi::cp_air_program_create", "ffi::cp_air_quotient_commit"):
+        assert fn in lib_rs, fn

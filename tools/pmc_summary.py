@@ -17,7 +17,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SHORT = [("k_leaf_hash_cols", "leaf_hash_cols"), ("k_levels_coop", "merkle_levels_coop"), ("k_level_coop", "merkle_level_coop"), ("k_level", "merkle_level"),
+SHORT = [("k_leaf_hash_cols", "leaf_hash_cols"), ("k_levels_coop", "merkle_levels_coop"), ("k_level_coop", "merkle_level_coop"), ("k_level_fused", "merkle_level_fused"), ("k_level", "merkle_level"),
          ("k_dif_pass16<8, 4, false", "ntt16_cols"), ("k_dif_pass16<12, 0, true", "ntt16_rows"), ("k_quot_gate", None),
          ("k_pow_grind", "fri_pow_grind")]
 
