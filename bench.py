@@ -33,8 +33,17 @@ VALU_PEAK_TLOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # = 78.6 T lane-ops/s; only an al
 # the sources that define the kernels whose PMC counters are stored under profiles/: the stored counts are used only
 # when the hash of these files is the one they were collected with (tools/pmc_summary.py writes it)
 KERNEL_SOURCES = ["gl.h", "poseidon.h", "poseidon_tables.h", "merkle.h", "ntt.h", "ntt16.h"]
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
-PMC_QBENCH_JSON = os.path.join(ROOT, "profiles", "r03_pmc_qbench.json")
+def _latest_profile(name):
+    """profiles/rNN_<name> of the latest round that has one (the counter files are re-collected when the kernels change)"""
+    for r in ("r04", "r03"):
+        p = os.path.join(ROOT, "profiles", "%s_%s" % (r, name))
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", "r04_" + name)
+
+
+PMC_JSON = _latest_profile("pmc_bench.json")
+PMC_QBENCH_JSON = _latest_profile("pmc_qbench.json")
 
 
 def permutations_per_proof():
@@ -64,7 +73,7 @@ def qbench_roofline(qb, poseidon_rate):
         import pmc_summary_qbench as P
         d = json.load(open(PMC_QBENCH_JSON))
         if d.get("kernel_source_hash") != P.source_hash():
-            out["pmc"] = "refused: profiles/r03_pmc_qbench.json is for other kernel sources (%s, now %s)" % (d.get("kernel_source_hash"), P.source_hash())
+            out["pmc"] = "refused: " + os.path.relpath(PMC_QBENCH_JSON, ROOT) + " is for other kernel sources (%s, now %s)" % (d.get("kernel_source_hash"), P.source_hash())
             return out
     except (OSError, ValueError, ImportError) as e:
         out["pmc"] = "none: %s" % e
@@ -126,13 +135,36 @@ def splitmix64_felts(seed, n):
     return z % P
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: the affinity mask, cut down to the cgroup's CPU quota when there is one (a GPU box
+    shows all 64+ logical CPUs of its host in the mask but schedules the container on a share of them: threads beyond the share
+    only take turns). Returns (usable, affinity, quota or None)."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()          # cgroup v2
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:                                                             # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    usable = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return usable, aff, quota
+
+
 def cpu_baseline(cols_host, log_n, cap_h):
     """The oracle (a port, not the Rust reference — which cannot be built offline) timed on this
     box's host cores on the same workload: ONE full step (135 NTTs of 2^20 + the Merkle cap)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
-    cores = min(len(os.sched_getaffinity(0)), 64)
+    usable, affinity, quota = host_cpu_share()
+    cores = min(usable, 64)
     L = O.lib()
     L.or_set_threads(cores)
     L.or_set_fast_poseidon(1)   # multiplier-free MDS planes, branch-free field ops: the faster form of the port
@@ -161,9 +193,12 @@ def cpu_baseline(cols_host, log_n, cap_h):
     t4 = time.perf_counter()
     L.or_set_fast_poseidon(0)
     perms = n * ((k + 7) // 8) + (n - 16)
+    all_rate, one_rate = perms / (t2 - t1), len(st) / (t4 - t3)
     return {
         "value": (t2 - t0) * 1e3 / k, "unit": "ms/NTT", "cores": cores, "kind": "port",
-        "poseidon_perms_per_s_all_cores": perms / (t2 - t1), "poseidon_perms_per_s_one_thread": len(st) / (t4 - t3),
+        "host": {"threads_used": cores, "cpus_in_affinity_mask": affinity, "cgroup_cpu_quota": quota, "nproc": os.cpu_count()},
+        "poseidon_perms_per_s_all_cores": all_rate, "poseidon_perms_per_s_one_thread": one_rate,
+        "poseidon_speedup_over_one_thread": all_rate / one_rate, "poseidon_parallel_efficiency": all_rate / one_rate / cores,
         "note": "a C restatement (scalar code: multiplier-free MDS on 32-bit planes, branch-free field ops, textbook round "
                 "structure, OpenMP over columns / leaves), NOT plonky2's AVX2 / rayon prover: no "
                 "speed-up over the reference may be read off this number (the reference cannot be built here: no Rust toolchain)",
@@ -200,10 +235,28 @@ def cpu_port_proof(prover, cores):
     want, _ = O.prove_full(osh, og, digest, c["public_inputs"], c["cs_values"], c["wires"])
     t2 = time.perf_counter()
     O.lib().or_set_threads(1)
-    O.lib().or_set_fast_poseidon(0)
     assert got == want, "GPU proof bytes != CPU oracle proof bytes"
     sec = (t2 - t1) - (t1 - t0)
-    return {"proofs_per_s": 1.0 / sec, "seconds_per_proof": sec, "cores": cores, "kind": "port",
+    # The reference scales its CPU path by running many proofs side by side (one worker process per core group,
+    # city_rollup_core_worker/src/lib.rs:131-145), not by spreading one proof over every core: N independent proofs on N threads,
+    # one thread each (the oracle's OpenMP regions run with one thread; ctypes releases the GIL), every one compared with the GPU's bytes
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one_proof(_):
+        b, _dbg = O.prove_full(osh, og, digest, c["public_inputs"], c["cs_values"], c["wires"])
+        return b
+    t3 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        many = list(ex.map(one_proof, range(cores)))
+    t4 = time.perf_counter()
+    O.lib().or_set_fast_poseidon(0)
+    assert all(b == got for b in many), "a side-by-side CPU proof differs from the GPU's bytes"
+    return {"proofs_per_s": cores / (t4 - t3), "seconds_per_proof": sec, "cores": cores, "kind": "port",
+            "proofs_per_s_one_proof_on_all_threads": 1.0 / sec,
+            "proofs_per_s_independent_proofs_one_thread_each": cores / (t4 - t3), "seconds_per_proof_on_one_thread": t4 - t3,
+            "throughput_note": "proofs_per_s = %d independent proofs on %d threads, one thread each (how the reference's worker processes scale); "
+                               "the latency figure is one proof spread over all threads (constants/sigmas commitment included in the side-by-side "
+                               "runs: +%.2f s of %.2f s each)" % (cores, cores, t1 - t0, t4 - t3),
             "sample": "1 proof of the qbench workload (n = 2^12, city-common gate set); constants/sigmas commitment "
                       "(%.2f s) subtracted: it belongs to circuit build" % (t1 - t0),
             "parity": "GPU proof bytes == oracle proof bytes (%d B)" % len(got)}
@@ -548,7 +601,7 @@ def main():
         for key in ("blocks_per_s", "proofs_per_s", "throughput_mode_proofs_per_s"):
             qb[key] = D.sum_over_ranks(dist, mine[key])
         if rank == 0 and not args.no_cpu_baseline:
-            qb["cpu_baseline"] = cpu_port_proof(prover, min(len(os.sched_getaffinity(0)), 64))
+            qb["cpu_baseline"] = cpu_port_proof(prover, min(host_cpu_share()[0], 64))
 
     # Groth16-wrap kernels, side measurement on rank 0: G1 MSM and F_r NTT at 2^20, both with a
     # correctness check inside (closed form resp. inverse round trip) — tools/bench_msm.py, tools/bench_fr_ntt.py
@@ -608,10 +661,10 @@ def main():
         # was collected with the kernel sources as they are now; the durations are this run's HIP events.
         default_shape = (k, log_n) == (COLS, LOG_N)
         pmc, pmc_refused = stored_pmc() if default_shape else ({}, "not the default workload shape")
-        # round 4: the leaf-hash workgroups also compute the first levels of their 256-leaf subtrees (csrc/merkle.h fused_levels;
-        # CITYPROVER_MERKLE_FUSE, default 3, as long as the level is at least as wide as the cooperative kernels' switch): those node
+        # round 4: the leaf-hash workgroups also compute the first level of their 256-leaf subtrees (csrc/merkle.h fused_levels;
+        # CITYPROVER_MERKLE_FUSE = 0..3, default 1: deeper measured slower, profiles/r04_merkle_fuse_matrix.jsonl): those node
         # permutations and digests are work of the SAME launch and are counted with it
-        fuse = max(0, min(3, int(os.environ.get("CITYPROVER_MERKLE_FUSE", "3"))))
+        fuse = max(0, min(3, int(os.environ.get("CITYPROVER_MERKLE_FUSE", "1"))))
         coop_max = int(os.environ.get("CITYPROVER_COOP_MAX", "16384"))
         while fuse > 0 and ((n >> fuse) < coop_max or (n >> (fuse + 0)) <= (1 << CAP_H) or n % 256):
             fuse -= 1

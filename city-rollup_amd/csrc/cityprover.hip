@@ -237,10 +237,20 @@ size_t merkle_words_per_tree(size_t n_leaves, int cap_height) {
   return nodes * 4;
 }
 
-// How many levels the leaf-hash workgroups (and the fused level kernel) compute themselves: CITYPROVER_MERKLE_FUSE = 0 (none: one
-// launch per level, the round-3 form) .. 3 (default, merkle.h fused_levels).
+// How many levels the leaf-hash workgroups (CITYPROVER_MERKLE_FUSE) and the lane-per-parent level kernel
+// (CITYPROVER_MERKLE_LEVEL_FUSE) compute on top of their own, 0 .. 3 (merkle.h fused_levels). Measured on the headline step
+// (profiles/r04_merkle_fuse_matrix.jsonl, VERDICT r3 "next" #2; ms per step, two rounds on one box): leaf 0 / 1 / 2 / 3 levels =
+// 7.98, 7.93 / 7.84, 7.86 / 7.89, 8.02 / 8.01, 8.06; the level kernel fused 1 or 2 deep 7.97-8.02. ONE fused level wins a little
+// (its 128 parents keep two of the workgroup's four waves fully busy for one permutation: 0.18 ms of separate launches become
+// 0.06-0.13 ms inside the leaf hash); deeper loses: the leaf hash runs at the issue rate of its instructions with exactly five
+// waves per SIMD, and every wave parked at the barrier of a fused level is an issue slot nobody uses (three levels: 0.92 M node
+// permutations cost 0.4-0.57 ms inside the leaf hash against 0.33 ms as launches of their own). Defaults: 1 and 0.
 int merkle_fuse_levels() {
-  static const int v = getenv("CITYPROVER_MERKLE_FUSE") ? atoi(getenv("CITYPROVER_MERKLE_FUSE")) : 3;
+  static const int v = getenv("CITYPROVER_MERKLE_FUSE") ? atoi(getenv("CITYPROVER_MERKLE_FUSE")) : 1;
+  return v < 0 ? 0 : v > 3 ? 3 : v;
+}
+int merkle_level_fuse_levels() {
+  static const int v = getenv("CITYPROVER_MERKLE_LEVEL_FUSE") ? atoi(getenv("CITYPROVER_MERKLE_LEVEL_FUSE")) : 0;
   return v < 0 ? 0 : v > 3 ? 3 : v;
 }
 // levels a 256-node workgroup may add on top of a level of `nodes` nodes: below the cap, and only whole workgroups
@@ -283,7 +293,7 @@ int merkle_levels(cp_ctx *ctx, uint64_t *D, size_t per_tree, size_t n_leaves, si
     }
     // a level that fills the chip, lane per parent: with up to three more levels by the same workgroups when they are whole and
     // stay below the cap (and those levels would not rather go to the cooperative kernels: they are at least as wide as its switch)
-    int fuse = np == cap_n ? 0 : fusable_levels(np, cap_n, merkle_fuse_levels());
+    int fuse = np == cap_n ? 0 : fusable_levels(np, cap_n, merkle_level_fuse_levels());
     while (fuse > 0 && (np >> fuse) * n_trees < coop_max) fuse--;
     if (fuse > 0) {
       const dim3 g((unsigned)(np / merkle::THREADS), (unsigned)n_trees), b(merkle::THREADS);

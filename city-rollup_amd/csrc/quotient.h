@@ -267,6 +267,110 @@ __global__ __launch_bounds__(256) void k_quot_gate(Args a, int gi, int t0) {
   gate_eval<TYPE, true>(a, gi, t0, s, proof, a.acc + proof * a.out_stride + s);
 }
 
+// THE ARITHMETIC GROUP (round 4, VERDICT r3 "next" #3). ConstantGate, PublicInputGate, ArithmeticGate, ArithmeticExtensionGate and
+// MulExtensionGate all read the FIRST wires of a row - 4, 8 and 6 wires per operation, ~80 wires each at the recursion
+// configuration - and little else: as five launches they stream the same 80 wire columns from HBM three times over (and the
+// accumulator five times). Here one lane walks the row once in windows of 24 wires (the least common multiple of 4, 8 and 6: six
+// Arithmetic operations, three ArithmeticExtension, four MulExtension per window), holds a window in registers and evaluates
+// every operation of every member gate on it. Each member keeps its own alpha-weighted sum (its selector filter multiplies the
+// sum once, as in gate_eval); the constraint indices, and therefore the alpha powers, are the gates' own - the same field
+// elements in another order of exact additions: the same bits. NC: accumulators compiled in (2 for the product's two challenges).
+struct ArithGroup { int constant, public_input, arithmetic, arithmetic_ext, mul_ext; };  // gate index of each member, -1 = not in the circuit
+GL_HD bool in_arith_group(int type) {
+  return type == gates::CONSTANT || type == gates::PUBLIC_INPUT || type == gates::ARITHMETIC || type == gates::ARITHMETIC_EXT || type == gates::MUL_EXT;
+}
+template <int NC>
+__device__ __forceinline__ void arith_group_eval(const Args &a, const ArithGroup &G, int t0, size_t s, size_t proof, uint64_t *out) {
+  const size_t N = a.N;
+  const uint64_t *cs = a.cs_lde[proof] + s;
+  const uint64_t *w = a.wires_lde + proof * a.wires_stride + s;
+  const uint64_t *apow = a.apow + proof * (size_t)a.nc * a.n_terms + t0;
+  const uint64_t *consts = cs + (size_t)a.num_selectors * N;
+  const int nc = a.nc;
+  uint64_t accA[NC], accE[NC], accM[NC], accS[NC];  // Arithmetic, ArithmeticExtension, MulExtension, the two small gates (pre-filtered)
+#pragma unroll
+  for (int c = 0; c < NC; c++) accA[c] = accE[c] = accM[c] = accS[c] = 0;
+  auto term = [&](uint64_t (&acc)[NC], uint64_t v, int idx) {
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+      if (c < nc) acc[c] = gl::mul_add_lazy(v, apow[(size_t)c * a.n_terms + idx], acc[c]);
+  };
+  auto filter_of = [&](int gi) -> uint64_t {
+    const Gate g = a.gates[gi];
+    const uint64_t sv = cs[(size_t)g.selector_index * N];
+    uint64_t f = 1;
+    for (int r = g.group_start; r < g.group_end; r++)
+      if (r != gi) f = gl::mul(f, gl::sub((uint64_t)r, sv));
+    if (a.num_selectors > 1) f = gl::mul(f, gl::sub(UNUSED_SELECTOR, sv));
+    return f;
+  };
+  const int nA = G.arithmetic >= 0 ? a.gates[G.arithmetic].param : 0, nE = G.arithmetic_ext >= 0 ? a.gates[G.arithmetic_ext].param : 0,
+            nM = G.mul_ext >= 0 ? a.gates[G.mul_ext].param : 0, nK = G.constant >= 0 ? a.gates[G.constant].param : 0;
+  const uint64_t c0 = consts[0], c1 = (G.arithmetic >= 0 || G.arithmetic_ext >= 0) ? consts[N] : 0;
+  int last = 0;  // wires the members read
+  if (4 * nA > last) last = 4 * nA;
+  if (8 * nE > last) last = 8 * nE;
+  if (6 * nM > last) last = 6 * nM;
+  if (nK > last) last = nK;
+  if (G.public_input >= 0 && last < 4) last = 4;
+  // the two small gates read the first wires only: their terms are multiplied by their filters at once and share one sum
+  if (G.constant >= 0) {
+    const uint64_t f = filter_of(G.constant);
+    for (int k = 0; k < nK; k++) term(accS, gl::mul(f, gl::sub(consts[(size_t)k * N], w[(size_t)k * N])), k);
+  }
+  if (G.public_input >= 0) {
+    const uint64_t f = filter_of(G.public_input);
+    const uint64_t *pih = a.pi_hash + proof * a.pi_stride;
+    for (int k = 0; k < 4; k++) term(accS, gl::mul(f, gl::sub(w[(size_t)k * N], pih[k])), k);
+  }
+  using gates::Alg;
+  for (int base = 0; base < last; base += 24) {
+    uint64_t x[24];
+#pragma unroll
+    for (int j = 0; j < 24; j++) x[j] = base + j < last ? w[(size_t)(base + j) * N] : 0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {  // ArithmeticGate: w3 - (w0 w1 c0 + w2 c1)
+      const int k = base / 4 + j;
+      if (k < nA) term(accA, gl::sub(x[4 * j + 3], gl::add(gl::mul(gl::mul(x[4 * j], x[4 * j + 1]), c0), gl::mul(x[4 * j + 2], c1))), k);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {  // ArithmeticExtensionGate: out - (c0 m0 m1 + c1 addend) in F[X]/(X^2 - 7)
+      const int i = base / 8 + j;
+      if (i < nE) {
+        const Alg<uint64_t> m0{x[8 * j], x[8 * j + 1]}, m1{x[8 * j + 2], x[8 * j + 3]}, ad{x[8 * j + 4], x[8 * j + 5]}, o{x[8 * j + 6], x[8 * j + 7]};
+        const Alg<uint64_t> d = gates::alg_sub(o, gates::alg_add(gates::alg_scale(gates::alg_mul(m0, m1), c0), gates::alg_scale(ad, c1)));
+        term(accE, d.a, 2 * i);
+        term(accE, d.b, 2 * i + 1);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {  // MulExtensionGate: out - c0 m0 m1
+      const int i = base / 6 + j;
+      if (i < nM) {
+        const Alg<uint64_t> m0{x[6 * j], x[6 * j + 1]}, m1{x[6 * j + 2], x[6 * j + 3]}, o{x[6 * j + 4], x[6 * j + 5]};
+        const Alg<uint64_t> d = gates::alg_sub(o, gates::alg_scale(gates::alg_mul(m0, m1), c0));
+        term(accM, d.a, 2 * i);
+        term(accM, d.b, 2 * i + 1);
+      }
+    }
+  }
+  const uint64_t fA = G.arithmetic >= 0 ? filter_of(G.arithmetic) : 0, fE = G.arithmetic_ext >= 0 ? filter_of(G.arithmetic_ext) : 0,
+                 fM = G.mul_ext >= 0 ? filter_of(G.mul_ext) : 0;
+#pragma unroll
+  for (int c = 0; c < NC; c++)
+    if (c < nc) {
+      uint64_t v = gl::add(gl::add(gl::mul(fA, accA[c]), gl::mul(fE, accE[c])), gl::add(gl::mul(fM, accM[c]), gl::canon(accS[c])));
+      out[(size_t)c * N] = gl::add(out[(size_t)c * N], v);
+    }
+}
+// grid = (N/256, B): acc[c] += every member of the arithmetic group
+template <int NC>
+__global__ __launch_bounds__(256) void k_quot_arith_group(Args a, ArithGroup G, int t0) {
+  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= a.N) return;
+  arith_group_eval<NC>(a, G, t0, s, blockIdx.y, a.acc + (size_t)blockIdx.y * a.out_stride + s);
+}
+
 // SMALL BATCHES (one or two proofs): a gate kernel of 2^15 points is 512 waves on 1 024 SIMDs, and fifteen of them in a row are
 // fifteen half-empty launches (0.67 ms of a lone proof's 3.2 ms of kernels). Here every piece of the quotient — each gate and the
 // permutation argument — is a slice of ONE grid (blockIdx.z) and writes its own slice of `parts`; k_quot_finish adds the slices.

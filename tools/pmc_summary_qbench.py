@@ -89,6 +89,8 @@ def main():
             g = k[len("k_quot_gate<"):-1]
             if g in gw:
                 alg = 8.0 * N_LDE * (gw[g] + N_CONST) + 2 * 8.0 * N_LDE * NC              # the gate's wires, selectors + constants; accumulator read + write
+        elif k.startswith("k_quot_arith_group"):   # Constant + PublicInput + Arithmetic + ArithmeticExtension + MulExtension: their ~80 first wires ONCE
+            alg = 8.0 * N_LDE * (max(gw.get(g, 0) for g in ("ARITHMETIC", "ARITHMETIC_EXT", "MUL_EXT", "CONSTANT", "PUBLIC_INPUT")) + N_CONST) + 2 * 8.0 * N_LDE * NC
         elif k == "k_quot_finish":
             alg = 2 * 8.0 * N_LDE * NC
         if alg is not None:
