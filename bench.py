@@ -730,6 +730,25 @@ def main():
                             "memory waits hidden by occupancy"}
         if roof_ntt["achieved"]:
             roof_ntt["frac"] = roof_ntt["achieved"] / HBM_PEAK_GBS
+        # The same two passes priced against VALU issue (VERDICT r3 "next" #5): wave-instructions per launch from the counter pass,
+        # this run's HIP-event durations, the shader clock rocm-smi reports while the passes run. A SIMD-32 issues a quarter-rate
+        # wave64 instruction (v_mad_u64_u32: the field product is made of them) every 4 cycles, a full-rate one every 2;
+        # tools/ubench_valu.hip measures 4.3-5.0 cycles for the VOP3 forms this mix is made of. cycles_per_instruction near 4 =
+        # the passes run at the issue rate of their instructions, whatever the HBM fraction says.
+        sclk_ntt = sorted((pw or {}).get("ntt_passes", {}).get("sclk_MHz") or [])
+        vi = {}
+        for nm, ms_ in (("ntt16_cols", cols_ms), ("ntt16_rows", rows_ms)):
+            insts = pmc.get(nm, {}).get("SQ_INSTS_VALU")
+            if insts and ms_ and sclk_ntt:
+                mhz = sclk_ntt[len(sclk_ntt) // 2]
+                cyc = ms_ * 1e-3 * mhz * 1e6 / (insts / 1024.0)
+                vi[nm] = {"valu_instructions_per_launch": insts, "valu_instructions_per_element": insts * 64.0 / (n * k),
+                          "sclk_MHz_while_running": mhz, "cycles_per_valu_instruction_per_simd": cyc, "frac_of_mix_rate": 4.0 / cyc,
+                          "lane_ops_per_s": insts * 64.0 / (ms_ * 1e-3), "frac_of_nominal_valu_peak": insts * 64.0 / (ms_ * 1e-3) / 1e12 / VALU_PEAK_TLOPS}
+        roof_ntt["valu_issue"] = vi or None
+        roof_ntt["valu_issue_note"] = ("priced against VALU issue the passes are NOT idle: frac_of_mix_rate is 4 cycles per wave64 instruction (the rate of "
+                                       "the quarter-rate multiply-adds the field product is made of) over the cycles a SIMD actually spent per instruction. A "
+                                       "10 + 10 split of the 20 stages moves no instruction out of the kernels; what would is a cheaper butterfly (DESIGN 4.3)")
         out = {
             "metric": "ms/NTT at 2^20 Goldilocks (commit-shaped step: 135-column 2^20-row NTT + Poseidon Merkle cap)",
             "value": value, "unit": "ms/NTT", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
