@@ -617,11 +617,40 @@ def main():
         f20 = bench_fr_ntt.run(prover, 20, reps=3)
         import bench_groth16
         pr20 = bench_groth16.run(prover, 20, reps=2)      # whole proof assembly: five MSMs + quotient + host part
+        # the size of a wrap: a gnark circuit that verifies a plonky2 proof is 2^24-2^25 constraints - timed AND checked
+        # against the trapdoor there too (CITYPROVER_BENCH_GROTH16_LOG overrides; 0 skips)
+        big = int(os.environ.get("CITYPROVER_BENCH_GROTH16_LOG", "24"))
+        pr_big = bench_groth16.run(prover, big, reps=1) if big > 20 else None
         g16 = {"msm_g1_2^18_ms": m18["ms"], "msm_g1_2^18_checked": m18["checked"], "msm_g1_2^20_ms": m20["ms"],
                "msm_g1_2^20_Mpoints_per_s": m20["Mpoints_per_s"], "msm_g2_2^18_ms": g2["ms"],
                "msm_g2_2^18_checked": g2["checked"], "msm_g2_2^20_ms": g2_20["ms"], "fr_ntt_2^20_forward_ms": f20["forward_ms"],
                "fr_ntt_2^20_inverse_ms": f20["inverse_ms"], "groth16_quotient_2^20_ms": f20["groth16_quotient_ms"],
                "groth16_prove_2^20_ms": pr20["prove_ms"], "groth16_prove_2^20_checked": pr20["checked"]}
+        if pr_big:
+            g16["groth16_prove_2^%d_ms" % big] = pr_big["prove_ms"]
+            g16["groth16_prove_2^%d_checked" % big] = pr_big["checked"]
+            # what fixed-base precomputation could remove (one bucket set for all windows shrinks the reduction tail, not the bucket
+            # sums): the tail's share of the kernels of the calling context's MSM chain at this size, and at 2^20
+            g16["reduction_tail_share"] = {"2^20": pr20.get("reduction_tail_share_of_main_chain"), "2^%d" % big: pr_big.get("reduction_tail_share_of_main_chain")}
+            g16["groth16_prove_2^%d_main_chain_kernels_ms" % big] = pr_big.get("main_chain_kernels_ms")
+        # the MSMs against the roof that bounds them: VALU issue of the quarter-rate multiply-add v_mad_u64_u32 (a Montgomery product
+        # of the 381-bit field is 392 of them + ~95 other instructions). Lane-operations per MSM from the counter pass of
+        # tools/profile_r04.sh (profiles/r04_pmc_msm.json), the durations of THIS run.
+        try:
+            pm = json.load(open(_latest_profile("pmc_msm.json")))
+            roof_msm = {"bound": "valu-issue (v_mad_u64_u32, quarter rate)", "unit": "T lane-ops/s",
+                        "peak": VALU_PEAK_TLOPS / 2.0,
+                        "peak_note": "1024 SIMD-32 x 64 lanes per 4 cycles at 2.4 GHz = the nominal issue rate of a quarter-rate wave64 instruction; "
+                                     "tools/ubench_valu.hip measures 31.5 T/s for a pure v_mad_u64_u32 stream (profiles/r01_ubench_valu.txt)",
+                        "measured_mad_stream_TLOPS": 31.5, "counter_source": os.path.relpath(_latest_profile("pmc_msm.json"), ROOT)}
+            for grp, ms_ in (("G1", m20["ms"]), ("G2", g2_20["ms"])):
+                lo = pm["groups"][grp]["valu_lane_ops_per_msm"]
+                ach = lo / (ms_ * 1e-3) / 1e12
+                roof_msm[grp] = {"points": 1 << 20, "ms": ms_, "valu_lane_ops_per_point": pm["groups"][grp]["valu_lane_ops_per_point"], "achieved": ach,
+                                 "frac": ach / (VALU_PEAK_TLOPS / 2.0), "frac_of_measured_mad_stream": ach / 31.5}
+            g16["msm_roofline"] = roof_msm
+        except (OSError, KeyError, ValueError) as e:
+            g16["msm_roofline"] = "no counter file for the MSM kernels: %s" % e
 
     # A13's polynomial-commitment half through the generic seams (cp_batch_commit_dev / cp_fri_prove) at the SHA-256 STARK's
     # shapes, side measurement on rank 0 with cp_fri_verify as its check — tools/bench_stark_fri.py

@@ -296,6 +296,26 @@ template <class F> GL_HD JacT<F> jac_add(const JacT<F> &p, const JacT<F> &q) {
   r.z = f_mul(f_mul(p.z, q.z), h);
   return r;
 }
+// p + q when p != q; returns false and leaves r alone when the operands are the same point (the caller doubles: keeping the
+// doubling out of this body halves its code and its live values)
+template <class F> GL_HD bool jac_add_distinct(const JacT<F> &p, const JacT<F> &q, JacT<F> &r) {
+  if (jac_is_inf(p)) { r = q; return true; }
+  if (jac_is_inf(q)) { r = p; return true; }
+  const F z1z1 = f_sqr(p.z), z2z2 = f_sqr(q.z);
+  const F u1 = f_mul(p.x, z2z2), u2 = f_mul(q.x, z1z1);
+  const F s1 = f_mul(f_mul(p.y, q.z), z2z2), s2 = f_mul(f_mul(q.y, p.z), z1z1);
+  if (f_eq(u1, u2)) {
+    if (f_eq(s1, s2)) return false;
+    r = jac_inf<F>();
+    return true;
+  }
+  const F h = f_sub(u2, u1), rr = f_sub(s2, s1);
+  const F hh = f_sqr(h), hhh = f_mul(h, hh), v = f_mul(u1, hh);
+  r.x = f_sub(f_sub(f_sqr(rr), hhh), f_dbl(v));
+  r.y = f_sub(f_mul(rr, f_sub(v, r.x)), f_mul(s1, hhh));
+  r.z = f_mul(f_mul(p.z, q.z), h);
+  return true;
+}
 // Bucket accumulators use extended Jacobian ("XYZZ") coordinates: x = X/ZZ, y = Y/ZZZ with ZZ^3 = ZZZ^2; zz = 0:
 // infinity. Adding an affine point costs 8 products + 2 squarings ("madd-2008-s") against 8 + 3 for the Jacobian
 // mixed addition, and the result goes back to Jacobian with two products: (X ZZ, Y ZZZ, ZZ).

@@ -307,24 +307,68 @@ __global__ __launch_bounds__(256) void k_heavy_combine(const uint32_t *__restric
   if (threadIdx.x == 0) buckets[hb.bucket] = part[0];
 }
 
-// grid = (segs / 64, windows), segs = nbs / seg_len: out[w][seg] = sum_{d in run} d * B[w][d]
+// Point operations on operands in memory, NOT inlined: the running-sum loop below holds two accumulators across iterations, and
+// with both additions (each carrying a doubling for the equal-points case) inlined beside them the F_p^2 instance needed 873
+// registers more than the 512 a lane has (1 664 B of scratch per lane: profiles/r03_msm_kernel_meta.csv). One addition at a time
+// fits (k_pair_reduce<Fp2>: 401 + 145 registers, no spills). dst may be one of the operands (the result is complete before it is stored).
 template <class F>
+__device__ __noinline__ void jac_double_mem(JacT<F> *dst, const JacT<F> *a) { *dst = bls::jac_double(*a); }
+template <class F>
+__device__ __noinline__ bool jac_add_distinct_mem(JacT<F> *dst, const JacT<F> *a, const JacT<F> *b) {
+  JacT<F> r;
+  if (!bls::jac_add_distinct(*a, *b, r)) return false;
+  *dst = r;
+  return true;
+}
+template <class F>
+__device__ __forceinline__ void jac_add_mem(JacT<F> *dst, const JacT<F> *a, const JacT<F> *b) {
+  if (!jac_add_distinct_mem<F>(dst, a, b)) jac_double_mem<F>(dst, a);  // the same point twice: a doubling (its own call)
+}
+
+// grid = (segs / 64, windows), segs = nbs / seg_len: out[w][seg] = sum_{d in run} d * B[w][d]
+// MEM (the F_p^2 instance): the two running sums of a lane live in LDS ([lane], 2 x 336 B x 64 lanes = 42 KB) and its multiple of
+// the run total in the lane's output slot; every point operation is a call of the two functions above.
+template <class F, bool MEM = (sizeof(JacT<F>) > 200)>
 __global__ __launch_bounds__(64) void k_segment_reduce(const JacT<F> *__restrict__ buckets, size_t nbs, uint32_t seg_len,
                                                        JacT<F> *__restrict__ out) {
   const uint32_t segs = (uint32_t)(nbs / seg_len);
   const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
-  if (seg >= segs) return;
   const int w = blockIdx.y;
   const uint32_t s = seg * seg_len;
   const JacT<F> *B = buckets + (size_t)w * nbs;
-  JacT<F> running = bls::jac_inf<F>(), acc = bls::jac_inf<F>();
-  for (int d = (int)(s + seg_len) - 1; d >= (int)s; d--) {
-    running = bls::jac_add(running, B[d]);
-    acc = bls::jac_add(acc, running);
+  if constexpr (MEM) {
+    __shared__ JacT<F> st[2][64];
+    if (seg >= segs) return;  // no barrier below: every lane works on its own slots
+    JacT<F> *running = &st[0][threadIdx.x], *acc = &st[1][threadIdx.x], *r = &out[(size_t)w * segs + seg];
+    *running = bls::jac_inf<F>();
+    *acc = bls::jac_inf<F>();
+    for (int d = (int)(s + seg_len) - 1; d >= (int)s; d--) {
+      jac_add_mem<F>(running, running, &B[d]);
+      jac_add_mem<F>(acc, acc, running);
+    }
+    // acc = sum (d - s + 1) B_d, running = T = sum B_d  ->  sum d B_d = acc + (s - 1) T
+    if (s == 0) {
+      *r = bls::jac_neg(*running);
+    } else {
+      *r = bls::jac_inf<F>();
+      const uint32_t k = s - 1;
+      for (int i = 31 - __clz(k | 1); i >= 0; i--) {  // double-and-add from the top set bit (same group element as jac_mul_small)
+        jac_double_mem<F>(r, r);
+        if ((k >> i) & 1) jac_add_mem<F>(r, r, running);
+      }
+    }
+    jac_add_mem<F>(r, acc, r);
+  } else {
+    if (seg >= segs) return;
+    JacT<F> running = bls::jac_inf<F>(), acc = bls::jac_inf<F>();
+    for (int d = (int)(s + seg_len) - 1; d >= (int)s; d--) {
+      running = bls::jac_add(running, B[d]);
+      acc = bls::jac_add(acc, running);
+    }
+    // acc = sum (d - s + 1) B_d, running = T = sum B_d  ->  sum d B_d = acc + (s - 1) T
+    const JacT<F> off = s == 0 ? bls::jac_neg(running) : bls::jac_mul_small(running, s - 1);
+    out[(size_t)w * segs + seg] = bls::jac_add(acc, off);
   }
-  // acc = sum (d - s + 1) B_d, running = T = sum B_d  ->  sum d B_d = acc + (s - 1) T
-  const JacT<F> off = s == 0 ? bls::jac_neg(running) : bls::jac_mul_small(running, s - 1);
-  out[(size_t)w * segs + seg] = bls::jac_add(acc, off);
 }
 // data[w][i] += data[w][i + half] for i + half < m   (m items left, half = ceil(m / 2); grid = (half/64, windows))
 template <class F>

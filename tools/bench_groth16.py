@@ -18,19 +18,25 @@ from bench_msm import G, G2  # noqa: E402
 R = (lambda x: x**4 - x**2 + 1)(-0xd201000000010000)   # the group order
 
 
-def limbs_sum(k, lo=0, hi=None):
+def limbs_sum(k, lo=0, hi=None, chunk=1 << 20):
     """(sum_i k_i, sum_i i * k_i) over rows lo..hi of an (n, 4) uint64 limb array, i counted from 0 at row lo — exact, in numpy:
-    32-bit half-limbs, the index split at 2^10 so that no partial sum passes 2^63"""
+    32-bit half-limbs, rows taken in chunks of 2^20 (the index inside a chunk split at 2^10) so that no partial sum passes 2^63
+    whatever n is: 2^32 * 2^10 * 2^20 = 2^62"""
     k = k[lo:hi]
-    idx = np.arange(k.shape[0], dtype=np.uint64)
-    i_lo, i_hi = idx & np.uint64(1023), idx >> np.uint64(10)
     s0 = s1 = 0
-    for j in range(4):
-        for h in range(2):
-            half = (k[:, j] >> np.uint64(32 * h)) & np.uint64(0xFFFFFFFF)
-            w = 1 << (64 * j + 32 * h)
-            s0 += int(half.sum(dtype=np.uint64)) * w
-            s1 += (int((half * i_lo).sum(dtype=np.uint64)) + (int((half * i_hi).sum(dtype=np.uint64)) << 10)) * w
+    for base in range(0, k.shape[0], chunk):
+        kc = k[base:base + chunk]
+        idx = np.arange(kc.shape[0], dtype=np.uint64)
+        i_lo, i_hi = idx & np.uint64(1023), idx >> np.uint64(10)
+        c0 = c1 = 0
+        for j in range(4):
+            for h in range(2):
+                half = (kc[:, j] >> np.uint64(32 * h)) & np.uint64(0xFFFFFFFF)
+                w = 1 << (64 * j + 32 * h)
+                c0 += int(half.sum(dtype=np.uint64)) * w
+                c1 += (int((half * i_lo).sum(dtype=np.uint64)) + (int((half * i_hi).sum(dtype=np.uint64)) << 10)) * w
+        s0 += c0
+        s1 += c1 + base * c0
     return s0, s1
 
 
@@ -81,13 +87,19 @@ def run(prover, log_n, reps=3, check=True):
     bufs = [prover.to_device(ev) for _ in range(3)]
     ts = []
     rr, ss = 12345, 67890
-    for _ in range(reps + 1):
+    kern = None
+    for it in range(reps + 1):
         for b in bufs:
             b.upload(ev)
         prover.sync()
+        if it == reps:
+            prover.profile_begin()   # the last repetition with per-kernel HIP events (the calling context's chain: A, B1, quotient, Z)
         t0 = time.perf_counter()
         A, B, C = cp.groth16_prove(prover, pk, dw.ptr, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, rr, ss)
         ts.append(time.perf_counter() - t0)
+        if it == reps:
+            prof = prover.profile_end()
+            kern = {k: round(v["total_ms"], 3) for k, v in prof.items() if k.startswith(("msm", "fr_", "groth16"))}
     checked = False
     if check:
         n_pub = n - pk.n_private
@@ -107,7 +119,10 @@ def run(prover, log_n, reps=3, check=True):
         d.free()
     for s in sets:
         s.free()
-    return {"log_constraints": log_n, "wires": n, "prove_ms": sorted(ts[1:])[len(ts[1:]) // 2] * 1e3, "checked": checked}
+    tail = sum(v for k, v in (kern or {}).items() if k in ("msm_segment_reduce", "msm_pair_reduce"))
+    allk = sum((kern or {}).values())
+    return {"log_constraints": log_n, "wires": n, "prove_ms": sorted(ts[1:])[len(ts[1:]) // 2] * 1e3, "checked": checked,
+            "main_chain_kernels_ms": kern, "reduction_tail_share_of_main_chain": tail / allk if allk else None}
 
 
 if __name__ == "__main__":

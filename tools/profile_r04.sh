@@ -40,6 +40,10 @@ python3 "$R/tools/pmc_summary_qbench.py" "$OUT/qpmc" "$OUT/r04_pmc_qbench.json" 
 # the MSM kernels at 2^20 (G1 and G2): per-kernel time beside the code-object metadata of profiles/r04_msm_kernel_meta.csv
 rocprofv3 --kernel-trace --stats -d "$OUT/trace_msm" -o msm -- python3 "$R/tools/bench_msm.py" 20 > "$OUT/r04_msm_bench.json" 2> "$OUT/trace_msm.err"
 python3 "$R/tools/rocpd_top_kernels.py" "$OUT/trace_msm" "rocprofv3 --kernel-trace --stats -- python3 tools/bench_msm.py 20" > "$OUT/r04_msm_kernel_stats.csv" || true
+# VALU instructions of the MSM kernels (the roof of the bucket method is the issue rate of v_mad_u64_u32): bench_msm.py 20 makes one
+# warm-up + three timed MSMs per group
+rocprofv3 --pmc $SQ -d "$OUT/msmpmc" -o pmc --output-format csv -- python3 "$R/tools/bench_msm.py" 20 > /dev/null 2> "$OUT/msmpmc.err" || true
+python3 "$R/tools/pmc_summary_msm.py" "$OUT/msmpmc" "$OUT/r04_pmc_msm.json" 20 4 || true
 # one proof alone: per-kernel and per-host-phase milliseconds (host transcript for a single proof, device transcript from 8 up)
 python3 "$R/tools/prove_profile_one.py" > "$OUT/r04_prove_profile_1.json" 2> "$OUT/prove_profile_1.err"
 python3 "$R/tools/bench_stark_fri.py" > "$OUT/r04_stark_commit_fri.json" 2> "$OUT/stark_fri.err" || true
