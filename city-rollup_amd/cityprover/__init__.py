@@ -29,6 +29,7 @@ ABI = {
     "cp_ctx_destroy": (None, [_vp]),
     "cp_ctx_set_lanes": (ctypes.c_int, [_vp, ctypes.c_int]),
     "cp_ctx_set_device_transcript": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "cp_ctx_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_long]),
     "cp_last_error": (ctypes.c_char_p, [_vp]),
     "cp_dev_alloc": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "cp_dev_free": (ctypes.c_int, [_vp, _vp]),
@@ -166,6 +167,10 @@ class Prover:
     def set_lanes(self, lanes):
         """internal pipelining of cp_prove_batch_host for a single-threaded caller (cp_ctx_set_lanes)"""
         self._check(self.lib.cp_ctx_set_lanes(self.ctx, int(lanes)))
+
+    def set_option(self, name, value):
+        """cp_ctx_set_option: one of the CITYPROVER_* switches for this context only"""
+        self._check(self.lib.cp_ctx_set_option(self.ctx, name.encode(), int(value)))
 
     def set_device_transcript(self, mode):
         """where the Fiat-Shamir transcripts are hashed: 1 device, 0 host, -1 by batch size (cp_ctx_set_device_transcript)"""

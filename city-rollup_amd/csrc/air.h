@@ -19,6 +19,7 @@
 #include <map>
 #include <queue>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "gl.h"
@@ -315,35 +316,63 @@ inline Compiled compile(const Program &p, uint32_t want_segments, bool prefetch 
   return C;
 }
 
+// compile-time loop over the points of a lane: indices are constants in the frontend already, so the small per-point arrays
+// (positions, flags) are scalarised into registers instead of living in scratch behind "dynamic" indices
+template <int N, class F>
+GL_HD void for_k(F f) {
+  if constexpr (N > 0) {
+    for_k<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// K points per lane: a value of the interpreter is K field elements (one per point), so that one decoded instruction - the scalar
+// work that bounds this kernel - serves K x 64 points
+template <int K>
+struct Vec { uint64_t v[K]; };
+template <int K> GL_HD Vec<K> vsplat(uint64_t x) { Vec<K> r; for (int k = 0; k < K; k++) r.v[k] = x; return r; }
+template <int K> GL_HD Vec<K> vadd(const Vec<K> &a, const Vec<K> &b) { Vec<K> r; for (int k = 0; k < K; k++) r.v[k] = gl::add(a.v[k], b.v[k]); return r; }
+template <int K> GL_HD Vec<K> vsub(const Vec<K> &a, const Vec<K> &b) { Vec<K> r; for (int k = 0; k < K; k++) r.v[k] = gl::sub(a.v[k], b.v[k]); return r; }
+template <int K> GL_HD Vec<K> vmul(const Vec<K> &a, const Vec<K> &b) { Vec<K> r; for (int k = 0; k < K; k++) r.v[k] = gl::mul(a.v[k], b.v[k]); return r; }
+template <int K> GL_HD Vec<K> vscale(const Vec<K> &a, uint64_t s) { Vec<K> r; for (int k = 0; k < K; k++) r.v[k] = gl::mul(a.v[k], s); return r; }
+template <int K> GL_HD Vec<K> vinv(const Vec<K> &a) { Vec<K> r; for (int k = 0; k < K; k++) r.v[k] = a.v[k] ? gl::inv(a.v[k]) : 0; return r; }
+
 // per-point selector values of the quotient (starky's ConstraintConsumer): z_last = x - g^(n-1), L_0(x), L_(n-1)(x)
-struct Selectors { uint64_t z_last, l_first, l_last; };
+template <int K>
+struct Selectors { Vec<K> z_last, l_first, l_last; };
 
 constexpr int MAX_ALPHAS = 4;
 
-// ---- the instruction semantics, shared by the host executor (tests/hostsim, cp_air_program_eval_ext has its own F_p^2 form)
-// and the device interpreter ----
-template <class Mem>  // Mem: code(pc), alpha(c), slot_read(i), slot_write(i, v), uni(i), local(i), next(i), store(col, v)
-GL_HD void run_segment(uint32_t first, uint32_t last, Mem &m, int n_alphas, const Selectors &sel,
-                       uint64_t *acc_out /* [MAX_ALPHAS], Horner sums of this segment */) {
-  uint64_t acc = 0;
+// ---- the instruction semantics, shared by the host executor (tests/hostsim; cp_air_program_eval_ext has its own F_p^2 form) and the
+// device interpreter ----
+template <class Mem>  // Mem: K, code(pc), alpha(c), slot_read(i), slot_write(i, v), uni(i), local(i), next(i), store(col, v)
+GL_HD void run_segment(uint32_t first, uint32_t last, Mem &m, int n_alphas, const Selectors<Mem::K> &sel,
+                       Vec<Mem::K> *acc_out /* [MAX_ALPHAS], Horner sums of this segment */) {
+  constexpr int K = Mem::K;
+  using V = Vec<K>;
+  V acc = vsplat<K>(0);
 #pragma unroll
-  for (int c = 0; c < MAX_ALPHAS; c++) acc_out[c] = 0;
+  for (int c = 0; c < MAX_ALPHAS; c++) acc_out[c] = vsplat<K>(0);
   for (uint32_t pc = first; pc < last; pc++) {
     const uint64_t w = m.code(pc);
     const uint32_t op = (uint32_t)w & 15, ka = (uint32_t)(w >> 4) & 7, kb = (uint32_t)(w >> 7) & 7, dst = (uint32_t)(w >> 10) & 0x3FFF,
                    ia = (uint32_t)(w >> 24) & 0xFFFFF, ib = (uint32_t)(w >> 44);
-    auto fetch = [&](uint32_t k, uint32_t i) -> uint64_t {
+    auto fetch = [&](uint32_t k, uint32_t i) -> V {
       switch (k) {
         case K_ACC: return acc;
         case K_SLOT: return m.slot_read(i);
-        case K_UNI: return m.uni(i);
+        case K_UNI: return vsplat<K>(m.uni(i));
         case K_LOCAL: return m.local(i);
         default: return m.next(i);
       }
     };
     if (op == I_LOAD) {
+      if constexpr (K > 1) {  // batched prefetch is a one-point-per-lane form (stark.inc keeps K = 1 when it is on): a plain load here
+        m.slot_write(dst, ka == K_NEXT ? m.next(ia) : m.local(ia));
+        continue;
+      }
       // a run of up to PREFETCH_BATCH loads: every load is issued before the first value is needed, then the slots are written
-      uint64_t v[PREFETCH_BATCH];
+      V v[PREFETCH_BATCH];
       uint32_t d[PREFETCH_BATCH];
       uint32_t r = 0;
 #pragma unroll
@@ -364,20 +393,25 @@ GL_HD void run_segment(uint32_t first, uint32_t last, Mem &m, int n_alphas, cons
       pc += r - 1;
       continue;
     }
-    const uint64_t a = fetch(ka, ia);
+    const V a = fetch(ka, ia);
     if (op == I_SINK) {
-      const uint64_t v = dst == 0 ? a : gl::mul(a, dst == 1 ? sel.z_last : dst == 2 ? sel.l_first : sel.l_last);
+      V v = a;
+      if (dst != 0) {  // element-wise selects keep the three selector vectors in registers (a select between whole structs goes through scratch)
+        V sv;
+        for (int k = 0; k < K; k++) sv.v[k] = dst == 1 ? sel.z_last.v[k] : dst == 2 ? sel.l_first.v[k] : sel.l_last.v[k];
+        v = vmul<K>(a, sv);
+      }
 #pragma unroll
       for (int c = 0; c < MAX_ALPHAS; c++)
-        if (c < n_alphas) acc_out[c] = gl::add(gl::mul(acc_out[c], m.alpha(c)), v);
+        if (c < n_alphas) acc_out[c] = vadd<K>(vscale<K>(acc_out[c], m.alpha(c)), v);
       continue;
     }
     if (op == I_STORE) { m.store(ib, a); continue; }
-    uint64_t r;
-    if (op == I_INV) r = a ? gl::inv(a) : 0;
+    V r;
+    if (op == I_INV) r = vinv<K>(a);
     else {
-      const uint64_t b = fetch(kb, ib);
-      r = op == I_ADD ? gl::add(a, b) : op == I_SUB ? gl::sub(a, b) : gl::mul(a, b);
+      const V b = fetch(kb, ib);
+      r = op == I_ADD ? vadd<K>(a, b) : op == I_SUB ? vsub<K>(a, b) : vmul<K>(a, b);
     }
     if (dst != DST_NONE) m.slot_write(dst, r);
     acc = r;
@@ -386,7 +420,7 @@ GL_HD void run_segment(uint32_t first, uint32_t last, Mem &m, int n_alphas, cons
 
 // ---- device side ----
 constexpr int WAVE = 64;
-constexpr uint32_t MAX_LDS_SLOTS = 24;  // 12 KB per one-wave workgroup (13 waves per CU); slots beyond live in global scratch (the
+constexpr uint32_t MAX_LDS_SLOTS = 24;  // x K points per lane: 512 B per slot, point and wave; slots beyond live in global scratch (the
                                         // allocator hands out the lowest free number first, so the high numbers are the long-lived, rarely touched ones)
 
 struct KArgs {
@@ -398,10 +432,10 @@ struct KArgs {
   const uint64_t *alphas;        // [n_alphas]
   const uint64_t *weights;       // [S][n_alphas]: alpha^(sinks after the segment)
   uint64_t *parts;               // quotient: [S][n_alphas][M]
-  uint64_t *spill;               // [n_slots - n_lds][S * M_padded]
+  uint64_t *spill;               // [n_slots - n_lds][S * lanes of the grid]
   uint64_t *const *out_cols;     // map: n_out_columns column base pointers
   size_t M;                      // points (quotient: n << q; map: n rows)
-  size_t spill_stride;           // S * M rounded up to whole waves
+  size_t spill_stride;           // S * (point lanes of the grid, whole waves)
   int degree_bits, n_alphas, n_lds;
 };
 
@@ -420,56 +454,87 @@ __device__ __forceinline__ const AIR_CONSTANT_AS T *constant_as(const T *p) {
   return (const AIR_CONSTANT_AS T *)p;
 }
 
+template <int KP>
 struct DevMem {
-  uint64_t *lds;  // this wave's slots, [slot][lane]
+  static constexpr int K = KP;
+  uint64_t *lds;  // this wave's slots, [slot][point of the lane][lane]
   const KArgs &a;
-  size_t pos, npos, gid;
+  size_t pos[KP], npos[KP], gid[KP];
+  bool active[KP];
   int lane;
   __device__ __forceinline__ uint64_t code(uint32_t pc) const { return constant_as(a.code)[pc]; }
   __device__ __forceinline__ uint64_t alpha(int c) const { return constant_as(a.alphas)[c]; }
-  __device__ __forceinline__ uint64_t slot_read(uint32_t i) const {
-    return (int)i < a.n_lds ? lds[i * WAVE + lane] : a.spill[(size_t)(i - a.n_lds) * a.spill_stride + gid];
+  __device__ __forceinline__ Vec<KP> slot_read(uint32_t i) const {
+    Vec<KP> r;
+    if ((int)i < a.n_lds) for_k<KP>([&](auto k) { r.v[k] = lds[(i * KP + k) * WAVE + lane]; });
+    else for_k<KP>([&](auto k) { r.v[k] = a.spill[(size_t)(i - a.n_lds) * a.spill_stride + gid[k]]; });
+    return r;
   }
-  __device__ __forceinline__ void slot_write(uint32_t i, uint64_t v) const {
-    if ((int)i < a.n_lds) lds[i * WAVE + lane] = v;
-    else a.spill[(size_t)(i - a.n_lds) * a.spill_stride + gid] = v;
+  __device__ __forceinline__ void slot_write(uint32_t i, const Vec<KP> &v) const {
+    if ((int)i < a.n_lds) for_k<KP>([&](auto k) { lds[(i * KP + k) * WAVE + lane] = v.v[k]; });
+    else for_k<KP>([&](auto k) { a.spill[(size_t)(i - a.n_lds) * a.spill_stride + gid[k]] = v.v[k]; });
   }
   __device__ __forceinline__ uint64_t uni(uint32_t i) const { return constant_as(a.uni)[i]; }
-  __device__ __forceinline__ uint64_t local(uint32_t i) const { return ((const uint64_t *)constant_as(a.cols)[i])[pos]; }
-  __device__ __forceinline__ uint64_t next(uint32_t i) const { return ((const uint64_t *)constant_as(a.cols)[i])[npos]; }
-  __device__ __forceinline__ void store(uint32_t col, uint64_t v) const {
-    if (pos < a.M) ((uint64_t *)constant_as(a.out_cols)[col])[pos] = v;
+  __device__ __forceinline__ Vec<KP> local(uint32_t i) const {
+    const uint64_t *c = (const uint64_t *)constant_as(a.cols)[i];
+    Vec<KP> r;
+    for_k<KP>([&](auto k) { r.v[k] = c[pos[k]]; });
+    return r;
+  }
+  __device__ __forceinline__ Vec<KP> next(uint32_t i) const {
+    const uint64_t *c = (const uint64_t *)constant_as(a.cols)[i];
+    Vec<KP> r;
+    for_k<KP>([&](auto k) { r.v[k] = c[npos[k]]; });
+    return r;
+  }
+  __device__ __forceinline__ void store(uint32_t col, const Vec<KP> &v) const {
+    uint64_t *c = (uint64_t *)constant_as(a.out_cols)[col];
+    for_k<KP>([&](auto k) {
+      if (active[k]) c[pos[k]] = v.v[k];
+    });
   }
 };
 
-// MODE 0: quotient (points in storage order: pos = [coset block][bit-reversed row]); MODE 1: map (pos = row, natural order)
-template <int MODE>
+// MODE 0: quotient (points in storage order: pos = [coset block][bit-reversed row]); MODE 1: map (pos = row, natural order).
+// A lane works on KP points, 64 apart: the wave covers KP * 64 consecutive points.
+template <int MODE, int KP>
 __global__ __launch_bounds__(WAVE) void k_run(KArgs a) {
   extern __shared__ uint64_t lds[];
   const int lane = threadIdx.x;
-  const size_t p0 = (size_t)blockIdx.x * WAVE + lane;
-  const bool active = p0 < a.M;
-  const size_t pos = active ? p0 : a.M - 1;  // idle lanes of a short grid shadow the last point (loads stay in bounds)
   const uint32_t seg = blockIdx.y;
-  size_t npos;
-  if (MODE == 0) {
-    const size_t n = (size_t)1 << a.degree_bits;
-    const uint32_t q = (uint32_t)(pos & (n - 1));
-    const uint32_t r = a.degree_bits ? __brev(q) >> (32 - a.degree_bits) : 0;
-    const uint32_t r1 = (r + 1) & (uint32_t)(n - 1);
-    npos = (pos & ~(n - 1)) | (a.degree_bits ? __brev(r1) >> (32 - a.degree_bits) : 0);
-  } else {
-    npos = pos + 1 == a.M ? 0 : pos + 1;
-  }
-  DevMem m{lds, a, pos, npos, (size_t)seg * gridDim.x * WAVE + p0, lane};
-  Selectors sel{0, 0, 0};
-  if (MODE == 0) sel = Selectors{a.sel[pos], a.sel[a.M + pos], a.sel[2 * a.M + pos]};
-  uint64_t acc[MAX_ALPHAS];
+  DevMem<KP> m{lds, a, {}, {}, {}, {}, lane};
+  Selectors<KP> sel;
+  for_k<KP>([&](auto k) {
+    const size_t p0 = ((size_t)blockIdx.x * KP + k) * WAVE + lane;
+    m.active[k] = p0 < a.M;
+    const size_t pos = m.active[k] ? p0 : a.M - 1;  // idle lanes of a short grid shadow the last point (loads stay in bounds)
+    m.pos[k] = pos;
+    m.gid[k] = ((size_t)seg * gridDim.x * KP + (size_t)blockIdx.x * KP + k) * WAVE + lane;
+    if (MODE == 0) {
+      const size_t n = (size_t)1 << a.degree_bits;
+      const uint32_t q = (uint32_t)(pos & (n - 1));
+      const uint32_t r = a.degree_bits ? __brev(q) >> (32 - a.degree_bits) : 0;
+      const uint32_t r1 = (r + 1) & (uint32_t)(n - 1);
+      m.npos[k] = (pos & ~(n - 1)) | (a.degree_bits ? __brev(r1) >> (32 - a.degree_bits) : 0);
+      sel.z_last.v[k] = a.sel[pos];
+      sel.l_first.v[k] = a.sel[a.M + pos];
+      sel.l_last.v[k] = a.sel[2 * a.M + pos];
+    } else {
+      m.npos[k] = pos + 1 == a.M ? 0 : pos + 1;
+      sel.z_last.v[k] = sel.l_first.v[k] = sel.l_last.v[k] = 0;
+    }
+  });
+  Vec<KP> acc[MAX_ALPHAS];
   run_segment(constant_as(a.seg_off)[seg], constant_as(a.seg_off)[seg + 1], m, MODE == 0 ? a.n_alphas : 0, sel, acc);
-  if (MODE == 0 && active) {
+  if (MODE == 0) {
 #pragma unroll
     for (int c = 0; c < MAX_ALPHAS; c++)
-      if (c < a.n_alphas) a.parts[((size_t)seg * a.n_alphas + c) * a.M + pos] = gl::mul(acc[c], constant_as(a.weights)[seg * a.n_alphas + c]);
+      if (c < a.n_alphas) {
+        const uint64_t wgt = constant_as(a.weights)[seg * a.n_alphas + c];
+        for_k<KP>([&](auto k) {
+          if (m.active[k]) a.parts[((size_t)seg * a.n_alphas + c) * a.M + m.pos[k]] = gl::mul(acc[c].v[k], wgt);
+        });
+      }
   }
 }
 

@@ -174,7 +174,7 @@ int run_dif(cp_ctx *ctx, uint64_t *data, int log_n, size_t batch, size_t stride,
     a.block_stride = ex.block_stride;
     a.block_bits = ex.block_bits;
     a.natural_out = ex.natural_out ? 1 : 0;
-    static const int staged = getenv("CITYPROVER_NTT_STAGED_STORE") ? atoi(getenv("CITYPROVER_NTT_STAGED_STORE")) : 1;
+    const int staged = (int)CP_KNOB(ctx, "NTT_STAGED_STORE", 1);
     a.staged_store = (staged && q_after == 0 && log_n >= 16) ? 1 : 0;
     dim3 grid((unsigned)(((size_t)1 << outer_bits) >> c), (unsigned)batch, (unsigned)ex.n_blocks);
     bool done = false;
@@ -245,12 +245,12 @@ size_t merkle_words_per_tree(size_t n_leaves, int cap_height) {
 // 0.06-0.13 ms inside the leaf hash); deeper loses: the leaf hash runs at the issue rate of its instructions with exactly five
 // waves per SIMD, and every wave parked at the barrier of a fused level is an issue slot nobody uses (three levels: 0.92 M node
 // permutations cost 0.4-0.57 ms inside the leaf hash against 0.33 ms as launches of their own). Defaults: 1 and 0.
-int merkle_fuse_levels() {
-  static const int v = getenv("CITYPROVER_MERKLE_FUSE") ? atoi(getenv("CITYPROVER_MERKLE_FUSE")) : 1;
+int merkle_fuse_levels(cp_ctx *ctx) {
+  const int v = (int)CP_KNOB(ctx, "MERKLE_FUSE", 1);
   return v < 0 ? 0 : v > 3 ? 3 : v;
 }
-int merkle_level_fuse_levels() {
-  static const int v = getenv("CITYPROVER_MERKLE_LEVEL_FUSE") ? atoi(getenv("CITYPROVER_MERKLE_LEVEL_FUSE")) : 0;
+int merkle_level_fuse_levels(cp_ctx *ctx) {
+  const int v = (int)CP_KNOB(ctx, "MERKLE_LEVEL_FUSE", 0);
   return v < 0 ? 0 : v > 3 ? 3 : v;
 }
 // levels a 256-node workgroup may add on top of a level of `nodes` nodes: below the cap, and only whole workgroups
@@ -277,8 +277,8 @@ int merkle_levels(cp_ctx *ctx, uint64_t *D, size_t per_tree, size_t n_leaves, si
     else { parent = D + off + n * 4; pstride = per_tree; }
     // a launch that cannot fill the chip is bound by the latency of ONE permutation: twelve lanes per state then
     // (poseidon_coop.h); lane-per-state otherwise. CITYPROVER_COOP_MAX overrides the switch (0 = never) for measurements.
-    static const size_t coop_max = getenv("CITYPROVER_COOP_MAX") ? strtoull(getenv("CITYPROVER_COOP_MAX"), nullptr, 10) : 16384;
-    static const int fuse_max = getenv("CITYPROVER_COOP_FUSE") ? atoi(getenv("CITYPROVER_COOP_FUSE")) : pcoop::MAX_FUSED;
+    const size_t coop_max = (size_t)CP_KNOB(ctx, "COOP_MAX", 16384);
+    const int fuse_max = (int)CP_KNOB(ctx, "COOP_FUSE", pcoop::MAX_FUSED);
     if (np * n_trees <= coop_max && fuse_max >= 1) {
       // ... and several such levels go into one launch (a workgroup walks a whole subtree): everything up to the cap
       while (n > cap_n) {
@@ -293,7 +293,7 @@ int merkle_levels(cp_ctx *ctx, uint64_t *D, size_t per_tree, size_t n_leaves, si
     }
     // a level that fills the chip, lane per parent: with up to three more levels by the same workgroups when they are whole and
     // stay below the cap (and those levels would not rather go to the cooperative kernels: they are at least as wide as its switch)
-    int fuse = np == cap_n ? 0 : fusable_levels(np, cap_n, merkle_level_fuse_levels());
+    int fuse = np == cap_n ? 0 : fusable_levels(np, cap_n, merkle_level_fuse_levels(ctx));
     while (fuse > 0 && (np >> fuse) * n_trees < coop_max) fuse--;
     if (fuse > 0) {
       const dim3 g((unsigned)(np / merkle::THREADS), (unsigned)n_trees), b(merkle::THREADS);
@@ -333,7 +333,7 @@ int merkle_cols_batch(cp_ctx *ctx, const uint64_t *cols, size_t n_leaves, size_t
   const dim3 grid(blocks_for(n_leaves, merkle::THREADS), (unsigned)n_trees), block(merkle::THREADS);
   // a few thousand leaves: the launch is bound by the latency of one lane's chain of permutations — twelve lanes per leaf then
   // (poseidon_coop.h; CITYPROVER_COOP_LEAF_MAX = largest number of leaves over all trees that takes this form, 0 = never)
-  static const size_t coop_leaf_max = getenv("CITYPROVER_COOP_LEAF_MAX") ? strtoull(getenv("CITYPROVER_COOP_LEAF_MAX"), nullptr, 10) : 8192;
+  const size_t coop_leaf_max = (size_t)CP_KNOB(ctx, "COOP_LEAF_MAX", 8192);
   const bool salted = salt && n_salt > 0;
   if (n_leaves * n_trees <= coop_leaf_max && leaf_len + (salted ? (size_t)n_salt : 0) > 4) {
     const dim3 cgrid(blocks_for(n_leaves, pcoop::STATES_PER_BLOCK), (unsigned)n_trees);
@@ -347,8 +347,8 @@ int merkle_cols_batch(cp_ctx *ctx, const uint64_t *cols, size_t n_leaves, size_t
   }
   // the first levels by the leaf-hash workgroups themselves (merkle.h fused_levels) when the levels they would write are wide
   // enough to belong to the lane-per-parent kernel anyway
-  static const size_t coop_max = getenv("CITYPROVER_COOP_MAX") ? strtoull(getenv("CITYPROVER_COOP_MAX"), nullptr, 10) : 16384;
-  int fuse = fusable_levels(n_leaves, (size_t)1 << cap_height, merkle_fuse_levels());
+  const size_t coop_max = (size_t)CP_KNOB(ctx, "COOP_MAX", 16384);
+  int fuse = fusable_levels(n_leaves, (size_t)1 << cap_height, merkle_fuse_levels(ctx));
   while (fuse > 0 && (n_leaves >> fuse) * n_trees < coop_max) fuse--;
 #define CP_LEAF_LAUNCH(SALTED, F, SP, NS, SS)                                                                                          \
   LAUNCH(ctx, "leaf_hash_cols", (merkle::k_leaf_hash_cols<SALTED, F>), grid, block, cols, n_leaves, (int)leaf_len, col_stride, D, \
@@ -473,6 +473,19 @@ int cp_ctx_set_lanes(cp_ctx *ctx, int lanes) try {
     ctx->lanes.push_back(lane);
   }
   ctx->n_lanes = lanes;
+  return CP_OK;
+} CP_CATCH(ctx)
+
+int cp_ctx_set_option(cp_ctx *ctx, const char *name, long value) try {
+  CHECK_CTX(ctx);
+  if (!name) return set_error(ctx, CP_ERR_INVALID_ARG, "NULL argument");
+  if (ctx->parent) return set_error(ctx, CP_ERR_INVALID_ARG, "a lane takes its options from its parent");
+  bool known = false;
+  for (const char *const *k = knob_names(); *k; k++) known = known || strcmp(*k, name) == 0;
+  if (!known) return set_error(ctx, CP_ERR_INVALID_ARG, "unknown option \"%s\" (see INTEGRATION.md section 5b)", name);
+  for (auto &kv : ctx->options)
+    if (kv.first == name) { kv.second = value; return CP_OK; }
+  ctx->options.emplace_back(name, value);
   return CP_OK;
 } CP_CATCH(ctx)
 

@@ -78,6 +78,12 @@ int cp_ctx_set_lanes(cp_ctx *ctx, int lanes);
  * -1 (default): by batch size (device from EIGHT proofs per batch up). Same proof bytes in every
  * mode. Lanes inherit the setting. */
 int cp_ctx_set_device_transcript(cp_ctx *ctx, int mode);
+/* One of the library's measurement switches for THIS context (and its lanes) instead of process-wide: `name` is the part after
+ * CITYPROVER_ of the environment variables INTEGRATION.md section 5b lists (DEVICE_TRANSCRIPT, QUOT_ALL_MAX, QUOT_FLIP, QUOT_GROUP,
+ * QUOT_TILE, COOP_MAX, COOP_FUSE, COOP_LEAF_MAX, COOP_FRI_MAX, MERKLE_FUSE, MERKLE_LEVEL_FUSE, NTT_STAGED_STORE, AIR_TARGET_WAVES,
+ * AIR_LDS_SLOTS, AIR_POINTS_PER_LANE). Order of precedence: this call, the environment variable (read once per process), the
+ * built-in default. The switches select among forms that give the same bytes; two contexts of one process may differ. */
+int cp_ctx_set_option(cp_ctx *ctx, const char *name, long value);
 /* last error message of `ctx`, or of the calling thread when ctx == NULL. Never NULL. */
 const char *cp_last_error(cp_ctx *ctx);
 /* Fault injection for tests of the error paths (the reference has none; a backend that lives inside

@@ -274,18 +274,19 @@ int hs_pool_script(size_t n_devices, size_t pool_cap, size_t capacity, const int
 #include "../../city-rollup_amd/csrc/ext3.h"
 namespace airsim {
 struct HostMem {
+  static constexpr int K = 1;
   std::vector<uint64_t> slots;
   const uint64_t *u, *loc, *nxt;
   uint64_t *out;
   const uint64_t *prog, *al;
   uint64_t code(uint32_t pc) const { return prog[pc]; }
   uint64_t alpha(int c) const { return al[c]; }
-  uint64_t slot_read(uint32_t i) const { return slots[i]; }
-  void slot_write(uint32_t i, uint64_t v) { slots[i] = v; }
+  air::Vec<1> slot_read(uint32_t i) const { return {{slots[i]}}; }
+  void slot_write(uint32_t i, const air::Vec<1> &v) { slots[i] = v.v[0]; }
   uint64_t uni(uint32_t i) const { return u[i]; }
-  uint64_t local(uint32_t i) const { return loc[i]; }
-  uint64_t next(uint32_t i) const { return nxt[i]; }
-  void store(uint32_t col, uint64_t v) { out[col] = v; }
+  air::Vec<1> local(uint32_t i) const { return {{loc[i]}}; }
+  air::Vec<1> next(uint32_t i) const { return {{nxt[i]}}; }
+  void store(uint32_t col, const air::Vec<1> &v) { out[col] = v.v[0]; }
 };
 }  // namespace airsim
 extern "C" {
@@ -310,13 +311,13 @@ int hs_air_point(int kind, const uint32_t *ops, size_t n_ops, const uint64_t *co
   uni.insert(uni.end(), challenges, challenges + P.n_challenge);
   uni.push_back(0);
   airsim::HostMem m{std::vector<uint64_t>(C.n_slots ? C.n_slots : 1, 0xDEADBEEFull), uni.data(), local, next, stores_out, C.code.data(), alphas};
-  const air::Selectors S{sel[0], sel[1], sel[2]};
+  const air::Selectors<1> S{{{sel[0]}}, {{sel[1]}}, {{sel[2]}}};
   for (int c = 0; c < n_alphas; c++) acc_out[c] = 0;
   for (uint32_t s = 0; s < C.n_segments(); s++) {
-    uint64_t acc[air::MAX_ALPHAS];
+    air::Vec<1> acc[air::MAX_ALPHAS];
     std::fill(m.slots.begin(), m.slots.end(), 0xDEADBEEFull);  // a segment must not read what another one left
     air::run_segment(C.seg_off[s], C.seg_off[s + 1], m, kind == 0 ? n_alphas : 0, S, acc);
-    for (int c = 0; c < n_alphas; c++) acc_out[c] = gl::add(acc_out[c], gl::mul(acc[c], gl::pow(alphas[c], C.sinks_after[s])));
+    for (int c = 0; c < n_alphas; c++) acc_out[c] = gl::add(acc_out[c], gl::mul(acc[c].v[0], gl::pow(alphas[c], C.sinks_after[s])));
   }
   info_out[0] = C.n_segments(); info_out[1] = C.n_slots; info_out[2] = (uint32_t)C.code.size(); info_out[3] = (uint32_t)P.n_live; info_out[4] = P.max_degree;
   return 0;

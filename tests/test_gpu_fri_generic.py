@@ -185,6 +185,31 @@ def test_twin_on_demand_of_a_cpu_committed_oracle(prover):
         host.close()
 
 
+def test_switches_are_per_context_and_give_the_same_bytes(prover):
+    """cp_ctx_set_option (the CITYPROVER_* switches used to be process-wide statics): a second context of the
+    same process with other forms selected - leaves hashed twelve lanes per leaf never / always, no fused Merkle level, other
+    cooperative-level switches - commits the same caps and proves the same FRI bytes as the first, which keeps its defaults."""
+    import cityprover
+    p2 = cityprover.Prover(0)
+    try:
+        with pytest.raises(cityprover.CityProverError, match="unknown option"):
+            p2.set_option("NO_SUCH_SWITCH", 1)
+        for name, v in (("COOP_LEAF_MAX", 0), ("MERKLE_FUSE", 0), ("COOP_MAX", 64), ("COOP_FRI_MAX", 1 << 20), ("COOP_FUSE", 2), ("DEVICE_TRANSCRIPT", 1)):
+            p2.set_option(name, v)
+        for seed in (1, 6, 11):
+            spec = F.random_instance(seed, degree_bits=10 if seed == 11 else None)
+            a = F.run_instance(F.GpuBackend(prover), spec)
+            b = F.run_instance(F.GpuBackend(p2), spec)
+            assert [c.tolist() for c in a["caps"]] == [c.tolist() for c in b["caps"]]
+            assert a["proof"] == b["proof"] and a["state_after"] == b["state_after"]
+        p2.set_option("COOP_LEAF_MAX", 1 << 30)          # and the other way round: twelve lanes per leaf always
+        p2.set_option("MERKLE_FUSE", 3)
+        spec = F.random_instance(4, degree_bits=9)
+        assert F.run_instance(F.GpuBackend(prover), spec)["proof"] == F.run_instance(F.GpuBackend(p2), spec)["proof"]
+    finally:
+        p2.close()
+
+
 N_RANDOM = int(os.environ.get("CITY_RANDOM_FRI", "40"))
 
 
