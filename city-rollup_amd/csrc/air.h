@@ -420,8 +420,12 @@ GL_HD void run_segment(uint32_t first, uint32_t last, Mem &m, int n_alphas, cons
 
 // ---- device side ----
 constexpr int WAVE = 64;
-constexpr uint32_t MAX_LDS_SLOTS = 24;  // x K points per lane: 512 B per slot, point and wave; slots beyond live in global scratch (the
-                                        // allocator hands out the lowest free number first, so the high numbers are the long-lived, rarely touched ones)
+constexpr uint32_t MAX_LDS_SLOTS = 10;  // x K points per lane: 512 B per slot, point and wave (10 KB per wave at K = 2: sixteen waves per
+                                        // CU); slots beyond live in global scratch (the allocator hands out the lowest free number first, so
+                                        // the high numbers are the long-lived, rarely touched ones). Measured: profiles/r04_air_ab3.jsonl -
+                                        // the launch is bound by the latency of its dependent scalar-load -> vector-load -> LDS chains, and
+                                        // resident waves are what hides it: 4 / 6 / 8 / 10 / 12 slots at two points per lane = 2.23 / 2.04 /
+                                        // 1.93 / 1.88 / 2.32 ms at 2^16 rows (24 slots, one point: 3.09)
 
 struct KArgs {
   const uint64_t *code;
