@@ -53,6 +53,37 @@ def test_gate_set_proofs_byte_identical(prover, name, gate_set, db, arity):
     dw.free(); circ.close()
 
 
+@pytest.mark.parametrize("options", [dict(QUOT_ALL_MAX=0), dict(QUOT_ALL_MAX=0, QUOT_GROUP=0), dict(QUOT_ALL_MAX=0, QUOT_TILE=1),
+                                     dict(QUOT_ALL_MAX=0, QUOT_FLIP=0, QUOT_TILE=1, QUOT_GROUP=0), dict(QUOT_ALL_MAX=100)])
+def test_every_form_of_the_quotient_gives_the_same_bytes(options):
+    """The quotient has four forms, chosen by batch size and switches: every piece a slice of one grid (small batches), a launch per
+    gate, the arithmetic family grouped into one launch (round 4, default for batches that fill the chip), and a workgroup per
+    64-point tile with the wires staged in LDS once (round 4, off by default). cp_ctx_set_option forces each on a context of its
+    own; a circuit with all 22 gate types and one with the city-common set must prove to the oracle's bytes under every one."""
+    import cityprover as cp
+    p = cp.Prover(0)
+    try:
+        for name, v in options.items():
+            p.set_option(name, v)
+        for gate_set, db in ((SG.ALL_GATES, 6), (SG.CITY_COMMON, 7)):
+            c = SG.build_gate_set(gate_set, db=db, seed=31 + db, arity_bits=(2,))
+            sh = cp_shape_of(cp, c["shape"])
+            digest = [5, 5, 5, db]
+            circ = cp.Circuit(p, sh, digest, c["cs_values"])
+            cp.set_gates(circ, c["gate_list"], c["num_selectors"])
+            O.lib().or_set_threads(8)
+            try:
+                want, _ = O.prove_full(c["shape"], c["gates"], digest, c["public_inputs"], c["cs_values"], c["wires"])
+            finally:
+                O.lib().or_set_threads(1)
+            for B in (1, 3):
+                got = cp.prove_batch(p, [circ] * B, [c["public_inputs"]] * B, [c["wires"]] * B)
+                assert all(g == want for g in got), (options, B)
+            circ.close()
+    finally:
+        p.close()
+
+
 def test_set_gates_parameter_validation(prover):
     import cityprover as cp
     c = SG.build_gate_set(SG.CITY_COMMON, db=6, seed=1, arity_bits=(2,))
