@@ -457,6 +457,7 @@ void cp_ctx_destroy(cp_ctx *ctx) {
     if (t.tab) hipFree(t.tab);
   if (ctx->msm_ws) hipFree(ctx->msm_ws);
   if (ctx->pin) hipHostFree(ctx->pin);
+  if (ctx->noncanonical_flag) hipHostFree(ctx->noncanonical_flag);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -535,6 +536,34 @@ int cp_h2d(cp_ctx *ctx, void *dst, const void *src, size_t bytes) try {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return CP_OK;
 } CP_CATCH(ctx)
+}  // extern "C"
+// Field elements that arrive from the host must be canonical (< p). Scanning 2^16 rows x 418 columns on one host core took 7 ms
+// of a 34 ms STARK proof (tools/stark_upload_probe.py); the same scan on the device, behind the upload, is lost in the noise. The
+// kernel sets a page-locked word; the caller reads it after the next synchronisation of the stream it already needs (the cap
+// download of a commitment) and only then looks for the offending index on the host, for the error message.
+__global__ __launch_bounds__(256) void k_flag_noncanonical(const uint64_t *__restrict__ v, size_t n, uint32_t *__restrict__ flag) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) bad |= v[i] >= gl::P;
+  if (bad) *flag = 1;
+}
+// enqueue the scan of v[0, n) (device memory) on the context's stream; the flag accumulates over several calls until it is read
+int canonical_check_enqueue(cp_ctx *ctx, const uint64_t *v_dev, size_t n, bool reset) {
+  if (!ctx->noncanonical_flag) {
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->noncanonical_flag, 64, hipHostMallocDefault));
+    *ctx->noncanonical_flag = 0;
+  }
+  if (reset) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // no earlier scan may still be writing
+    __atomic_store_n(ctx->noncanonical_flag, 0u, __ATOMIC_SEQ_CST);
+  }
+  if (n == 0) return CP_OK;
+  const size_t blocks = std::min<size_t>(blocks_for(n, 256), 4096);
+  LAUNCH(ctx, "canonical_check", k_flag_noncanonical, dim3((unsigned)blocks), dim3(256), v_dev, n, ctx->noncanonical_flag);
+  return CP_OK;
+}
+// after the stream has been synchronised: did any scan since the last reset meet an element >= p?
+bool canonical_check_failed(cp_ctx *ctx) { return ctx->noncanonical_flag && __atomic_load_n(ctx->noncanonical_flag, __ATOMIC_SEQ_CST) != 0; }
+extern "C" {
 int cp_d2h(cp_ctx *ctx, void *dst, const void *src, size_t bytes) try {
   CHECK_CTX(ctx);
   if (bytes == 0) return CP_OK;

@@ -96,6 +96,9 @@ struct cp_ctx {
   // valid, the handle can then only be destroyed), so that the order of the two destroy calls does not matter
   std::mutex batches_m;
   std::vector<struct cp_poly_batch *> live_batches;
+  // page-locked word a kernel sets when it meets a field element >= p in an array that came from the host (canonical_check_*
+  // in cityprover.hip): the scan runs on the device behind the upload instead of on one host core in front of it
+  uint32_t *noncanonical_flag = nullptr;
   // cp_ctx_set_option: per-context values of the measurement switches (a lane asks its parent); empty = the process-wide
   // CITYPROVER_<NAME> environment variable, else the built-in default
   std::vector<std::pair<std::string, long>> options;

@@ -227,6 +227,20 @@ def test_toy_air_with_a_lookup_end_to_end(prover, db, device_transcript):
         oc = O.challenger_new()
         gc = cityprover.ChallengerState()
         assert cityprover.stark_prove(prover, gd, trace, gc, pow_override=77) == O.stark_prove(od, trace, oc, pow_override=77)
+        # a trace element >= p (the scan runs on the device, behind the upload): refused, the transcript untouched, and the next
+        # call with a good trace gives the same bytes as before (the flag does not stick)
+        for where in ((0, 0), (A.LOOKUP_K0 - 1, (1 << db) - 1)):
+            badt = np.array(trace, dtype=np.uint64, copy=True)
+            badt[where] = O.P + 5
+            gc3 = cityprover.ChallengerState()
+            gc3.observe([1, 2, 3, 4, 5])
+            before = gc3.as_tuple()
+            with pytest.raises(cityprover.CityProverError, match="not canonical"):
+                cityprover.stark_prove(prover, gd, badt, gc3)
+            assert gc3.as_tuple() == before
+        gc = cityprover.ChallengerState()
+        gc.observe([1, 2, 3, 4, 5])
+        assert cityprover.stark_prove(prover, gd, trace, gc) == want
     finally:
         prover.set_device_transcript(-1)
         for g in progs:

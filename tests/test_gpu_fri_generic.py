@@ -77,6 +77,19 @@ def test_batch_commit_refuses_bad_arguments(prover):
         cityprover.PolyBatch(prover, bad, 1, 2)
     with pytest.raises(cityprover.CityProverError, match="cap_height"):
         cityprover.PolyBatch(prover, ok, 1, 9)
+    # the scan for elements >= p runs on the device behind the upload: the message still names the element, the last element of the
+    # last polynomial is seen, a bad salt is seen, and the flag does not stick to the next call
+    for r, c in ((0, 0), (3, 15)):
+        bad = ok.copy()
+        bad[r, c] = 2**64 - 1
+        with pytest.raises(cityprover.CityProverError, match="polynomial element %d is not canonical" % (16 * r + c)):
+            cityprover.PolyBatch(prover, bad, 1, 2)
+    salts = O.splitmix64_felts(2, 4 * 32).reshape(4, 32)
+    bs = salts.copy()
+    bs[3, 31] = O.P
+    with pytest.raises(cityprover.CityProverError, match="salt element 127 is not canonical"):
+        cityprover.PolyBatch(prover, ok, 1, 2, salts=bs)
+    cityprover.PolyBatch(prover, ok, 1, 2, salts=salts).close()
     b = cityprover.PolyBatch(prover, ok, 1, 2)
     with pytest.raises(cityprover.CityProverError, match="out of range"):
         b.eval_ext(np.array([3, 0], dtype=np.uint64), 2, 3)
