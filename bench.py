@@ -663,11 +663,13 @@ def main():
     # A13's own two steps on the generic device machinery (cp_air_quotient_commit / cp_stark_prove: a recorded constraint program
     # of >= 10^4 ops at the SHA-256 STARK's width evaluated on the quotient coset straight from the committed traces; the whole
     # prover with its extended columns filled on the device) - tools/bench_stark_air.py; tests/test_gpu_air.py holds the bytes
-    stark_air = None
+    stark_air = stark_sha = None
     if rank == 0 and not args.no_qbench:
         import bench_stark_air
         stark_air = {"2^10": bench_stark_air.run(prover, 10, reps=3), "2^14": bench_stark_air.run(prover, 14, reps=3),
                      "2^16": bench_stark_air.run(prover, 16, reps=2)}
+        # ... and a SATISFIED AIR through the same prover, verified in full: SHA-256 of a 2^k / 64 - 1 block message, digest == hashlib
+        stark_sha = {"2^10": bench_stark_air.run_sha256(prover, 10, reps=3), "2^14": bench_stark_air.run_sha256(prover, 14, reps=3)}
 
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
@@ -801,6 +803,7 @@ def main():
             "stark_quotient_ms": {k: v["stark_quotient_ms"] for k, v in stark_air.items()} if stark_air else None,
             "stark_prove_ms": {k: v["stark_prove_ms"] for k, v in stark_air.items()} if stark_air else None,
             "stark_air": stark_air,
+            "stark_sha256": stark_sha,
             "power_and_clock": pw,
         }
         emit(out)
