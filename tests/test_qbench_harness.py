@@ -280,6 +280,16 @@ def test_one_block_end_to_end_with_byte_parity(golden_dir, tmp_path):
     # the all-zero dev-mode proof: three per block
     res = run(["-i", dump, "--pack", pack, "--contexts", "2", "--batch", "8", "--groth16-log-size", "10"])
     assert res["blocks_complete"] == 1 and res["groth16_proofs"] == 3 and res["groth16_log_constraints"] == 10
+    # the three SHA-256 STARKs of a block (tools/qbench/stark_stage.h: cp_stark_prove on a synthetic AIR of the reference's shape, once
+    # per sighash job), alone and together with the Groth16 stage; the proofs of the block are byte-checked as before
+    res = run(["-i", dump, "--pack", pack, "--contexts", "2", "--batch", "8", "--stark-log-rows", "7", "--check-plan"])
+    assert res["blocks_complete"] == 1 and res["stark_proofs"] == 3 and res["stark_log_rows"] == 7 and res["stark_proof_bytes_mean"] > 100000
+    assert res["proofs"] == 64 and res["proofs_byte_checked"] >= 64
+    res = run(["-i", dump, "-n", "2", "--blocks-in-flight", "2", "--pack", pack, "--contexts", "2", "--batch", "8", "--stark-log-rows", "8",
+               "--groth16-log-size", "10"])
+    assert res["blocks_complete"] == 2 and res["stark_proofs"] == 6 and res["groth16_proofs"] == 6
+    assert "--stark-log-rows must be" in run(["-i", dump, "--pack", pack, "--stark-log-rows", "3"], ok=False)
+    assert "one caller per context" in run(["-i", dump, "--pack", pack, "--callers", "4", "--stark-log-rows", "8"], ok=False)
     # the worker pool over a device LIST (section 8(e)): the one GPU of the test box named twice gives two device entries,
     # each with its own contexts and resident circuits, all four workers on the one ready queue
     res = run(["-i", dump, "-n", "2", "--blocks-in-flight", "2", "--pack", pack, "--devices", "0,0", "--contexts", "2", "--batch", "8",

@@ -68,6 +68,7 @@
 
 #include "cityprover.h"
 #include "qbench/jobs.h"
+#include "qbench/stark_stage.h"
 #include "qbench/pack.h"
 #include "qbench/redis.h"
 
@@ -92,6 +93,7 @@ struct Options {
   bool dry_stages = false;  // --dry-run-stages: every stage of a job is a queue entry, as in a real run
   int dry_job_us = 0;   // --dry-run only: pretend a proving batch takes this long, so that the queue is shared among the worker slots
   int groth16_log = 0;  // > 0: the Groth16 job runs cp_groth16_prove_bls12381 on a synthetic key of 2^groth16_log constraints
+  int stark_log_rows = 0;  // > 0: every GenerateSigHashIntrospectionProof job first proves a STARK of 2^stark_log_rows rows (qbench/stark_stage.h)
   std::vector<int> devices;  // empty: all visible
   bool dry_run = false, ref_counters = false, check_plan = false;
   bool sliding = false;    // --sliding: a window of --blocks-in-flight blocks (a block that completes starts the next) instead of waves
@@ -344,6 +346,9 @@ struct Worker {
   size_t parity_checked = 0, proofs = 0, groth16_proofs = 0, launches = 0;
   Groth16Stage groth16;
   bool has_groth16 = false;
+  qb::StarkStage stark;
+  bool has_stark = false;
+  size_t stark_proofs = 0, stark_bytes = 0;
   cp_batcher *batcher = nullptr;  // --callers: several threads share this worker and prove one job per call through it
 
   void check(int rc, const char *what) const {
@@ -460,6 +465,7 @@ struct Worker {
     if (batcher) cp_batcher_destroy(batcher);
     batcher = nullptr;
     if (has_groth16) groth16.close(ctx);
+    if (has_stark) stark.close(ctx);
     for (auto *w : wires) cp_host_free(ctx, w);
     for (auto *c : circuits) cp_circuit_destroy(c);
     if (ctx) cp_ctx_destroy(ctx);
@@ -487,6 +493,17 @@ struct Shared {
   std::vector<std::vector<uint8_t>> expected;           // pack witness -> the proof bytes that passed the gate
   std::vector<std::unordered_map<JobId, size_t, qb::JobIdHash>> ordinals;  // per dump: proving job -> its index among the block's jobs of its type
 };
+
+// the STARK a sighash job proves before its first plonky2 proof (sighash.rs:132-146): with --stark-log-rows, once per job, when
+// its stage 0 is taken
+static void stark_of_sighash_jobs(Worker *worker, const std::vector<QueueEntry> &batch) {
+  if (!worker || !worker->has_stark) return;
+  for (const auto &e : batch)
+    if (e.stage == 0 && e.job.topic == qb::GenerateStandardProof && e.job.circuit_type == qb::GenerateSigHashIntrospectionProof) {
+      worker->stark_bytes += worker->stark.prove(worker->ctx, (uint64_t)e.job.goal_id * 16 + e.job.task_index);
+      worker->stark_proofs++;
+    }
+}
 
 void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Shared &shared, const std::vector<QueueEntry> &batch) {
   const JobId first = batch[0].job;
@@ -578,6 +595,7 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
           const qb::Binding &b = (*st[i])[(size_t)batch[i].stage];
           items.push_back({b.circuit, b.witness_for(job_ordinal(batch[i]))});
         }
+        stark_of_sighash_jobs(worker, batch);
         auto proofs = worker->prove_items(items, expected);
         for (size_t i = 0; i < batch.size(); i++) {
           if (batch[i].stage + 1 == (int)st[i]->size()) {
@@ -590,6 +608,7 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
         }
         max_stages = 0;
       }
+      if (max_stages > 0) stark_of_sighash_jobs(worker, batch);
       for (int s = 0; s < max_stages; s++) {
         std::vector<std::pair<int, size_t>> order;  // (class of the stage's circuit, position in the batch)
         for (size_t i = 0; i < batch.size(); i++)
@@ -768,6 +787,11 @@ int run_qbench(const Options &opt) {
           w.has_groth16 = true;
           w.groth16.prove(w.ctx, 0);
         }
+        if (opt.stark_log_rows > 0) {
+          w.stark.open(w.ctx, opt.stark_log_rows);
+          w.has_stark = true;
+          w.stark.prove(w.ctx, 0);
+        }
       }
       for (auto &w : workers) { w.parity_checked = 0; w.proofs = 0; w.launches = 0; }
     } catch (const std::exception &e) {
@@ -778,6 +802,7 @@ int run_qbench(const Options &opt) {
   const size_t per_worker = opt.callers > 0 && !opt.dry_run ? (size_t)opt.callers : 1;
   if (opt.callers > 0 && !opt.dry_run) {
     if (opt.groth16_log > 0) die("--callers shares a context between threads: the Groth16 stage (one caller per context) cannot run there");
+    if (opt.stark_log_rows > 0) die("--callers shares a context between threads: the STARK stage (one caller per context) cannot run there");
     for (auto &w : workers) {
       w.batcher = cp_batcher_create(w.ctx, (size_t)opt.batch, (unsigned)opt.linger_us);
       if (!w.batcher) die(std::string("cp_batcher_create: ") + cp_last_error(nullptr));
@@ -895,8 +920,11 @@ int run_qbench(const Options &opt) {
     jobs += inst->jobs_done;
     proofs += inst->proofs_done;
   }
-  size_t groth16_proofs = 0, launches = 0, launched = 0;
-  for (const auto &w : workers) { parity += w.parity_checked; groth16_proofs += w.groth16_proofs; launches += w.launches; launched += w.proofs; }
+  size_t groth16_proofs = 0, launches = 0, launched = 0, stark_proofs = 0, stark_bytes = 0;
+  for (const auto &w : workers) {
+    parity += w.parity_checked; groth16_proofs += w.groth16_proofs; launches += w.launches; launched += w.proofs;
+    stark_proofs += w.stark_proofs; stark_bytes += w.stark_bytes;
+  }
   std::string per_device = "null";
   if (dry_slots) {  // jobs taken by the worker slots of each device
     per_device = "{";
@@ -917,14 +945,15 @@ int run_qbench(const Options &opt) {
          "\"proofs_per_s\": %.2f, \"mean_block_latency_ms\": %.2f, \"devices\": [%s], \"contexts_per_device\": %d, \"workers\": %zu, "
          "\"callers_per_context\": %d, \"lanes_per_context\": %d, \"linger_us\": %d, \"max_batch\": %d, \"blocks_in_flight\": %d, \"window\": \"%s\", \"proofs_byte_checked\": %zu, \"distinct_proofs\": %zu, \"distinct_proofs_equal_to_recorded_bytes\": %zu, \"distinct_proofs_cp_verified\": %zu, "
          "\"circuits\": %zu, \"witnesses\": %zu, \"batch_classes\": %d, \"launches\": %zu, \"mean_batch\": %.2f, \"dry_run_jobs_per_device\": %s, "
-         "\"groth16_proofs\": %zu, \"groth16_log_constraints\": %d, \"pack\": \"%s\", \"timed\": \"from the first enqueue to the "
+         "\"groth16_proofs\": %zu, \"groth16_log_constraints\": %d, \"stark_proofs\": %zu, \"stark_log_rows\": %d, \"stark_proof_bytes_mean\": %.0f, \"pack\": \"%s\", \"timed\": \"from the first enqueue to the "
          "last completion; circuits resident, witnesses page-locked on the host (PCIe-inclusive), witness generation excluded\"}\n",
          opt.dry_run ? "dry-run" : "qbench", dumps.size(), opt.iterations, instances.size(), complete, jobs, proofs,
          instances.empty() ? 0.0 : (double)jobs / instances.size(), instances.empty() ? 0.0 : (double)proofs / instances.size(), wall,
          wall > 0 ? complete / wall : 0.0, wall > 0 ? proofs / wall : 0.0, complete ? latency_sum / complete * 1e3 : 0.0, devs.c_str(), opt.contexts,
          n_workers, opt.dry_run ? 0 : opt.callers, opt.lanes, opt.linger_us, opt.batch, opt.blocks_in_flight, opt.sliding ? "sliding" : "waves", parity, oracle_checked + verified,
          oracle_checked, verified, pack.circuit_files.size(), pack.witnesses.size(), n_classes, launches, launches ? (double)launched / launches : 0.0,
-         per_device.c_str(), groth16_proofs, opt.groth16_log, json_escape(opt.pack_dir).c_str());
+         per_device.c_str(), groth16_proofs, opt.groth16_log, stark_proofs, opt.stark_log_rows, stark_proofs ? (double)stark_bytes / (double)stark_proofs : 0.0,
+         json_escape(opt.pack_dir).c_str());
   for (auto &w : workers) w.close();
   return complete == instances.size() || opt.ref_counters ? 0 : 1;
 }
@@ -1269,6 +1298,7 @@ int main(int argc, char **argv) {
     else if (a == "--linger-us") opt.linger_us = atoi(val().c_str());
     else if (a == "--trace") opt.trace_path = val();
     else if (a == "--groth16-log-size") opt.groth16_log = atoi(val().c_str());
+    else if (a == "--stark-log-rows") opt.stark_log_rows = atoi(val().c_str());
     else if (a == "--dry-run") opt.dry_run = true;
     else if (a == "--skip-gate") opt.skip_gate = true;
     else if (a == "--sliding") opt.sliding = true;
@@ -1294,6 +1324,7 @@ int main(int argc, char **argv) {
     } else die("unknown argument " + a);
   }
   if (opt.groth16_log != 0 && (opt.groth16_log < 4 || opt.groth16_log > 26)) die("--groth16-log-size must be 0 (off) or 4..26");
+  if (opt.stark_log_rows != 0 && (opt.stark_log_rows < 6 || opt.stark_log_rows > 20)) die("--stark-log-rows must be 0 (off) or 6..20");
   if (opt.iterations < 1 || opt.contexts < 1 || opt.batch < 1 || opt.blocks_in_flight < 1 || opt.iters < 1 || opt.lanes < 1 || opt.callers < 0 || opt.linger_us < 0) die("bad argument value");
   // Every context owns a HIP stream, and the runtime multiplexes the streams of ONE process onto GPU_MAX_HW_QUEUES hardware
   // queues (default 4): with more contexts than that, kernels of different contexts queue behind each other instead of
