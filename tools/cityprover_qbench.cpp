@@ -33,6 +33,9 @@
 //     CityGroth16ProofData of the reference's GROTH16_DISABLED_DEV_MODE (toolbox/root.rs:287-294): no gnark circuit or
 //     proving key exists in the tree. --groth16-log-size L adds the Groth16 prover kernels on a synthetic key of 2^L
 //     constraints (five MSMs + quotient + the 192-byte packing): the cost of that stage, not a valid proof.
+//   * the SHA-256 STARK a sighash job proves before its first plonky2 proof (sighash.rs:132-146) is left out unless
+//     --stark-log-rows K is given: then cp_stark_prove runs on a synthetic AIR of the reference's shape (qbench/stark_stage.h),
+//     three times per block — the cost of that stage, not a valid proof either (the AIR lives in an absent crate).
 //   * the reference re-plans every iteration but never resets `counters` (memory_proof_store/mod.rs:77-83), so from the
 //     second iteration on no group ever reaches its goal again and only leaf jobs run; here every iteration starts from
 //     fresh counters (--ref-counters keeps the reference's behaviour).
