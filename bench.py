@@ -184,6 +184,24 @@ def cpu_baseline(cols_host, log_n, cap_h):
     cap = np.zeros((1 << cap_h, 4), np.uint64)
     L.or_merkle_tree_cols(O.ptr(work), n, k, n, cap_h, None, O.ptr(cap))
     t2 = time.perf_counter()
+    # ... and with eight states per AVX-512 permutation (oracle/poseidon_simd.c) where the host has it: the
+    # same bytes (tests/test_oracle_simd.py; the cap is compared here too), what a CPU prover that uses its vector units reaches
+    L.or_simd_available.restype = ctypes.c_int
+    simd = bool(L.or_simd_available())
+    simd_cap_s = simd_rate_one = None
+    if simd:
+        L.or_set_simd_poseidon(1)
+        cap2 = np.zeros_like(cap)
+        ts = time.perf_counter()
+        L.or_merkle_tree_cols(O.ptr(work), n, k, n, cap_h, None, O.ptr(cap2))
+        simd_cap_s = time.perf_counter() - ts
+        assert (cap2 == cap).all(), "AVX-512 Merkle cap differs from the scalar port's"
+        st8 = splitmix64_felts(12, 12 * 80000).reshape(-1, 12).copy()
+        L.or_set_threads(1)
+        ts = time.perf_counter()
+        O.permute_many(st8)
+        simd_rate_one = len(st8) / (time.perf_counter() - ts)
+        L.or_set_simd_poseidon(0)
     L.or_set_threads(1)
     # single-thread permutation rate of the port, on a bounded sample: the honest scale of this baseline
     st = splitmix64_felts(11, 12 * 20000).reshape(-1, 12).copy()
@@ -194,17 +212,24 @@ def cpu_baseline(cols_host, log_n, cap_h):
     L.or_set_fast_poseidon(0)
     perms = n * ((k + 7) // 8) + (n - 16)
     all_rate, one_rate = perms / (t2 - t1), len(st) / (t4 - t3)
+    step_s = (t1 - t0) + (simd_cap_s if simd else (t2 - t1))
     return {
-        "value": (t2 - t0) * 1e3 / k, "unit": "ms/NTT", "cores": cores, "kind": "port",
-        "host": {"threads_used": cores, "cpus_in_affinity_mask": affinity, "cgroup_cpu_quota": quota, "nproc": os.cpu_count()},
+        "value": step_s * 1e3 / k, "unit": "ms/NTT", "cores": cores, "kind": "port-simd" if simd else "port",
+        "host": {"threads_used": cores, "cpus_in_affinity_mask": affinity, "cgroup_cpu_quota": quota, "nproc": os.cpu_count(), "avx512": simd},
         "poseidon_perms_per_s_all_cores": all_rate, "poseidon_perms_per_s_one_thread": one_rate,
         "poseidon_speedup_over_one_thread": all_rate / one_rate, "poseidon_parallel_efficiency": all_rate / one_rate / cores,
-        "note": "a C restatement (scalar code: multiplier-free MDS on 32-bit planes, branch-free field ops, textbook round "
-                "structure, OpenMP over columns / leaves), NOT plonky2's AVX2 / rayon prover: no "
+        "scalar_port": {"value": (t2 - t0) * 1e3 / k, "merkle_cap_s": t2 - t1},
+        "simd": None if not simd else {
+            "poseidon_perms_per_s_all_cores": perms / simd_cap_s, "poseidon_perms_per_s_one_thread": simd_rate_one, "merkle_cap_s": simd_cap_s,
+            "speedup_over_the_scalar_port": (t2 - t1) / simd_cap_s,
+            "note": "eight states per permutation in AVX-512 lanes (oracle/poseidon_simd.c), same round structure and bytes as the scalar port"},
+        "note": "a C restatement (multiplier-free MDS on 32-bit planes, branch-free field ops, textbook round structure, OpenMP over "
+                "columns / leaves; `value` uses the AVX-512 permutation over eight states where the host has it, `scalar_port` is the "
+                "same step without it; the poseidon_* figures at this level are the scalar port's), NOT plonky2's own prover: no "
                 "speed-up over the reference may be read off this number (the reference cannot be built here: no Rust toolchain)",
         "sample": f"one full step on the host: {k} x 2^{log_n} NTT (+bit-reverse) = {(t1 - t0):.2f} s, "
-                  f"Poseidon Merkle cap over 2^{log_n} x {k} = {(t2 - t1):.2f} s; C oracle, "
-                  f"{cores} threads",
+                  f"Poseidon Merkle cap over 2^{log_n} x {k} = {(t2 - t1):.2f} s scalar"
+                  + (f", {simd_cap_s:.2f} s with AVX-512" if simd else "") + f"; C oracle, {cores} threads",
         "ntt_ms": (t1 - t0) * 1e3 / k, "merkle_cap_s": t2 - t1,
     }, work, cap
 
@@ -215,6 +240,7 @@ def cpu_port_proof(prover, cores):
     the host cores, and a live parity check: the GPU's bytes for the same job must equal the oracle's."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ctypes
     import oracle_lib as O
     import bench_prove
     import cityprover as cp
@@ -229,6 +255,14 @@ def cpu_port_proof(prover, cores):
     circ.close()
     O.lib().or_set_threads(cores)
     O.lib().or_set_fast_poseidon(1)
+    O.lib().or_simd_available.restype = ctypes.c_int
+    simd = bool(O.lib().or_simd_available())
+    scalar_sec = None
+    if simd:   # one scalar proof for the record, then everything below with the AVX-512 permutation (same bytes: asserted)
+        ts = time.perf_counter()
+        O.prove_full(osh, og, digest, c["public_inputs"], c["cs_values"], c["wires"])
+        scalar_sec = time.perf_counter() - ts
+        O.lib().or_set_simd_poseidon(1)
     t0 = time.perf_counter()
     O.commit_batch(c["cs_values"], 3, 4, want=("cap",))   # circuit data: built once per circuit upstream, not per proof
     t1 = time.perf_counter()
@@ -250,8 +284,10 @@ def cpu_port_proof(prover, cores):
         many = list(ex.map(one_proof, range(cores)))
     t4 = time.perf_counter()
     O.lib().or_set_fast_poseidon(0)
+    O.lib().or_set_simd_poseidon(0)
     assert all(b == got for b in many), "a side-by-side CPU proof differs from the GPU's bytes"
-    return {"proofs_per_s": cores / (t4 - t3), "seconds_per_proof": sec, "cores": cores, "kind": "port",
+    return {"proofs_per_s": cores / (t4 - t3), "seconds_per_proof": sec, "cores": cores, "kind": "port-simd" if simd else "port",
+            "seconds_per_proof_scalar_port_all_threads_incl_constants_commitment": scalar_sec,
             "proofs_per_s_one_proof_on_all_threads": 1.0 / sec,
             "proofs_per_s_independent_proofs_one_thread_each": cores / (t4 - t3), "seconds_per_proof_on_one_thread": t4 - t3,
             "throughput_note": "proofs_per_s = %d independent proofs on %d threads, one thread each (how the reference's worker processes scale); "

@@ -219,8 +219,15 @@ void or_poseidon_permute(uint64_t s[POS_W]) {
 
 void or_poseidon_permute_many(uint64_t *states, size_t count) {
   rc_init();
+  size_t done = 0;
+  if (or_simd_poseidon_enabled()) {  /* bench.py's cpu_baseline only: eight states per AVX-512 permutation (poseidon_simd.c) */
+    const size_t groups = count / 8;
 #pragma omp parallel for num_threads(g_threads) schedule(static)
-  for (size_t i = 0; i < count; i++) or_poseidon_permute(states + i * POS_W);
+    for (size_t g = 0; g < groups; g++) or_simd_permute_aos_x8(states + 8 * g * POS_W);
+    done = 8 * groups;
+  }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (size_t i = done; i < count; i++) or_poseidon_permute(states + i * POS_W);
 }
 
 void or_hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4]) {
@@ -266,8 +273,15 @@ static void merkle_from_leaf_digests(uint64_t *level0, size_t n_leaves, int cap_
       dout += n * 4;
     }
     uint64_t *next = (uint64_t *)malloc((n / 2) * 32);
+    size_t first = 0;
+    if (or_simd_poseidon_enabled()) {
+      const size_t groups = (n / 2) / 8;
 #pragma omp parallel for num_threads(g_threads) schedule(static)
-    for (size_t i = 0; i < n / 2; i++)
+      for (size_t g = 0; g < groups; g++) or_simd_two_to_one_x8(cur + 64 * g, next + 32 * g);
+      first = 8 * groups;
+    }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (size_t i = first; i < n / 2; i++)
       or_two_to_one(cur + 8 * i, cur + 8 * i + 4, next + 4 * i);
     if (owned) free(owned);
     owned = next;
@@ -294,11 +308,18 @@ void or_merkle_tree_cols(const uint64_t *cols, size_t n_leaves, size_t leaf_len,
                          uint64_t *cap_out) {
   rc_init();
   uint64_t *lvl = (uint64_t *)malloc(n_leaves * 32);
+  size_t first_scalar = 0;
+  if (or_simd_poseidon_enabled() && leaf_len > 4) {  /* eight consecutive leaves per AVX-512 sponge: a column is contiguous */
+    const size_t groups = n_leaves / 8;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (size_t g = 0; g < groups; g++) or_simd_leaf_hash_cols_x8(cols, leaf_len, col_stride, 8 * g, lvl + 32 * g);
+    first_scalar = 8 * groups;
+  }
 #pragma omp parallel num_threads(g_threads)
   {
     uint64_t *row = (uint64_t *)malloc(leaf_len * sizeof(uint64_t));
 #pragma omp for schedule(static)
-    for (size_t i = 0; i < n_leaves; i++) {
+    for (size_t i = first_scalar; i < n_leaves; i++) {
       for (size_t j = 0; j < leaf_len; j++) row[j] = cols[j * col_stride + i];
       or_hash_or_noop(row, leaf_len, lvl + 4 * i);
     }

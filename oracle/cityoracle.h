@@ -40,6 +40,17 @@ void or_poseidon_mds(uint64_t *circ, uint64_t *diag);
 void or_set_fast_poseidon(int on);
 void or_poseidon_permute(uint64_t state[12]);
 void or_poseidon_permute_many(uint64_t *states, size_t count);
+/* poseidon_simd.c — eight states per AVX-512 permutation, for bench.py's cpu_baseline legs ONLY ("port-simd"): off by default, so
+ * that the checker of the tests is the scalar textbook form; tests/test_oracle_simd.py holds the two against each other.
+ * or_set_simd_poseidon(1) routes the leaf hashes and levels of or_merkle_tree_cols (and everything built on it: commitments,
+ * whole proofs) and or_poseidon_permute_many through it when the CPU has AVX-512 F / DQ / VL / BW; else it stays off. */
+int or_simd_available(void);
+void or_set_simd_poseidon(int on);
+int or_simd_poseidon_enabled(void);
+void or_poseidon_permute_x8(uint64_t st[12][8]);
+void or_simd_leaf_hash_cols_x8(const uint64_t *cols, size_t leaf_len, size_t col_stride, size_t i0, uint64_t *digests_out);
+void or_simd_two_to_one_x8(const uint64_t *children, uint64_t *parents_out);
+void or_simd_permute_aos_x8(uint64_t *states);
 
 /* PoseidonHash::hash_no_pad — overwrite-mode sponge, rate 8
  * (call sites: city_crypto/src/hash/traits/hasher.rs:82-95). */
