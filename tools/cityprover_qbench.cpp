@@ -150,7 +150,9 @@ struct Scheduler {
   std::vector<BenchRecord> benchmarks;  // completion order
   std::vector<JobId> processed;        // every job popped, in pop order (barrier and notify jobs included)
   int stage_class[256][8] = {{0}};     // (circuit type, stage) -> batch-compatibility class of that stage's circuit
-  int cls(const QueueEntry &e) const { return stage_class[e.job.circuit_type][e.stage < 8 ? e.stage : 7]; }
+  int cls(const QueueEntry &e) const { return e.stage < 0 ? -2 : stage_class[e.job.circuit_type][e.stage < 8 ? e.stage : 7]; }
+  bool stark_stage = false;            // --stark-log-rows: a sighash job enters the queue at stage -1 = its STARK (a unit of its own: the
+                                       // three of a block go to three workers instead of one after the other on whoever took the jobs)
   size_t n_workers = 1;                // threads draining the queue
   size_t busy = 0;                     // of them, holding work (between the take() that returned it and their next take())
   std::function<void()> on_block_complete;  // --sliding: starts the next block
@@ -164,7 +166,8 @@ struct Scheduler {
     std::lock_guard<std::mutex> l(m);
     for (size_t i = 0; i < jobs.size(); i++) {
       const JobId &j = jobs[i];
-      queue.push_back({inst, j, chain[i]});
+      const bool stark_first = stark_stage && j.topic == qb::GenerateStandardProof && j.circuit_type == qb::GenerateSigHashIntrospectionProof;
+      queue.push_back({inst, j, chain[i] + (stark_first ? 1 : 0), stark_first ? -1 : 0});
       cv.notify_one();  // one sleeper per job: with a hundred worker threads, waking them all for every job is what costs
     }
   }
@@ -214,6 +217,7 @@ struct Scheduler {
     out.push_back(queue.front());
     queue.pop_front();
     const JobId first = out[0].job;
+    if (out[0].stage < 0) max_batch = 1;  // a STARK is proved alone
     if (first.topic == qb::GenerateStandardProof && max_batch > 1 && n_workers > 1 && share_short_queues) {
       // A queue that the free workers could empty between them is SHARED among them instead of going to whoever woke first: one
       // block alone, twenty-three ready stages, is three launches on three contexts at once, not one launch while two contexts
@@ -497,17 +501,6 @@ struct Shared {
   std::vector<std::unordered_map<JobId, size_t, qb::JobIdHash>> ordinals;  // per dump: proving job -> its index among the block's jobs of its type
 };
 
-// the STARK a sighash job proves before its first plonky2 proof (sighash.rs:132-146): with --stark-log-rows, once per job, when
-// its stage 0 is taken
-static void stark_of_sighash_jobs(Worker *worker, const std::vector<QueueEntry> &batch) {
-  if (!worker || !worker->has_stark) return;
-  for (const auto &e : batch)
-    if (e.stage == 0 && e.job.topic == qb::GenerateStandardProof && e.job.circuit_type == qb::GenerateSigHashIntrospectionProof) {
-      worker->stark_bytes += worker->stark.prove(worker->ctx, (uint64_t)e.job.goal_id * 16 + e.job.task_index);
-      worker->stark_proofs++;
-    }
-}
-
 void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Shared &shared, const std::vector<QueueEntry> &batch) {
   const JobId first = batch[0].job;
   const qb::Pack *pack = shared.pack;
@@ -520,7 +513,16 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
   };
   const double t0 = now_s();
   static const bool whole_jobs = getenv("CITYPROVER_QBENCH_WHOLE_JOBS") != nullptr;  // A/B: a worker keeps a job through all its stages
-  auto t_first = [&](size_t i) { return batch[i].stage == 0 ? t0 : batch[i].t_first; };  // when the job's first stage started
+  auto t_first = [&](size_t i) { return batch[i].t_first > 0 ? batch[i].t_first : t0; };  // when the job's first stage started
+  if (batch[0].stage < 0) {  // the STARK of a sighash job (sighash.rs:132-146): proved, then the job goes on with its first plonky2 proof
+    for (const auto &e : batch) {
+      if (!worker || !worker->has_stark) throw std::runtime_error("a STARK stage was scheduled without a STARK prover");
+      worker->stark_bytes += worker->stark.prove(worker->ctx, (uint64_t)e.job.goal_id * 16 + e.job.task_index);
+      worker->stark_proofs++;
+      S.requeue({e.inst, e.job, e.chain > 0 ? e.chain - 1 : 0, 0, t0});
+    }
+    return;
+  }
   std::vector<std::vector<uint8_t>> outputs(batch.size());
   std::vector<char> done(batch.size(), 0);
   // the tail of process_job (actors/simple.rs:89-106) for one job of the batch: store the output, record the duration, count,
@@ -598,7 +600,6 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
           const qb::Binding &b = (*st[i])[(size_t)batch[i].stage];
           items.push_back({b.circuit, b.witness_for(job_ordinal(batch[i]))});
         }
-        stark_of_sighash_jobs(worker, batch);
         auto proofs = worker->prove_items(items, expected);
         for (size_t i = 0; i < batch.size(); i++) {
           if (batch[i].stage + 1 == (int)st[i]->size()) {
@@ -611,7 +612,6 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
         }
         max_stages = 0;
       }
-      if (max_stages > 0) stark_of_sighash_jobs(worker, batch);
       for (int s = 0; s < max_stages; s++) {
         std::vector<std::pair<int, size_t>> order;  // (class of the stage's circuit, position in the batch)
         for (size_t i = 0; i < batch.size(); i++)
@@ -815,6 +815,7 @@ int run_qbench(const Options &opt) {
                                        : workers.size() * per_worker;
 
   Scheduler S;
+  S.stark_stage = !opt.dry_run && opt.stark_log_rows > 0;
   if (!opt.dry_run)
     for (int t = 0; t < 256; t++) {
       if (!pack.by_type.count(t) && !pack.by_type.count(-1)) continue;

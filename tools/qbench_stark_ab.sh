@@ -7,5 +7,8 @@ python3 "$R/tools/make_circuit_pack.py" /tmp/ab_pack 0 12 > /dev/null
 for k in 0 10 11 12; do
   "$R/tools/cityprover_qbench" -i "$R/tests/golden/qbench_example.bin" -n 128 --blocks-in-flight 64 --pack /tmp/ab_pack --contexts 3 --batch 128 --stark-log-rows $k
 done
-"$R/tools/cityprover_qbench" -i "$R/tests/golden/qbench_example.bin" -n 1 --blocks-in-flight 1 --pack /tmp/ab_pack --contexts 3 --batch 128 --stark-log-rows 0
-"$R/tools/cityprover_qbench" -i "$R/tests/golden/qbench_example.bin" -n 1 --blocks-in-flight 1 --pack /tmp/ab_pack --contexts 3 --batch 128 --stark-log-rows 10
+for c in 4 5; do
+  "$R/tools/cityprover_qbench" -i "$R/tests/golden/qbench_example.bin" -n 128 --blocks-in-flight 64 --pack /tmp/ab_pack --contexts $c --batch 128 --stark-log-rows 10
+done
+"$R/tools/cityprover_qbench" -i "$R/tests/golden/qbench_example.bin" -n 8 --blocks-in-flight 1 --pack /tmp/ab_pack --contexts 3 --batch 128 --stark-log-rows 0
+"$R/tools/cityprover_qbench" -i "$R/tests/golden/qbench_example.bin" -n 8 --blocks-in-flight 1 --pack /tmp/ab_pack --contexts 3 --batch 128 --stark-log-rows 10
