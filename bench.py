@@ -762,9 +762,12 @@ def main():
             roof = {"kernel": "leaf_hash_cols", "bound": "valu-issue", "unit": "T lane-ops/s",
                     "achieved": lane_ops / (leaf_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TLOPS,
                     "peak_note": "NOMINAL peak: 1024 SIMD-32 x one full-rate wave64 VALU instruction per 2 cycles at 2.4 GHz "
-                                 "(MI355X_MICROARCH.md). The kernel's mix is quarter-rate (v_mad_u64_u32, v_fma_f64: 4 cycles per wave64 "
-                                 "instruction; measured 31.5-36 T/s for such streams, 54 T/s for all-VOP2, profiles/r01_ubench_valu.txt), "
-                                 "so the ceiling of the MIX is about half this peak: see frac_of_mix_rate",
+                                 "(MI355X_MICROARCH.md). Measured per instruction with eight waves per SIMD (tools/ubench_valu, "
+                                 "profiles/r04_ubench_valu.txt, cycles per wave64 instruction at the nominal clock): only plain 32-bit add / sub / "
+                                 "and / xor / mov and f32 multiply-add reach 2.4-3.0; everything a 64-bit modular product and the exact f64 "
+                                 "limb planes are made of takes 4.2-5.0 (v_mad_u64_u32 5.0, v_fma_f64 / v_add_f64 4.3, carry chains 4.3-4.9, "
+                                 "v_cndmask on an SGPR mask 4.5, shifts 4.1, three-operand integer forms 4.4-4.7): the ceiling of the MIX is about "
+                                 "half this peak - see frac_of_mix_rate",
                     "frac_is_against": "the nominal full-rate peak (roofline.frac, frac_at_measured_clock); roofline.frac_of_mix_rate is "
                                        "against the measured issue rate of this instruction mix (4 cycles per instruction)",
                     "valu_instructions_per_launch": pl["SQ_INSTS_VALU"], "valu_instructions_per_permutation": lane_ops / perms,
