@@ -288,6 +288,11 @@ def test_one_block_end_to_end_with_byte_parity(golden_dir, tmp_path):
     res = run(["-i", dump, "-n", "2", "--blocks-in-flight", "2", "--pack", pack, "--contexts", "2", "--batch", "8", "--stark-log-rows", "8",
                "--groth16-log-size", "10"])
     assert res["blocks_complete"] == 2 and res["stark_proofs"] == 6 and res["groth16_proofs"] == 6
+    # ... and with contexts of their own for the STARK stages (they prove nothing else, the other contexts no STARK)
+    res = run(["-i", dump, "-n", "2", "--blocks-in-flight", "2", "--pack", pack, "--contexts", "2", "--batch", "8", "--stark-log-rows", "7",
+               "--stark-contexts", "2", "--check-plan"])
+    assert res["blocks_complete"] == 2 and res["stark_proofs"] == 6 and res["workers"] == 4 and res["proofs_byte_checked"] >= 128
+    assert "--stark-contexts must be" in run(["-i", dump, "--pack", pack, "--stark-contexts", "2"], ok=False)
     assert "--stark-log-rows must be" in run(["-i", dump, "--pack", pack, "--stark-log-rows", "3"], ok=False)
     assert "one caller per context" in run(["-i", dump, "--pack", pack, "--callers", "4", "--stark-log-rows", "8"], ok=False)
     # the worker pool over a device LIST (section 8(e)): the one GPU of the test box named twice gives two device entries,

@@ -97,6 +97,7 @@ struct Options {
   int dry_job_us = 0;   // --dry-run only: pretend a proving batch takes this long, so that the queue is shared among the worker slots
   int groth16_log = 0;  // > 0: the Groth16 job runs cp_groth16_prove_bls12381 on a synthetic key of 2^groth16_log constraints
   int stark_log_rows = 0;  // > 0: every GenerateSigHashIntrospectionProof job first proves a STARK of 2^stark_log_rows rows (qbench/stark_stage.h)
+  int stark_contexts = 0;  // > 0: that many EXTRA contexts per device prove nothing but STARK stages, and the --contexts workers none of them
   std::vector<int> devices;  // empty: all visible
   bool dry_run = false, ref_counters = false, check_plan = false;
   bool sliding = false;    // --sliding: a window of --blocks-in-flight blocks (a block that completes starts the next) instead of waves
@@ -168,14 +169,16 @@ struct Scheduler {
       const JobId &j = jobs[i];
       const bool stark_first = stark_stage && j.topic == qb::GenerateStandardProof && j.circuit_type == qb::GenerateSigHashIntrospectionProof;
       queue.push_back({inst, j, chain[i] + (stark_first ? 1 : 0), stark_first ? -1 : 0});
-      cv.notify_one();  // one sleeper per job: with a hundred worker threads, waking them all for every job is what costs
+      if (roles) cv.notify_all();
+      else cv.notify_one();  // one sleeper per job: with a hundred worker threads, waking them all for every job is what costs
     }
   }
   // the next stage of a job whose stage has just been proved: ahead of what has not started yet
   void requeue(const QueueEntry &e) {
     std::lock_guard<std::mutex> l(m);
     queue.push_front(e);
-    cv.notify_one();
+    if (roles) cv.notify_all();
+    else cv.notify_one();
   }
   void fail(const std::string &msg) {
     std::lock_guard<std::mutex> l(m);
@@ -185,13 +188,17 @@ struct Scheduler {
   // Blocks until work is ready. Takes the front job and, when it is a proving job, up to max_batch - 1 further ready jobs
   // whose circuits may share a launch with it (FIFO among them). Returns false when the run is over (all instances complete,
   // or a failure).
-  bool take(size_t max_batch, std::vector<QueueEntry> &out) {
+  bool roles = false;  // --stark-contexts: workers take by role, so every enqueue wakes all sleepers (the one woken may not be the one who can take it)
+  static bool fits(const QueueEntry &e, int role) { return role == 0 || (role == 2) == (e.stage < 0); }
+  bool take(size_t max_batch, std::vector<QueueEntry> &out, int role = 0) {
     std::unique_lock<std::mutex> l(m);
     static thread_local bool holds_work = false;  // a worker is busy from the take() that gave it work to its next take()
-    if (holds_work) { busy--; holds_work = false; }
+    if (holds_work) { if (role != 2) busy--; holds_work = false; }
     for (;;) {
       if (failed) return false;
-      if (!queue.empty()) break;
+      bool any = false;
+      for (const auto &e : queue) if (fits(e, role)) { any = true; break; }
+      if (any) break;
       if (in_flight == 0 && pending_instances == 0) return false;
       if (in_flight == 0 && queue.empty() && pending_instances > 0) {
         // nothing running, nothing ready, blocks unfinished: the DAG cannot make progress
@@ -214,8 +221,12 @@ struct Scheduler {
       // launches shrink to 9 (34 -> 28 blocks/s, profiles/r03_qbench_window_ab_oldest_first.jsonl).
       // CITYPROVER_QBENCH_FIFO=1 restores the queue order.
       std::stable_sort(queue.begin(), queue.end(), [](const QueueEntry &a, const QueueEntry &b) { return a.chain > b.chain; });
-    out.push_back(queue.front());
-    queue.pop_front();
+    {
+      auto it = queue.begin();
+      while (!fits(*it, role)) ++it;
+      out.push_back(*it);
+      queue.erase(it);
+    }
     const JobId first = out[0].job;
     if (out[0].stage < 0) max_batch = 1;  // a STARK is proved alone
     if (first.topic == qb::GenerateStandardProof && max_batch > 1 && n_workers > 1 && share_short_queues) {
@@ -236,7 +247,7 @@ struct Scheduler {
     }
     if (first.topic == qb::GenerateStandardProof)
       for (auto it = queue.begin(); it != queue.end() && out.size() < max_batch;) {
-        if (it->job.topic == qb::GenerateStandardProof && cls(*it) == cls(out[0])) {
+        if (it->job.topic == qb::GenerateStandardProof && cls(*it) == cls(out[0]) && fits(*it, role)) {
           out.push_back(*it);
           it = queue.erase(it);
         } else {
@@ -246,7 +257,7 @@ struct Scheduler {
     for (const auto &e : out)
       if (e.stage == 0) processed.push_back(e.job);
     in_flight += out.size();
-    busy++;
+    if (role != 2) busy++;   // `busy` counts the workers that share plonky2 launches
     holds_work = true;
     return true;
   }
@@ -360,6 +371,12 @@ struct Worker {
 
   void check(int rc, const char *what) const {
     if (rc != CP_OK) throw std::runtime_error(std::string(what) + ": " + cp_last_error(ctx));
+  }
+  int role = 0;  // 0: takes any ready stage; 1: plonky2 stages only; 2: STARK stages only (Scheduler::take)
+  void open_bare(int dev) {  // a context without resident circuits: a STARK-only worker
+    device = dev;
+    ctx = cp_ctx_create(dev);
+    if (!ctx) throw std::runtime_error(std::string("cp_ctx_create: ") + cp_last_error(nullptr));
   }
   void open(const qb::Pack &p, int dev, int lanes) {
     pack = &p;
@@ -651,7 +668,7 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
 
 void worker_loop(const Options &opt, Scheduler &S, Worker *worker, const Shared &shared, size_t take, std::atomic<size_t> *jobs_of_slot) {
   std::vector<QueueEntry> batch;
-  while (S.take(take, batch)) {
+  while (S.take(take, batch, worker ? worker->role : 0)) {
     try {
       process_batch(opt, S, worker, shared, batch);
       if (jobs_of_slot && batch[0].job.topic == qb::GenerateStandardProof) jobs_of_slot->fetch_add(batch.size());
@@ -774,23 +791,36 @@ int run_qbench(const Options &opt) {
     } catch (const std::exception &e) {
       die(std::string("circuit pack: ") + e.what());
     }
-    workers.resize(devices.size() * (size_t)opt.contexts);
+    const size_t n_general = devices.size() * (size_t)opt.contexts;
+    workers.resize(n_general + devices.size() * (size_t)opt.stark_contexts);
     try {
-      for (size_t w = 0; w < workers.size(); w++) {
+      for (size_t w = 0; w < n_general; w++) {
         workers[w].index = (int)w;
+        workers[w].role = opt.stark_contexts > 0 ? 1 : 0;
         workers[w].open(pack, devices[w / (size_t)opt.contexts], opt.lanes);
+      }
+      for (size_t w = n_general; w < workers.size(); w++) {  // STARK-only contexts: no resident circuits
+        workers[w].index = (int)w;
+        workers[w].role = 2;
+        workers[w].open_bare(devices[(w - n_general) / (size_t)opt.stark_contexts]);
       }
       // warm-up = the gate every distinct proof passes before the clock starts (allocations and the staging ring come with it)
       shared.circuit_class = workers[0].circuit_classes();
       shared.expected.assign(pack.witnesses.size(), {});
       for (auto &w : workers) {
+        if (w.role == 2) {
+          w.stark.open(w.ctx, opt.stark_log_rows);
+          w.has_stark = true;
+          w.stark.prove(w.ctx, 0);
+          continue;
+        }
         w.gate(shared.expected, &oracle_checked, &verified);
         if (opt.groth16_log > 0) {
           w.groth16.open(w.ctx, opt.groth16_log);
           w.has_groth16 = true;
           w.groth16.prove(w.ctx, 0);
         }
-        if (opt.stark_log_rows > 0) {
+        if (opt.stark_log_rows > 0 && opt.stark_contexts == 0) {
           w.stark.open(w.ctx, opt.stark_log_rows);
           w.has_stark = true;
           w.stark.prove(w.ctx, 0);
@@ -816,6 +846,7 @@ int run_qbench(const Options &opt) {
 
   Scheduler S;
   S.stark_stage = !opt.dry_run && opt.stark_log_rows > 0;
+  S.roles = S.stark_stage && opt.stark_contexts > 0;
   if (!opt.dry_run)
     for (int t = 0; t < 256; t++) {
       if (!pack.by_type.count(t) && !pack.by_type.count(-1)) continue;
@@ -845,7 +876,7 @@ int run_qbench(const Options &opt) {
       S.enqueue(&inst, leaves[i]);
     };
     S.on_block_complete = start_next;
-    S.n_workers = n_workers;
+    S.n_workers = n_workers - (opt.dry_run ? 0 : devices.size() * (size_t)opt.stark_contexts);  // the workers that share plonky2 launches
     for (int k = 0; k < opt.blocks_in_flight; k++) start_next();
     std::vector<std::thread> threads;
     for (size_t w = 0; w < n_workers; w++)
@@ -875,7 +906,7 @@ int run_qbench(const Options &opt) {
       S.enqueue(&inst, leaves[i]);
     }
     std::vector<std::thread> threads;
-    S.n_workers = n_workers;
+    S.n_workers = n_workers - (opt.dry_run ? 0 : devices.size() * (size_t)opt.stark_contexts);  // the workers that share plonky2 launches
     for (size_t w = 0; w < n_workers; w++)
       threads.emplace_back([&, w] {
         worker_loop(opt, S, opt.dry_run ? nullptr : &workers[w / per_worker], shared,
@@ -1303,6 +1334,7 @@ int main(int argc, char **argv) {
     else if (a == "--trace") opt.trace_path = val();
     else if (a == "--groth16-log-size") opt.groth16_log = atoi(val().c_str());
     else if (a == "--stark-log-rows") opt.stark_log_rows = atoi(val().c_str());
+    else if (a == "--stark-contexts") opt.stark_contexts = atoi(val().c_str());
     else if (a == "--dry-run") opt.dry_run = true;
     else if (a == "--skip-gate") opt.skip_gate = true;
     else if (a == "--sliding") opt.sliding = true;
@@ -1329,6 +1361,7 @@ int main(int argc, char **argv) {
   }
   if (opt.groth16_log != 0 && (opt.groth16_log < 4 || opt.groth16_log > 26)) die("--groth16-log-size must be 0 (off) or 4..26");
   if (opt.stark_log_rows != 0 && (opt.stark_log_rows < 6 || opt.stark_log_rows > 20)) die("--stark-log-rows must be 0 (off) or 6..20");
+  if (opt.stark_contexts < 0 || opt.stark_contexts > 8 || (opt.stark_contexts > 0 && opt.stark_log_rows == 0)) die("--stark-contexts must be 0..8 and needs --stark-log-rows");
   if (opt.iterations < 1 || opt.contexts < 1 || opt.batch < 1 || opt.blocks_in_flight < 1 || opt.iters < 1 || opt.lanes < 1 || opt.callers < 0 || opt.linger_us < 0) die("bad argument value");
   // Every context owns a HIP stream, and the runtime multiplexes the streams of ONE process onto GPU_MAX_HW_QUEUES hardware
   // queues (default 4): with more contexts than that, kernels of different contexts queue behind each other instead of

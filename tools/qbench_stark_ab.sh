@@ -10,5 +10,10 @@ done
 for c in 4 5; do
   "$R/tools/cityprover_qbench" -i "$R/tests/golden/qbench_example.bin" -n 128 --blocks-in-flight 64 --pack /tmp/ab_pack --contexts $c --batch 128 --stark-log-rows 10
 done
+# contexts that prove nothing but STARK stages, beside three that prove none
+for c in 1 2 3; do
+  "$R/tools/cityprover_qbench" -i "$R/tests/golden/qbench_example.bin" -n 128 --blocks-in-flight 64 --pack /tmp/ab_pack --contexts 3 --batch 128 --stark-log-rows 10 --stark-contexts $c
+done
+"$R/tools/cityprover_qbench" -i "$R/tests/golden/qbench_example.bin" -n 8 --blocks-in-flight 1 --pack /tmp/ab_pack --contexts 3 --batch 128 --stark-log-rows 10 --stark-contexts 3
 "$R/tools/cityprover_qbench" -i "$R/tests/golden/qbench_example.bin" -n 8 --blocks-in-flight 1 --pack /tmp/ab_pack --contexts 3 --batch 128 --stark-log-rows 0
 "$R/tools/cityprover_qbench" -i "$R/tests/golden/qbench_example.bin" -n 8 --blocks-in-flight 1 --pack /tmp/ab_pack --contexts 3 --batch 128 --stark-log-rows 10
