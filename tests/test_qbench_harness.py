@@ -247,12 +247,21 @@ def test_scheduler_under_thread_sanitizer(golden_dir, tmp_path):
                  # the stage machinery (a job of k proofs passes through the queue k times: requeue, longest chain first,
                  # shared short queues) and the sliding window, with simulated launch times so that the workers interleave
                  ["--contexts", "6", "--batch", "8", "-n", "12", "--blocks-in-flight", "3", "--dry-run-stages", "--dry-run-job-us", "200"],
-                 ["--contexts", "6", "--batch", "8", "-n", "12", "--blocks-in-flight", "3", "--dry-run-stages", "--dry-run-job-us", "200", "--sliding"]):
+                 ["--contexts", "6", "--batch", "8", "-n", "12", "--blocks-in-flight", "3", "--dry-run-stages", "--dry-run-job-us", "200", "--sliding"],
+                 # the STARK of a sighash job as a queue stage of its own, taken by any worker / only by workers of its own
+                 ["--contexts", "6", "--batch", "8", "-n", "12", "--blocks-in-flight", "3", "--dry-run-stages", "--dry-run-job-us", "200",
+                  "--stark-log-rows", "10"],
+                 ["--contexts", "4", "--batch", "8", "-n", "12", "--blocks-in-flight", "3", "--dry-run-stages", "--dry-run-job-us", "200",
+                  "--stark-log-rows", "10", "--stark-contexts", "2"],
+                 ["--contexts", "4", "--batch", "8", "-n", "12", "--blocks-in-flight", "3", "--dry-run-stages", "--dry-run-job-us", "100",
+                  "--stark-log-rows", "10", "--stark-contexts", "1", "--sliding"]):
         r = subprocess.run([exe, "-i", dump, "--dry-run"] + args, capture_output=True, text=True, timeout=300)
         assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
         assert r.returncode == 0, r.stderr[-1000:]
         res = json.loads(r.stdout.strip().splitlines()[-1])
         assert res["blocks_complete"] == res["blocks"] == int(args[5])
+        if "--stark-log-rows" in args:
+            assert res["stark_proofs"] == 3 * res["blocks"]
 
 
 @pytest.mark.gpu

@@ -152,6 +152,7 @@ struct Scheduler {
   std::vector<JobId> processed;        // every job popped, in pop order (barrier and notify jobs included)
   int stage_class[256][8] = {{0}};     // (circuit type, stage) -> batch-compatibility class of that stage's circuit
   int cls(const QueueEntry &e) const { return e.stage < 0 ? -2 : stage_class[e.job.circuit_type][e.stage < 8 ? e.stage : 7]; }
+  size_t dry_stark_stages = 0;         // --dry-run --stark-log-rows: STARK stages that went through the queue
   bool stark_stage = false;            // --stark-log-rows: a sighash job enters the queue at stage -1 = its STARK (a unit of its own: the
                                        // three of a block go to three workers instead of one after the other on whoever took the jobs)
   size_t n_workers = 1;                // threads draining the queue
@@ -533,9 +534,15 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
   auto t_first = [&](size_t i) { return batch[i].t_first > 0 ? batch[i].t_first : t0; };  // when the job's first stage started
   if (batch[0].stage < 0) {  // the STARK of a sighash job (sighash.rs:132-146): proved, then the job goes on with its first plonky2 proof
     for (const auto &e : batch) {
-      if (!worker || !worker->has_stark) throw std::runtime_error("a STARK stage was scheduled without a STARK prover");
-      worker->stark_bytes += worker->stark.prove(worker->ctx, (uint64_t)e.job.goal_id * 16 + e.job.task_index);
-      worker->stark_proofs++;
+      if (opt.dry_run) {  // the schedule alone: the stage takes the dry run's job time, five times over (a STARK is the longest unit)
+        if (opt.dry_job_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(5 * opt.dry_job_us));
+        std::lock_guard<std::mutex> l(S.m);
+        S.dry_stark_stages++;
+      } else {
+        if (!worker || !worker->has_stark) throw std::runtime_error("a STARK stage was scheduled without a STARK prover");
+        worker->stark_bytes += worker->stark.prove(worker->ctx, (uint64_t)e.job.goal_id * 16 + e.job.task_index);
+        worker->stark_proofs++;
+      }
       S.requeue({e.inst, e.job, e.chain > 0 ? e.chain - 1 : 0, 0, t0});
     }
     return;
@@ -666,9 +673,9 @@ void process_batch(const Options &opt, Scheduler &S, Worker *worker, const Share
   for (size_t i = 0; i < batch.size(); i++) finish(i);
 }
 
-void worker_loop(const Options &opt, Scheduler &S, Worker *worker, const Shared &shared, size_t take, std::atomic<size_t> *jobs_of_slot) {
+void worker_loop(const Options &opt, Scheduler &S, Worker *worker, const Shared &shared, size_t take, std::atomic<size_t> *jobs_of_slot, int role) {
   std::vector<QueueEntry> batch;
-  while (S.take(take, batch, worker ? worker->role : 0)) {
+  while (S.take(take, batch, role)) {
     try {
       process_batch(opt, S, worker, shared, batch);
       if (jobs_of_slot && batch[0].job.topic == qb::GenerateStandardProof) jobs_of_slot->fetch_add(batch.size());
@@ -841,11 +848,13 @@ int run_qbench(const Options &opt) {
       if (!w.batcher) die(std::string("cp_batcher_create: ") + cp_last_error(nullptr));
     }
   }
-  const size_t n_workers = opt.dry_run ? (opt.devices.empty() ? (size_t)std::max(1, opt.contexts) : opt.devices.size() * (size_t)opt.contexts)
-                                       : workers.size() * per_worker;
+  const size_t n_dev_slots = opt.devices.empty() ? 1 : opt.devices.size();
+  const size_t n_stark_only = (opt.dry_run ? n_dev_slots : devices.size()) * (size_t)opt.stark_contexts;  // the LAST workers
+  const size_t n_workers = opt.dry_run ? n_dev_slots * (size_t)std::max(1, opt.contexts) + n_stark_only : workers.size() * per_worker;
+  auto role_of = [&](size_t w) { return n_stark_only == 0 ? 0 : w >= n_workers - n_stark_only ? 2 : 1; };
 
   Scheduler S;
-  S.stark_stage = !opt.dry_run && opt.stark_log_rows > 0;
+  S.stark_stage = opt.stark_log_rows > 0;
   S.roles = S.stark_stage && opt.stark_contexts > 0;
   if (!opt.dry_run)
     for (int t = 0; t < 256; t++) {
@@ -876,13 +885,13 @@ int run_qbench(const Options &opt) {
       S.enqueue(&inst, leaves[i]);
     };
     S.on_block_complete = start_next;
-    S.n_workers = n_workers - (opt.dry_run ? 0 : devices.size() * (size_t)opt.stark_contexts);  // the workers that share plonky2 launches
+    S.n_workers = n_workers - n_stark_only;  // the workers that share plonky2 launches
     for (int k = 0; k < opt.blocks_in_flight; k++) start_next();
     std::vector<std::thread> threads;
     for (size_t w = 0; w < n_workers; w++)
       threads.emplace_back([&, w] {
         worker_loop(opt, S, opt.dry_run ? nullptr : &workers[w / per_worker], shared,
-                    opt.callers > 0 && !opt.dry_run ? 1 : (size_t)opt.batch, dry_slots ? &slot_jobs[w] : nullptr);
+                    opt.callers > 0 && !opt.dry_run ? 1 : (size_t)opt.batch, dry_slots && w < dry_slots ? &slot_jobs[w] : nullptr, role_of(w));
       });
     for (auto &t : threads) t.join();
     next = instances.size();
@@ -906,11 +915,11 @@ int run_qbench(const Options &opt) {
       S.enqueue(&inst, leaves[i]);
     }
     std::vector<std::thread> threads;
-    S.n_workers = n_workers - (opt.dry_run ? 0 : devices.size() * (size_t)opt.stark_contexts);  // the workers that share plonky2 launches
+    S.n_workers = n_workers - n_stark_only;  // the workers that share plonky2 launches
     for (size_t w = 0; w < n_workers; w++)
       threads.emplace_back([&, w] {
         worker_loop(opt, S, opt.dry_run ? nullptr : &workers[w / per_worker], shared,
-                    opt.callers > 0 && !opt.dry_run ? 1 : (size_t)opt.batch, dry_slots ? &slot_jobs[w] : nullptr);
+                    opt.callers > 0 && !opt.dry_run ? 1 : (size_t)opt.batch, dry_slots && w < dry_slots ? &slot_jobs[w] : nullptr, role_of(w));
       });
     for (auto &t : threads) t.join();
     if (opt.ref_counters && !S.failed && !instances[next]->complete) {
@@ -960,6 +969,7 @@ int run_qbench(const Options &opt) {
     parity += w.parity_checked; groth16_proofs += w.groth16_proofs; launches += w.launches; launched += w.proofs;
     stark_proofs += w.stark_proofs; stark_bytes += w.stark_bytes;
   }
+  stark_proofs += S.dry_stark_stages;
   std::string per_device = "null";
   if (dry_slots) {  // jobs taken by the worker slots of each device
     per_device = "{";
