@@ -279,3 +279,93 @@ def test_stark_prove_bytes_at_the_sha256_stark_width(prover):
     finally:
         for g in gp:
             g.close()
+
+
+def random_map_program(rng, k0, k1, n_public, n_global, n_challenge, inv_cols):
+    """a map program that stores every extended column: products / sums of a few trace columns, publics, globals and round
+    challenges; the columns in `inv_cols` hold an inverse (INV: zero maps to zero)"""
+    m = A.Builder(A.MAP, k0 + k1, n_public=n_public, n_global=n_global, n_challenge=n_challenge, n_out_columns=k1)
+    for j in range(k1):
+        v = m.local(int(rng.integers(0, k0))) if rng.random() < 0.7 else m.next(int(rng.integers(0, k0)))
+        for _ in range(int(rng.integers(0, 3))):
+            kind = int(rng.integers(0, 5))
+            other = (m.local(int(rng.integers(0, k0))) if kind == 0 else m.public(int(rng.integers(0, n_public))) if kind == 1 and n_public else
+                     m.glob(int(rng.integers(0, n_global))) if kind == 2 and n_global else
+                     m.challenge(int(rng.integers(0, n_challenge))) if kind == 3 and n_challenge else m.const(int(rng.integers(1, P, dtype=np.uint64))))
+            v = (m.mul, m.add, m.sub)[int(rng.integers(0, 3))](v, other)
+        if j in inv_cols:
+            v = m.inv(v)
+        m.store(j, v)
+    return m
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_stark_prove_bytes_on_small_random_shapes(prover, seed):
+    """the whole prover == the oracle's on seeded small shapes: with and without an extended round, 1 - 4 alphas, quotient degree
+    bits 1 - 2 at rates 2 - 8, publics / globals / round challenges present or not, one to three steps of every kind in any order,
+    cap heights from 0 up, with and without FRI reduction layers, host and device transcripts, an injected PoW witness."""
+    import cityprover
+    rng = np.random.default_rng(9000 + seed)
+    db = int(rng.integers(3, 9))
+    rb = int(rng.integers(1, 4))
+    q = int(rng.integers(1, min(rb, 2) + 1))
+    na = int(rng.integers(1, 5))
+    k0 = int(rng.integers(1, 12))
+    k1 = 0 if seed % 3 == 0 else 3 * int(rng.integers(1, 4))
+    n_pub, n_glob = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+    n_rch = int(rng.integers(1, 4)) if k1 else 0
+    ch = int(rng.integers(0, min(db + rb, 4) + 1))
+    cons = A.random_program(seed + 50, k0 + k1, int(rng.integers(30, 400)), n_public=n_pub, n_global=n_glob, n_challenge=n_rch, max_degree=(1 << q) + 1)
+    steps_g, steps_o, progs = [], [], []
+    gcons, ocons = cons.gpu(prover), cons.oracle()
+    progs.append(gcons)
+    if k1:
+        kinds = ["map"] + [("cubic_inverse", "prefix_sum", "map")[int(x)] for x in rng.integers(0, 3, int(rng.integers(0, 3)))]
+        for kind in kinds:
+            if kind == "map":
+                m = random_map_program(rng, k0, k1, n_pub, n_glob, n_rch, set(int(x) for x in rng.integers(0, k1, 2)))
+                g, o = m.gpu(prover), m.oracle()
+                progs.append(g)
+                steps_g.append(("map", g))
+                steps_o.append(("map", o))
+            elif kind == "cubic_inverse":
+                cnt = int(rng.integers(1, k1 // 3 + 1))
+                first = 3 * int(rng.integers(0, k1 // 3 - cnt + 1))
+                st = ("cubic_inverse", first, cnt, A.CUBIC_MODULUS if rng.random() < 0.5 else (int(rng.integers(1, P, dtype=np.uint64)), int(rng.integers(0, P, dtype=np.uint64))))
+                steps_g.append(st)
+                steps_o.append(st)
+            else:
+                cnt = int(rng.integers(1, k1 + 1))
+                st = ("prefix_sum", int(rng.integers(0, k1 - cnt + 1)), cnt, bool(rng.integers(0, 2)))
+                steps_g.append(st)
+                steps_o.append(st)
+    arity = ()
+    d = db
+    while d > 3 and d + rb - 2 >= ch and rng.random() < 0.7 and len(arity) < 3:
+        a = int(rng.integers(1, 3))
+        if d - a < 1 or d - a + rb < ch:
+            break
+        arity += (a,)
+        d -= a
+    pow_bits, nq = int(rng.integers(0, 9)), int(rng.integers(1, 12))
+    gd, gk = cityprover.stark_desc(db, q, na, cityprover.fri_params(db, rb, ch, pow_bits, nq, arity), k0, gcons, k1, n_rch, n_public=n_pub, n_global=n_glob, steps=steps_g)
+    od, okk = O.stark_desc(db, q, na, O.fri_params(db, rb, ch, pow_bits, nq, arity), k0, ocons, k1, n_rch, n_public=n_pub, n_global=n_glob, steps=steps_o)
+    trace = rng.integers(0, P, (k0, 1 << db), dtype=np.uint64)
+    pub = rng.integers(0, P, n_pub, dtype=np.uint64)
+    glob = rng.integers(0, P, n_glob, dtype=np.uint64)
+    prefix = rng.integers(0, P, int(rng.integers(0, 11)), dtype=np.uint64)
+    prover.set_device_transcript(seed % 2)
+    try:
+        for pow_override in (None, 12345):
+            oc, gc = O.challenger_new(), cityprover.ChallengerState()
+            if prefix.size:
+                O.challenger_observe(oc, prefix)
+                gc.observe(prefix)
+            want = O.stark_prove(od, trace, oc, publics=pub, globals_=glob, pow_override=pow_override)
+            got = cityprover.stark_prove(prover, gd, trace, gc, publics=pub if n_pub else None, globals_=glob if n_glob else None, pow_override=pow_override)
+            assert got == want, (db, rb, q, na, k0, k1, ch, arity, [s[0] for s in steps_g])
+            assert gc.as_tuple() == O.challenger_tuple(oc)
+    finally:
+        prover.set_device_transcript(-1)
+        for g in progs:
+            g.close()
