@@ -308,6 +308,56 @@ GL_HD void mds_layer_d(uint64_t (&s)[W], int next_rc_base) {
   for (int i = 0; i < W; i++) s[i] = recombine_d(yl[i], yh[i], rcd(next_rc_base >= 0 ? next_rc_base + i : ROUNDS * W));
 }
 
+// ---- the scaled layer two deep (partial_rounds): constants derived from dom_mul_d<true> at compile time ------------------------
+template <int N> struct DomMat { double a[N][N]; };
+template <int N> constexpr DomMat<N> dom_mat_sq(const DomMat<N> &m) {
+  DomMat<N> r{};
+  for (int i = 0; i < N; i++)
+    for (int j = 0; j < N; j++) {
+      double acc = 0;
+      for (int k = 0; k < N; k++) acc += m.a[i][k] * m.a[k][j];
+      r.a[i][j] = acc;
+    }
+  return r;
+}
+// the blocks of the scaled layer K as matrices (rows: products, columns: inputs): aa = 64 (J + P), P: row i takes column (i + 2) % 3
+constexpr DomMat<3> DOM_K_AB = {{{-4, -8, 32}, {-32, -4, -8}, {8, -32, -4}}};
+constexpr DomMat<6> DOM_K_B = {{{4, 2, 2, -2, -32, 8}, {-8, 4, 2, 2, -2, -32}, {32, -8, 4, 2, 2, -2},
+                                {2, 32, -8, 4, 2, 2}, {-2, 2, 32, -8, 4, 2}, {-2, -2, 2, 32, -8, 4}}};
+constexpr DomMat<3> DOM_K_AB2 = dom_mat_sq(DOM_K_AB);
+constexpr DomMat<6> DOM_K_B2 = dom_mat_sq(DOM_K_B);
+// l K: element 0 of the NEXT layer read off this layer's inputs (rows 0, 3, 6 of K)
+GL_HD double dom_next_z(const double (&u)[W]) {
+  constexpr double CZ[W] = {64, 64, 128, -4, -8, 32, 4, 2, 2, -2, -32, 8};
+  double acc = u[0] * CZ[0];
+#pragma unroll
+  for (int k = 1; k < W; k++) acc = __builtin_fma(u[k], CZ[k], acc);
+  return acc;
+}
+// o = K^2 u + d K t   (K t = columns 0 of the blocks of K over (4, 4, 2): a change d of element 0, one layer on)
+GL_HD void dom_mul2_d(const double (&u)[W], double d, double (&o)[W]) {
+  constexpr double KT[W] = {16, 32, 16, -1, -8, 2, 2, -4, 16, 1, -1, -1};
+  // aa: (64 (J + P))^2 = 4096 (5 J + P^2), P^2: row i takes column (i + 1) % 3
+  const double t = (u[0] + u[1] + u[2]) * 20480.0;
+  o[0] = __builtin_fma(u[1], 4096.0, __builtin_fma(d, KT[0], t));
+  o[1] = __builtin_fma(u[2], 4096.0, __builtin_fma(d, KT[1], t));
+  o[2] = __builtin_fma(u[0], 4096.0, __builtin_fma(d, KT[2], t));
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double acc = d * KT[3 + k];
+#pragma unroll
+    for (int j = 0; j < 3; j++) acc = __builtin_fma(u[3 + j], DOM_K_AB2.a[k][j], acc);
+    o[3 + k] = acc;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double acc = d * KT[6 + k];
+#pragma unroll
+    for (int j = 0; j < 6; j++) acc = __builtin_fma(u[6 + j], DOM_K_B2.a[k][j], acc);
+    o[6 + k] = acc;
+  }
+}
+
 // The 22 partial rounds with the MDS layers on either side of them. s in: the S-box OUTPUTS of the last full round before
 // them (round 3); s out: the state entering the S-boxes of the first full round after them (round 26), constants included.
 // `input(i, x)` sees the S-box input x (lazy u64) of partial round i on element 0 and returns what goes into the S-box — x
@@ -330,6 +380,16 @@ GL_HD bool partial_rounds(uint64_t (&s)[W], Input input, Stop stop) {
     dom_mul_d<false>(wl, ol);
     dom_mul_d<false>(wh, oh);
   }
+  // TWO partial rounds per trip, with ONE application of the layer squared. Let W = (E, F, v) be the products at the top of round r,
+  // K the scaled layer (dom_mul_d<true>), t = (1/4, 0, 0 | 1/4, 0, 0 | 1/2, 0, ...) what a change of element 0 is in the domain and
+  // l = e_0 + e_3 + e_6 the functional that reads element 0 off the products. Round r: z = l W, S-box, W' = W + (new - z) t. Round r + 1
+  // needs only ELEMENT 0 of the next layer — z' = l K W' = <CZ, W'>, twelve multiply-adds instead of the 51 operations of the whole
+  // layer — and then W'' = K (K W' + (new' - z') t) = K^2 W' + (new' - z') K t: the squared layer costs what one layer costs (its
+  // blocks are dense already: 6 + 9 + 36), so a trip is 12 + 51 + 12 operations per plane where two layers were 102. K^2 grows a limb
+  // by at most 2^16 (aa: 4096 (5 J + P^2), rows sum to 2^16), which is the two layers of growth a limb was normalised for anyway:
+  // one renorm per trip as before, now in front of the squared layer. Magnitudes (tests/test_hostsim.py replays them): W at the top of
+  // a trip is below 2^47.3 with no fractional bits, z below 2^48.9.
+#if defined(POSEIDON_PARTIAL_V1)  // one layer per round (rounds 2-3 of the build): kept for the A/B in tools/ubench_poseidon_variants.hip
   // one partial round: read element 0 off the products (a), S-box it, put it back (W = (E, F, v) + (new - z) / (4, 4, 2) on
   // aa0, ab0, b0, in place), optionally normalise, next products (a -> b). Two rounds per trip, ping-pong, so nothing is copied.
   auto round = [&](int i, double (&al)[W], double (&ah)[W], double (&bl)[W], double (&bh)[W], bool normalise) {
@@ -363,6 +423,48 @@ GL_HD bool partial_rounds(uint64_t (&s)[W], Input input, Stop stop) {
   yl[0] = __builtin_fma(nl, 8.0, yl[0]), yh[0] = __builtin_fma(nh, 8.0, yh[0]);
 #pragma unroll
   for (int k = 0; k < W; k++) s[k] = recombine_d(yl[k], yh[k], domd_last(k));
+#else
+  auto trip = [&](int i, double (&al)[W], double (&ah)[W], double (&bl)[W], double (&bh)[W]) {
+    // round i: element 0 = E0 + F0 + v0 + the diagonal 8 of the MDS on the previous S-box output
+    {
+      const double zl = al[0] + al[3] + al[6], zh = ah[0] + ah[3] + ah[6];
+      const uint64_t x = sbox_lazy(input(i, recombine_d(__builtin_fma(nl, 8.0, zl), __builtin_fma(nh, 8.0, zh), domd_k(i))));
+      nl = (double)(uint32_t)x;
+      nh = (double)(uint32_t)(x >> 32);
+      const double dl = nl - zl, dh = nh - zh;
+      al[0] = __builtin_fma(dl, 0.25, al[0]), ah[0] = __builtin_fma(dh, 0.25, ah[0]);
+      al[3] = __builtin_fma(dl, 0.25, al[3]), ah[3] = __builtin_fma(dh, 0.25, ah[3]);
+      al[6] = __builtin_fma(dl, 0.5, al[6]), ah[6] = __builtin_fma(dh, 0.5, ah[6]);
+    }
+#pragma unroll
+    for (int k = 0; k < W; k++) renorm_d(al[k], ah[k]);
+    // round i + 1: element 0 one layer ahead, then the squared layer with the change of element 0 carried one layer on (a -> b)
+    const double zl = dom_next_z(al), zh = dom_next_z(ah);
+    const uint64_t x = sbox_lazy(input(i + 1, recombine_d(__builtin_fma(nl, 8.0, zl), __builtin_fma(nh, 8.0, zh), domd_k(i + 1))));
+    nl = (double)(uint32_t)x;
+    nh = (double)(uint32_t)(x >> 32);
+    dom_mul2_d(al, nl - zl, bl);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);  // one plane after the other: interleaved, the four arrays are live at once and the leaf hash (96 registers) spills
+#endif
+    dom_mul2_d(ah, nh - zh, bh);
+  };
+  static_assert(PARTIAL % 4 == 2, "five double trips (ping-pong, nothing is copied) and a last single one");
+#pragma unroll 1
+  for (int i = 0; i + 4 <= PARTIAL; i += 4) {
+    if (stop()) return false;
+    trip(i, ol, oh, wl, wh);
+    trip(i + 2, wl, wh, ol, oh);
+  }
+  trip(PARTIAL - 2, ol, oh, wl, wh);
+  // leave the domain: natural limbs, + what is pending of the constants
+  double yl[W], yh[W];
+  dom_leave_d(wl, yl);
+  dom_leave_d(wh, yh);
+  yl[0] = __builtin_fma(nl, 8.0, yl[0]), yh[0] = __builtin_fma(nh, 8.0, yh[0]);
+#pragma unroll
+  for (int k = 0; k < W; k++) s[k] = recombine_d(yl[k], yh[k], domd_last(k));
+#endif
   return true;
 }
 struct SameInput {

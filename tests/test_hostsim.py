@@ -180,20 +180,27 @@ def test_double_precision_magnitudes(hs):
     hs.hs_recombine_d.restype = ctypes.c_uint64
     hs.hs_recombine_d.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_uint64]
     lim = (1 << 31) + (1 << 20)                    # a normalised limb (test above)
-    grow = max(64 + 64 + 128, 4 + 32 + 8, 2 * (2 + 4 + 16 + 1 + 1 + 1))    # one scaled layer: aa 256, ab 44, b 50
-    zsum = 256 + 44 + 50                           # element 0 = E0 + F0 + v0
     n = 1 << 32                                    # a limb of an S-box output
-    # entry from the full rounds: limbs < 2^32, T sums four, the unscaled products multiply by at most 64
+    # The partial rounds go two per trip (poseidon.h partial_rounds): W = (E, F, v) at the top of a trip is the output of the first
+    # layer (entry from the full rounds: limbs < 2^32, T sums four, the unscaled products multiply by at most 64) or of a SQUARED scaled
+    # layer; element 0 is read off it (three entries), the change goes in with a factor <= 1/2, W is normalised, element 0 of the next
+    # layer is a 12-term dot product with l K (sum of |coefficients| 350), and the squared layer (rows sum to at most 2^16: aa =
+    # 4096 (5 J + P^2)) plus the second change times K t (entries <= 32) gives the next W.
+    cz = 64 + 64 + 128 + 4 + 8 + 32 + 4 + 2 + 2 + 2 + 32 + 8
+    k2 = max(4096 * 16, (4 + 8 + 32) ** 2, (2 * (2 + 4 + 16 + 1 + 1 + 1)) ** 2)
+    kt = 32
+    assert cz == 350 and k2 == 1 << 16
     x = 64 * 4 * n
-    for rnd in range(22):                          # x bounds the limbs of W = (E, F, v) at the top of round `rnd`
-        z = zsum * (x // grow) + 8 * n             # element 0 from the layer's INPUT bound (x = grow * input) + the diagonal
-        assert z < 1 << 51                         # recombine_d
-        w = x + (n + z)                            # + (new - z) / 4 (bounded by |new - z|)
+    for trip in range(11):                         # x bounds the limbs of W at the top of the trip (integers)
+        z = 3 * x + 8 * n                          # element 0 + the diagonal
+        assert z < (1 << 51) - (1 << 32)           # recombine_d
+        w = x + (n + z)                            # + (new - z) / 4, / 2 (bounded by |new - z|)
         assert w * 4 < 1 << 53                     # two fractional bits
-        if rnd & 1:
-            w = lim
-        x = grow * w
-    assert x * 4 < 1 << 53 and 4 * x + 8 * n < 1 << 51       # leaving: natural limbs (T^-1' adds four products) + diagonal
+        z2 = cz * lim + 8 * n                      # one layer ahead, from the normalised W
+        assert z2 < (1 << 51) - (1 << 32)
+        x = k2 * lim + kt * (n + z2)               # the squared layer + the second change one layer on: integers again
+        assert x < 1 << 53
+    assert 4 * x + 8 * n < (1 << 51) - (1 << 32)   # leaving: natural limbs (T^-1' adds four products) + diagonal
     # the conversion itself at its limits, against exact integers
     for l, h, c in ((0, 0, 0), ((1 << 51) - (1 << 32) - 1, (1 << 51) - (1 << 32) - 1, P - 1), (-(1 << 51) + 1, -(1 << 51) + 1, 5), (-1, 0, 0), (0, -1, 0),
                     (123456789012345, -98765432109876, 0xFFFFFFFF00000000)):
