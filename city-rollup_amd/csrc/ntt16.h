@@ -72,8 +72,14 @@ GL_HD void stage(uint64_t (&x)[16], uint64_t T) {
 }
 
 // NSTAGES DIF stages on the top bits of the 4-bit register field. T3 = omega_{2^(f+4)}^(r_lo).
+// The thread-uniform factor of stage B is T_B = T3^(2^(3-B)), and it multiplies ALL the differences of its stage: every later butterfly
+// pairs two values that carry the same T_B, so the factor commutes with the rest of the round. The stages therefore run with their
+// shift twiddles only, and register m is multiplied ONCE at the end by T3^e(m), e(m) = sum over the round's stages of m_B 2^(3-B) —
+// the powers T3^1 .. T3^(2^NSTAGES - 1) walked in order by one lazy product each: 14 + 15 products for four stages where the
+// factor-per-stage form took 3 squarings + 32 (NTT16_STAGE_TWIDDLES restores it for the A/B). Same field elements, bit for bit.
 template <bool INV, int NSTAGES, bool UNIT_T>
 GL_HD void round16(uint64_t (&x)[16], uint64_t T3) {
+#if defined(NTT16_STAGE_TWIDDLES)
   uint64_t T2 = UNIT_T ? 1 : gl::sqr(T3);
   stage<INV, 3, UNIT_T>(x, T3);
   if constexpr (NSTAGES >= 2) {
@@ -87,6 +93,29 @@ GL_HD void round16(uint64_t (&x)[16], uint64_t T3) {
       stage<INV, 0, UNIT_T>(x, T0);
     }
   }
+#else
+  stage<INV, 3, true>(x, 1);
+  if constexpr (NSTAGES >= 2) stage<INV, 2, true>(x, 1);
+  if constexpr (NSTAGES >= 3) stage<INV, 1, true>(x, 1);
+  if constexpr (NSTAGES >= 4) stage<INV, 0, true>(x, 1);
+  if constexpr (!UNIT_T) {
+    uint64_t pw = T3;  // T3^e, lazy from the second on (a product takes any u64)
+#pragma unroll
+    for (int e = 1; e < (1 << NSTAGES); e++) {
+      if (e > 1) {
+        uint64_t lo, hi;
+        gl::mul_wide(pw, T3, lo, hi);
+        pw = gl::reduce128_lazy(lo, hi);
+      }
+#pragma unroll
+      for (int m = 0; m < 16; m++) {
+        int em = 0;  // e(m): bit B of m (B = 3 .. 4 - NSTAGES) weighs 2^(3 - B)
+        for (int B = 3; B >= 4 - NSTAGES; B--) em += ((m >> B) & 1) << (3 - B);
+        if (em == e) x[m] = gl::mul(x[m], pw);
+      }
+    }
+  }
+#endif
 }
 
 constexpr int LOG_TILE = 12;
