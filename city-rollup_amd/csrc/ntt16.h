@@ -257,7 +257,11 @@ __global__ __launch_bounds__(THREADS, (HALF && !(L == 4 && !ROWS)) ? NTT16_MIN_W
         for (int j = 0; j < 16; j++) {
           const int m = ((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3);
           x[m] = gl::mul(x[m], w);
-          if (j < 15) w = gl::mul(w, G);
+          if (j < 15) {  // the running power stays lazy: a product takes any u64
+            uint64_t wl, wh;
+            gl::mul_wide(w, G, wl, wh);
+            w = gl::reduce128_lazy(wl, wh);
+          }
         }
       }
     }
